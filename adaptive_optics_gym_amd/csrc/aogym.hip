@@ -1,0 +1,522 @@
+// libaogym.so — C-ABI (include/aogym.h) over the gfx950 kernels in aogym_kernels.h.
+// Host side only: argument checking, table conversion/upload, launch geometry, stream-ordered launches.
+#include "../../include/aogym.h"
+#include "aogym_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e__ = (expr);                                                                       \
+    if (e__ != hipSuccess)                                                                         \
+      return fail(AOG_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+  } while (0)
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+}  // namespace
+
+struct aog_env {
+  aog_config cfg{};
+  int device = 0;
+  bool tables_ready = false;
+  bool screens_ready = false;
+  int B = 0, Bp = 0, A = 0, A_pad = 0, n_ap = 0, n_ap_pad = 0, n_quads = 0, n_ptiles = 0, n_etiles = 0;
+  int MRW = 0, MRS = 0;          // padded table counts of the fast kernels
+  int MRW_used = 0, MRS_used = 0;
+  int n_obs = 0, n_out = 0;
+  int kernel = AOG_KERNEL_VALU;  // resolved
+  int sincos_hw = 0;
+  // launch geometry
+  int valu_chunks = 0, valu_qpc = 0;
+  int mfma_we = 1, mfma_chunks_x = 0, mfma_tpc = 0;
+  int n_chunks = 0;              // partial slabs the epilogue sums
+  int64_t dev_bytes = 0;
+  // constant tables
+  int32_t* ap_index = nullptr;
+  float* modes_f32 = nullptr;    // [n_ap_pad][A_pad]
+  float* modes_tile = nullptr;   // [n_ptiles][A_pad/8][64][4]
+  float* tabs_f32 = nullptr;     // [n_ap_pad][TROW]
+  float* tabs_tile = nullptr;    // [n_ptiles][4][2][MRW+MRS][4]
+  double* gram = nullptr;        // [A][A]
+  double* wfs_coef = nullptr;    // [n_out][MRW_used][2]
+  double* sci_coef = nullptr;    // [MRS_used][2]
+  double* modes64 = nullptr;     // validation: [n_ap][A]
+  double* tabs64 = nullptr;      // validation: [n_ap][MRW_used+MRS_used]
+  // state
+  float* psi_rev = nullptr;      // [n_quads][Bp][4]
+  float* psi_tile = nullptr;     // [Bp/32][n_ptiles][4][64][4]
+  double* psi64 = nullptr;       // validation: [B][n_ap]
+  double* act_dm = nullptr;      // [B][A]
+  float* act_rev = nullptr;      // [A_pad][Bp]
+  float* act_tile = nullptr;     // [Bp/32][A_pad][32]
+  int32_t* t_render = nullptr;   // [B]
+  double* partials = nullptr;
+  size_t partial_elems = 0;
+  // profiling of the fused kernel
+  bool profile = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  size_t events_used = 0;
+  std::vector<void*> allocs;
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(aog_env* e, T** out, size_t count, bool zero = true) {
+  void* p = nullptr;
+  const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+  HIP_TRY(hipMalloc(&p, bytes));
+  if (zero) HIP_TRY(hipMemset(p, 0, bytes));
+  e->allocs.push_back(p);
+  e->dev_bytes += (int64_t)bytes;
+  *out = static_cast<T*>(p);
+  return AOG_OK;
+}
+
+int pick_pad(int v, const int* opts, int n) {
+  for (int i = 0; i < n; ++i)
+    if (v <= opts[i]) return opts[i];
+  return -1;
+}
+
+const int kApadOpts[] = {8, 16, 32, 64, 128};
+const int kMrwOpts[] = {8, 12, 20, 28};
+
+// ---- fused kernel dispatch -------------------------------------------------------------------------
+template <int A_PAD, int MRW, int SC>
+void launch_valu(aog_env* e, hipStream_t s) {
+  const int n_groups = e->Bp / 64;
+  dim3 grid(e->valu_chunks, (n_groups + 3) / 4);
+  const float ratio = (float)(e->cfg.wavelength_wfs / e->cfg.wavelength_sci);
+  hipLaunchKernelGGL((aog::k_fused_valu<A_PAD, MRW, 1, SC>), grid, dim3(256), 0, s, e->modes_f32, e->tabs_f32,
+                     reinterpret_cast<const float4*>(e->psi_rev), e->act_rev, e->partials, e->n_quads, e->Bp, n_groups,
+                     e->valu_qpc, ratio);
+}
+
+template <int A_PAD, int MRW, int SC>
+void launch_mfma(aog_env* e, hipStream_t s) {
+  dim3 grid(e->mfma_chunks_x, (e->n_etiles + e->mfma_we - 1) / e->mfma_we);
+  const float ratio = (float)(e->cfg.wavelength_wfs / e->cfg.wavelength_sci);
+  const size_t lds = (size_t)e->mfma_tpc * 8 * (MRW + 1) * 16;
+  hipLaunchKernelGGL((aog::k_fused_mfma<A_PAD, MRW, 1, SC>), grid, dim3(256), lds, s,
+                     reinterpret_cast<const aog::f32x4*>(e->modes_tile), reinterpret_cast<const aog::f32x4*>(e->tabs_tile),
+                     reinterpret_cast<const aog::f32x4*>(e->psi_tile), e->act_tile, e->partials, e->n_ptiles, e->n_etiles,
+                     e->Bp, e->mfma_tpc, e->mfma_we, ratio);
+}
+
+template <int A_PAD, int MRW>
+void launch_fast2(aog_env* e, hipStream_t s) {
+  if (e->kernel == AOG_KERNEL_MFMA) {
+    if (e->sincos_hw) launch_mfma<A_PAD, MRW, 1>(e, s); else launch_mfma<A_PAD, MRW, 0>(e, s);
+  } else {
+    if (e->sincos_hw) launch_valu<A_PAD, MRW, 1>(e, s); else launch_valu<A_PAD, MRW, 0>(e, s);
+  }
+}
+
+template <int A_PAD>
+void launch_fast1(aog_env* e, hipStream_t s) {
+  switch (e->MRW) {
+    case 8: launch_fast2<A_PAD, 8>(e, s); break;
+    case 12: launch_fast2<A_PAD, 12>(e, s); break;
+    case 20: launch_fast2<A_PAD, 20>(e, s); break;
+    default: launch_fast2<A_PAD, 28>(e, s); break;
+  }
+}
+
+void launch_fast(aog_env* e, hipStream_t s) {
+  switch (e->A_pad) {
+    case 8: launch_fast1<8>(e, s); break;
+    case 16: launch_fast1<16>(e, s); break;
+    case 32: launch_fast1<32>(e, s); break;
+    case 64: launch_fast1<64>(e, s); break;
+    default: launch_fast1<128>(e, s); break;
+  }
+}
+
+int launch_fused(aog_env* e, hipStream_t s) {
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (e->profile) {
+    if (e->events_used == e->events.size()) {
+      HIP_TRY(hipEventCreate(&ev0));
+      HIP_TRY(hipEventCreate(&ev1));
+      e->events.emplace_back(ev0, ev1);
+    }
+    ev0 = e->events[e->events_used].first;
+    ev1 = e->events[e->events_used].second;
+    ++e->events_used;
+    HIP_TRY(hipEventRecord(ev0, s));
+  }
+  if (e->cfg.precision == AOG_PRECISION_FP64) {
+    hipLaunchKernelGGL(aog::k_fused_ref, dim3(e->B), dim3(256), 0, s, e->modes64, e->tabs64, e->psi64, e->act_dm,
+                       e->partials, e->n_ap, e->A, e->MRW_used, e->MRS_used, e->Bp, e->cfg.wavelength_wfs,
+                       e->cfg.wavelength_sci);
+  } else {
+    launch_fast(e, s);
+  }
+  HIP_TRY(hipGetLastError());
+  if (e->profile) HIP_TRY(hipEventRecord(ev1, s));
+  return AOG_OK;
+}
+
+int launch_epilogue(aog_env* e, bool is_step, float* obs_raw, uint16_t* obs, float* reward, uint8_t* done, float* power,
+                    float* strehl, hipStream_t s) {
+  aog::EpilogueArgs p{};
+  p.partials = e->partials;
+  p.wfs_coef = e->wfs_coef;
+  p.sci_coef = e->sci_coef;
+  p.obs_raw = obs_raw;
+  p.obs = obs;
+  p.reward = reward;
+  p.done = done;
+  p.power = power;
+  p.strehl = strehl;
+  p.t_render = e->t_render;
+  p.B = e->B;
+  p.Bp = e->Bp;
+  const bool ref = e->cfg.precision == AOG_PRECISION_FP64;
+  p.n_chunks = ref ? 1 : e->n_chunks;
+  p.MRW = ref ? e->MRW_used : e->MRW;
+  p.MRS = ref ? e->MRS_used : e->MRS;
+  p.MRW_used = e->MRW_used;
+  p.MRS_used = e->MRS_used;
+  p.n_obs = e->n_obs;
+  p.n_fiber = e->cfg.n_fiber_modes;
+  p.reward_type = e->cfg.reward_type;
+  p.has_thr = e->cfg.has_rew_threshold;
+  p.max_steps = e->cfg.max_steps;
+  p.is_step = is_step ? 1 : 0;
+  p.thr = e->cfg.rew_threshold;
+  p.ssim_peak = e->cfg.ssim_ref_peak;
+  p.ssim_alpha = e->cfg.ssim_alpha;
+  hipLaunchKernelGGL(aog::k_epilogue, dim3((e->B + 63) / 64), dim3(64), 0, s, p);
+  HIP_TRY(hipGetLastError());
+  return AOG_OK;
+}
+
+template <typename T>
+int set_screens(aog_env* e, const T* psi, int first, int count, hipStream_t s) {
+  if (!e || !psi) return fail(AOG_ERR_INVALID, "aog_set_screens: null argument");
+  if (!e->tables_ready) return fail(AOG_ERR_STATE, "aog_set_screens before aog_upload_tables");
+  if (first < 0 || count < 0 || first + count > e->B)
+    return fail(AOG_ERR_INVALID, "aog_set_screens: env range [%d,%d) outside [0,%d)", first, first + count, e->B);
+  if (count == 0) return AOG_OK;
+  HIP_TRY(hipSetDevice(e->device));
+  const double inv = 1.0 / (2.0 * M_PI * e->cfg.wavelength_wfs);
+  hipLaunchKernelGGL((aog::k_pack_screens<T>), dim3(count), dim3(256), 0, s, psi, e->ap_index, e->psi_rev, e->psi_tile,
+                     e->psi64, first, e->cfg.n_pupil * e->cfg.n_pupil, e->n_ap, e->n_ap_pad, e->Bp, inv);
+  HIP_TRY(hipGetLastError());
+  e->screens_ready = true;
+  return AOG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int aog_abi_version(void) { return AOG_ABI_VERSION; }
+
+const char* aog_last_error(void) { return g_last_error.c_str(); }
+
+int aog_create(const aog_config* cfg, int device, aog_env** out) {
+  if (!cfg || !out) return fail(AOG_ERR_INVALID, "aog_create: null argument");
+  *out = nullptr;
+  if (cfg->abi_version != AOG_ABI_VERSION)
+    return fail(AOG_ERR_INVALID, "aog_create: abi_version %d != %d", cfg->abi_version, AOG_ABI_VERSION);
+  if (cfg->num_envs < 1 || cfg->n_pupil < 2 || cfg->n_modes < 1 || cfg->obs_dim < 1 || cfg->n_ap < 1 ||
+      cfg->n_ap > cfg->n_pupil * cfg->n_pupil)
+    return fail(AOG_ERR_INVALID, "aog_create: bad sizes (B=%d N=%d A=%d o=%d n_ap=%d)", cfg->num_envs, cfg->n_pupil,
+                cfg->n_modes, cfg->obs_dim, cfg->n_ap);
+  if (cfg->n_wfs_tables < 1 || cfg->n_sci_tables < 1 || cfg->n_fiber_modes < 0)
+    return fail(AOG_ERR_INVALID, "aog_create: bad table counts");
+  if (cfg->reward_type != AOG_REWARD_STREHL && cfg->reward_type != AOG_REWARD_SMF_SSIM)
+    return fail(AOG_ERR_INVALID, "aog_create: reward_type must be 'strehl_ratio' or 'smf_ssim' (AO_env.py:476,487)");
+  if (cfg->obs_dim * cfg->obs_dim > 64) return fail(AOG_ERR_UNSUPPORTED, "aog_create: obs_dim > 8 not built");
+  if (cfg->n_modes > 256) return fail(AOG_ERR_UNSUPPORTED, "aog_create: act_dim > 256 not built");
+  if (cfg->n_wfs_tables + cfg->n_sci_tables > 80) return fail(AOG_ERR_UNSUPPORTED, "aog_create: > 80 tables");
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail(AOG_ERR_HIP, "aog_create: device %d not present (%d HIP devices)", device, ndev);
+  HIP_TRY(hipSetDevice(device));
+
+  aog_env* e = new aog_env();
+  e->cfg = *cfg;
+  e->device = device;
+  e->B = cfg->num_envs;
+  e->Bp = round_up(e->B, 64);
+  e->A = cfg->n_modes;
+  e->n_ap = cfg->n_ap;
+  e->n_ap_pad = round_up(e->n_ap, 32);
+  e->n_quads = e->n_ap_pad / 4;
+  e->n_ptiles = e->n_ap_pad / 32;
+  e->n_etiles = e->Bp / 32;
+  e->MRW_used = cfg->n_wfs_tables;
+  e->MRS_used = cfg->n_sci_tables;
+  e->n_obs = cfg->obs_dim * cfg->obs_dim;
+  e->n_out = e->n_obs + cfg->n_fiber_modes;
+  e->sincos_hw = 0;
+  if (const char* sc = getenv("AOG_SINCOS")) e->sincos_hw = (strcmp(sc, "hw") == 0) ? 1 : 0;
+
+  if (cfg->precision == AOG_PRECISION_FAST) {
+    e->A_pad = pick_pad(e->A, kApadOpts, 5);
+    e->MRW = pick_pad(e->MRW_used, kMrwOpts, 4);
+    e->MRS = 1;
+    if (e->A_pad < 0 || e->MRW < 0 || e->MRS_used != 1) {
+      delete e;
+      return fail(AOG_ERR_UNSUPPORTED,
+                  "aog_create: fast kernels are built for act_dim <= 128, <= 28 wfs tables and 1 science table; "
+                  "use AOG_PRECISION_FP64 for this shape");
+    }
+    e->kernel = cfg->kernel == AOG_KERNEL_AUTO ? AOG_KERNEL_MFMA : cfg->kernel;
+    if (e->kernel == AOG_KERNEL_MFMA && e->A_pad > 64) e->kernel = AOG_KERNEL_VALU;
+    // launch geometry: aim at ~3 (VALU) / ~2 (MFMA) waves per SIMD over 256 CUs
+    const int n_groups = e->Bp / 64;
+    int P = cfg->pixel_chunks > 0 ? cfg->pixel_chunks : std::max(1, (256 * 4 * 3 + n_groups - 1) / n_groups);
+    int qpc = round_up((e->n_quads + P - 1) / P, 8);
+    e->valu_qpc = qpc;
+    e->valu_chunks = (e->n_quads + qpc - 1) / qpc;
+    e->mfma_we = e->n_etiles >= 4 ? 4 : (e->n_etiles >= 2 ? 2 : 1);
+    const int wp = 4 / e->mfma_we;
+    const int wg_y = (e->n_etiles + e->mfma_we - 1) / e->mfma_we;
+    int Pm = cfg->pixel_chunks > 0 ? cfg->pixel_chunks : std::max(1, (256 * 2 + wg_y - 1) / wg_y);
+    int tpc = std::max(wp, (e->n_ptiles + Pm - 1) / Pm);
+    const int max_tpc = (int)(60 * 1024 / (8 * (e->MRW + 1) * 16));  // keep the table stage <= 60 KiB of LDS
+    tpc = std::min(tpc, std::max(wp, max_tpc));
+    e->mfma_tpc = tpc;
+    e->mfma_chunks_x = (e->n_ptiles + tpc - 1) / tpc;
+    e->n_chunks = e->kernel == AOG_KERNEL_MFMA ? e->mfma_chunks_x * wp : e->valu_chunks;
+  } else {
+    e->A_pad = round_up(e->A, 8);
+    e->MRW = e->MRW_used;
+    e->MRS = e->MRS_used;
+    e->kernel = 0;
+    e->n_chunks = 1;
+  }
+
+  int rc = AOG_OK;
+  const size_t NS = 2 * (size_t)(e->MRW + e->MRS);
+  e->partial_elems = (size_t)e->n_chunks * NS * e->Bp;
+#define TRY_ALLOC(x) if ((rc = (x)) != AOG_OK) { aog_destroy(e); return rc; }
+  TRY_ALLOC(dev_alloc(e, &e->ap_index, e->n_ap));
+  TRY_ALLOC(dev_alloc(e, &e->gram, (size_t)e->A * e->A));
+  TRY_ALLOC(dev_alloc(e, &e->wfs_coef, (size_t)e->n_out * e->MRW_used * 2));
+  TRY_ALLOC(dev_alloc(e, &e->sci_coef, (size_t)e->MRS_used * 2));
+  TRY_ALLOC(dev_alloc(e, &e->act_dm, (size_t)e->B * e->A));
+  TRY_ALLOC(dev_alloc(e, &e->act_rev, (size_t)e->A_pad * e->Bp));
+  TRY_ALLOC(dev_alloc(e, &e->act_tile, (size_t)e->n_etiles * e->A_pad * 32));
+  TRY_ALLOC(dev_alloc(e, &e->t_render, e->B));
+  TRY_ALLOC(dev_alloc(e, &e->partials, e->partial_elems));
+  if (cfg->precision == AOG_PRECISION_FAST) {
+    const int TROW = round_up(e->MRW + e->MRS, 4);
+    TRY_ALLOC(dev_alloc(e, &e->modes_f32, (size_t)e->n_ap_pad * e->A_pad));
+    TRY_ALLOC(dev_alloc(e, &e->modes_tile, (size_t)e->n_ap_pad * e->A_pad));
+    TRY_ALLOC(dev_alloc(e, &e->tabs_f32, (size_t)e->n_ap_pad * TROW));
+    TRY_ALLOC(dev_alloc(e, &e->tabs_tile, (size_t)e->n_ap_pad * (e->MRW + e->MRS)));
+    TRY_ALLOC(dev_alloc(e, &e->psi_rev, (size_t)e->n_quads * e->Bp * 4));
+    TRY_ALLOC(dev_alloc(e, &e->psi_tile, (size_t)e->n_etiles * e->n_ptiles * 1024));
+  } else {
+    TRY_ALLOC(dev_alloc(e, &e->modes64, (size_t)e->n_ap * e->A));
+    TRY_ALLOC(dev_alloc(e, &e->tabs64, (size_t)e->n_ap * (e->MRW_used + e->MRS_used)));
+    TRY_ALLOC(dev_alloc(e, &e->psi64, (size_t)e->B * e->n_ap));
+  }
+#undef TRY_ALLOC
+  *out = e;
+  return AOG_OK;
+}
+
+void aog_destroy(aog_env* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  for (void* p : e->allocs) (void)hipFree(p);
+  for (auto& ev : e->events) {
+    (void)hipEventDestroy(ev.first);
+    (void)hipEventDestroy(ev.second);
+  }
+  delete e;
+}
+
+int aog_get_info(const aog_env* e, aog_info* out) {
+  if (!e || !out) return fail(AOG_ERR_INVALID, "aog_get_info: null argument");
+  memset(out, 0, sizeof *out);
+  out->abi_version = AOG_ABI_VERSION;
+  out->num_envs = e->B;
+  out->num_envs_padded = e->Bp;
+  out->n_ap = e->n_ap;
+  out->n_ap_padded = e->n_ap_pad;
+  out->n_modes_padded = e->A_pad;
+  out->pixel_chunks = e->n_chunks;
+  out->kernel = e->kernel;
+  out->n_sums = 2 * (e->MRW + e->MRS);
+  out->device_bytes = e->dev_bytes;
+  return AOG_OK;
+}
+
+int aog_upload_tables(aog_env* e, const aog_tables* t) {
+  if (!e || !t) return fail(AOG_ERR_INVALID, "aog_upload_tables: null argument");
+  if (!t->ap_index || !t->modes || !t->gram || !t->wfs_tables || !t->sci_tables || !t->wfs_coef || !t->sci_coef)
+    return fail(AOG_ERR_INVALID, "aog_upload_tables: null table pointer");
+  HIP_TRY(hipSetDevice(e->device));
+  const int n_ap = e->n_ap, A = e->A, N2 = e->cfg.n_pupil * e->cfg.n_pupil;
+  for (int p = 0; p < n_ap; ++p) {
+    if (t->ap_index[p] < 0 || t->ap_index[p] >= N2) return fail(AOG_ERR_INVALID, "aog_upload_tables: ap_index[%d] out of range", p);
+    if (p && t->ap_index[p] <= t->ap_index[p - 1]) return fail(AOG_ERR_INVALID, "aog_upload_tables: ap_index must be strictly increasing");
+  }
+  HIP_TRY(hipMemcpy(e->ap_index, t->ap_index, sizeof(int32_t) * n_ap, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->gram, t->gram, sizeof(double) * A * A, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->wfs_coef, t->wfs_coef, sizeof(double) * e->n_out * e->MRW_used * 2, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->sci_coef, t->sci_coef, sizeof(double) * e->MRS_used * 2, hipMemcpyHostToDevice));
+  if (e->cfg.precision == AOG_PRECISION_FP64) {
+    HIP_TRY(hipMemcpy(e->modes64, t->modes, sizeof(double) * n_ap * A, hipMemcpyHostToDevice));
+    const int MR = e->MRW_used + e->MRS_used;
+    std::vector<double> tb((size_t)n_ap * MR);
+    for (int p = 0; p < n_ap; ++p) {
+      for (int m = 0; m < e->MRW_used; ++m) tb[(size_t)p * MR + m] = t->wfs_tables[(size_t)m * n_ap + p];
+      for (int m = 0; m < e->MRS_used; ++m) tb[(size_t)p * MR + e->MRW_used + m] = t->sci_tables[(size_t)m * n_ap + p];
+    }
+    HIP_TRY(hipMemcpy(e->tabs64, tb.data(), sizeof(double) * tb.size(), hipMemcpyHostToDevice));
+  } else {
+    const int Ap = e->A_pad, MR = e->MRW + e->MRS, TROW = round_up(MR, 4), NKQ = Ap / 8;
+    std::vector<float> mf((size_t)e->n_ap_pad * Ap, 0.f), mt((size_t)e->n_ap_pad * Ap, 0.f);
+    for (int p = 0; p < n_ap; ++p)
+      for (int k = 0; k < A; ++k) {
+        const float v = (float)t->modes[(size_t)p * A + k];
+        mf[(size_t)p * Ap + k] = v;
+        // modes_tile[pt][kq][lane = 32*h + i][el], mode k = 2*(4*kq + el) + h
+        const int pt = p >> 5, i = p & 31, h = k & 1, kk = k >> 1, kq = kk >> 2, el = kk & 3;
+        mt[(((size_t)pt * NKQ + kq) * 64 + (h * 32 + i)) * 4 + el] = v;
+      }
+    std::vector<float> tf((size_t)e->n_ap_pad * TROW, 0.f), tt((size_t)e->n_ap_pad * MR, 0.f);
+    auto tab = [&](int m, int p) -> float {
+      if (m < e->MRW_used) return (float)t->wfs_tables[(size_t)m * n_ap + p];
+      if (m >= e->MRW && m - e->MRW < e->MRS_used) return (float)t->sci_tables[(size_t)(m - e->MRW) * n_ap + p];
+      return 0.f;
+    };
+    for (int p = 0; p < n_ap; ++p)
+      for (int m = 0; m < MR; ++m) {
+        const float v = tab(m, p);
+        tf[(size_t)p * TROW + m] = v;
+        // tabs_tile[pt][g][h][m][r], pixel i = 8g + 4h + r
+        const int pt = p >> 5, i = p & 31, g = i >> 3, h = (i >> 2) & 1, r = i & 3;
+        tt[((((size_t)pt * 4 + g) * 2 + h) * MR + m) * 4 + r] = v;
+      }
+    HIP_TRY(hipMemcpy(e->modes_f32, mf.data(), sizeof(float) * mf.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->modes_tile, mt.data(), sizeof(float) * mt.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->tabs_f32, tf.data(), sizeof(float) * tf.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->tabs_tile, tt.data(), sizeof(float) * tt.size(), hipMemcpyHostToDevice));
+  }
+  e->tables_ready = true;
+  return AOG_OK;
+}
+
+int aog_set_screens_f64(aog_env* e, const double* psi, int first, int count, void* stream) {
+  return set_screens<double>(e, psi, first, count, static_cast<hipStream_t>(stream));
+}
+
+int aog_set_screens_f32(aog_env* e, const float* psi, int first, int count, void* stream) {
+  return set_screens<float>(e, psi, first, count, static_cast<hipStream_t>(stream));
+}
+
+int aog_get_actuators(aog_env* e, double* act_dev, void* stream) {
+  if (!e || !act_dev) return fail(AOG_ERR_INVALID, "aog_get_actuators: null argument");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipMemcpyAsync(act_dev, e->act_dm, sizeof(double) * e->B * e->A, hipMemcpyDeviceToDevice,
+                         static_cast<hipStream_t>(stream)));
+  return AOG_OK;
+}
+
+int aog_set_actuators(aog_env* e, const double* act_dev, void* stream) {
+  if (!e || !act_dev) return fail(AOG_ERR_INVALID, "aog_set_actuators: null argument");
+  HIP_TRY(hipSetDevice(e->device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  HIP_TRY(hipMemcpyAsync(e->act_dm, act_dev, sizeof(double) * e->B * e->A, hipMemcpyDeviceToDevice, s));
+  const int n = e->B * e->A_pad;
+  hipLaunchKernelGGL(aog::k_load_actuators, dim3((n + 255) / 256), dim3(256), 0, s, e->act_dm, e->act_rev, e->act_tile,
+                     e->B, e->A, e->A_pad, e->Bp, 2.0 / e->cfg.wavelength_wfs);
+  HIP_TRY(hipGetLastError());
+  return AOG_OK;
+}
+
+int aog_reset(aog_env* e, const uint8_t* mask, float* obs_raw, uint16_t* obs, void* stream) {
+  if (!e) return fail(AOG_ERR_INVALID, "aog_reset: null handle");
+  if (!e->tables_ready || !e->screens_ready) return fail(AOG_ERR_STATE, "aog_reset before aog_upload_tables/aog_set_screens");
+  HIP_TRY(hipSetDevice(e->device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  {
+    const int n = e->B * e->A;
+    hipLaunchKernelGGL(aog::k_reset_state, dim3((n + 255) / 256), dim3(256), 0, s, mask, e->act_dm, e->t_render, e->B, e->A,
+                       e->cfg.flat_mirror_start);
+    const int n2 = e->B * e->A_pad;
+    hipLaunchKernelGGL(aog::k_load_actuators, dim3((n2 + 255) / 256), dim3(256), 0, s, e->act_dm, e->act_rev, e->act_tile,
+                       e->B, e->A, e->A_pad, e->Bp, 2.0 / e->cfg.wavelength_wfs);
+    HIP_TRY(hipGetLastError());
+  }
+  int rc = launch_fused(e, s);
+  if (rc != AOG_OK) return rc;
+  return launch_epilogue(e, false, obs_raw, obs, nullptr, nullptr, nullptr, nullptr, s);
+}
+
+int aog_step(aog_env* e, const float* action, float* obs_raw, uint16_t* obs, float* reward, uint8_t* done, float* power,
+             float* strehl, void* stream) {
+  if (!e || !action) return fail(AOG_ERR_INVALID, "aog_step: null argument");
+  if (!e->tables_ready || !e->screens_ready) return fail(AOG_ERR_STATE, "aog_step before aog_upload_tables/aog_set_screens");
+  if (e->cfg.reward_type == AOG_REWARD_SMF_SSIM && e->n_obs < 7)
+    return fail(AOG_ERR_INVALID, "win_size exceeds image extent (smf_ssim needs obs_dim**2 >= 7; AO_env.py:495)");
+  HIP_TRY(hipSetDevice(e->device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(aog::k_prologue, dim3(e->B), dim3(64), 0, s, action, e->gram, e->act_dm, e->act_rev, e->act_tile, e->A,
+                     e->A_pad, e->Bp, e->cfg.sh_operation, e->cfg.surface_rms_target, 2.0 / e->cfg.wavelength_wfs);
+  HIP_TRY(hipGetLastError());
+  int rc = launch_fused(e, s);
+  if (rc != AOG_OK) return rc;
+  return launch_epilogue(e, true, obs_raw, obs, reward, done, power, strehl, s);
+}
+
+int aog_profile_enable(aog_env* e, int enable) {
+  if (!e) return fail(AOG_ERR_INVALID, "aog_profile_enable: null handle");
+  e->profile = enable != 0;
+  e->events_used = 0;
+  return AOG_OK;
+}
+
+int aog_profile_read(aog_env* e, double* mean_ms, int* launches) {
+  if (!e || !mean_ms || !launches) return fail(AOG_ERR_INVALID, "aog_profile_read: null argument");
+  HIP_TRY(hipSetDevice(e->device));
+  double total = 0;
+  for (size_t i = 0; i < e->events_used; ++i) {
+    HIP_TRY(hipEventSynchronize(e->events[i].second));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e->events[i].first, e->events[i].second));
+    total += ms;
+  }
+  *launches = (int)e->events_used;
+  *mean_ms = e->events_used ? total / (double)e->events_used : 0.0;
+  e->events_used = 0;
+  return AOG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,493 @@
+// Device kernels of libaogym.so (gfx950 only).  See DESIGN.md for the data layout and the roofline of each.
+//
+// Notation: B envs (padded to Bp, a multiple of 64), n_ap aperture pixels packed row-major (padded to a
+// multiple of 32 = one MFMA pixel tile), A modes (padded to A_PAD), MRW / MRS real pupil-plane tables at the
+// wavefront-sensing / science wavelength, NS = 2*(MRW+MRS) real sums per env.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace aog {
+
+constexpr float kLog2Dummy = 0.f;
+
+// ------------------------------------------------------------------------------------------------
+// sin/cos of 2*pi*u for u in revolutions.  Range reduction is exact in fp32 (u - rint(u), then the
+// octant split), so accuracy does not degrade with |u|; max abs error 7.4e-8, zero mean bias (checked
+// on the host against float64 and on the device by tests/test_gpu_kernels.py).
+//   SINCOS = 0: polynomial (degree 7 / 8 in the reduced argument)
+//   SINCOS = 1: hardware v_sin_f32 / v_cos_f32, which take revolutions directly
+// ------------------------------------------------------------------------------------------------
+template <int SINCOS>
+__device__ __forceinline__ void sincos_rev(float u, float& s, float& c) {
+  const float r = u - rintf(u);  // [-0.5, 0.5], exact
+  if constexpr (SINCOS == 1) {
+    s = __builtin_amdgcn_sinf(r);
+    c = __builtin_amdgcn_cosf(r);
+  } else {
+    const float q = rintf(4.0f * r);       // -2..2
+    const float t = fmaf(q, -0.25f, r);    // [-1/8, 1/8], exact
+    const float z = t * t;
+    const float ps = fmaf(z, fmaf(z, -75.43880659180556f, 81.5934996521887f), -41.34166926730038f);
+    // sin(2 pi t) = t*(2pi_hi) + t*(2pi_lo + z*ps)
+    const float sp = fmaf(t, 6.2831854820251465f, t * fmaf(z, ps, -1.8420333e-07f));
+    const float pc = fmaf(z, fmaf(z, fmaf(z, 59.43078516585609f, -85.44897459881716f), 64.93936989759587f),
+                          -19.739208790231338f);
+    const float cp = fmaf(z, pc, 1.0f);
+    const int qi = (int)q;
+    const bool swap = (qi & 1) != 0;
+    const float ss = swap ? cp : sp;
+    const float cc = swap ? sp : cp;
+    s = (qi & 2) ? -ss : ss;
+    c = ((qi + 1) & 2) ? -cc : cc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K0  pack_screens: achromatic screens [count][N][N] (T = double|float) -> internal layouts.
+//   psi_rev   fp32, revolutions at lambda_wfs, aperture mean removed, layout [quad q][env][4]
+//             (lane = env reads one float4 = 4 consecutive packed pixels; 1 KiB per wave instruction)
+//   psi_tile  fp32, same values in MFMA accumulator order (see k_fused_mfma)
+//   psi64     (validation mode) float64 [env][n_ap], aperture mean removed, hcipy units
+// One workgroup per env.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double block_reduce_sum(double v, double* sm) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sm[wave] = v;
+  __syncthreads();
+  double r = 0;
+  const int nw = (blockDim.x + 63) >> 6;
+  for (int i = 0; i < nw; ++i) r += sm[i];
+  return r;
+}
+
+// index of (env, packed pixel p) in the MFMA-tiled screen layout:
+//   [env_tile = env/32][pixel tile = p/32][g = (p%32)/8][lane = 32*h + env%32][r = p%4],  h = ((p%32)/4)&1
+__device__ __host__ __forceinline__ size_t psi_tile_index(int env, int p, int n_ptiles) {
+  const int et = env >> 5, e = env & 31, pt = p >> 5, i = p & 31;
+  const int g = i >> 3, h = (i >> 2) & 1, r = i & 3;
+  return ((((size_t)et * n_ptiles + pt) * 4 + g) * 64 + (h * 32 + e)) * 4 + r;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_pack_screens(const T* __restrict__ psi, const int32_t* __restrict__ ap_index,
+                                                      float* __restrict__ psi_rev, float* __restrict__ psi_tile,
+                                                      double* __restrict__ psi64, int first, int n_pix2, int n_ap,
+                                                      int n_ap_pad, int Bp, double inv_two_pi_lambda) {
+  __shared__ double sm[8];
+  const int e = blockIdx.x;
+  const int env = first + e;
+  const T* src = psi + (size_t)e * n_pix2;
+  double acc = 0;
+  for (int p = threadIdx.x; p < n_ap; p += blockDim.x) acc += (double)src[ap_index[p]];
+  const double mean = block_reduce_sum(acc, sm) / (double)n_ap;
+  const int n_ptiles = n_ap_pad >> 5;
+  for (int p = threadIdx.x; p < n_ap_pad; p += blockDim.x) {
+    const double v = (p < n_ap) ? ((double)src[ap_index[p]] - mean) : 0.0;
+    const float vr = (float)(v * inv_two_pi_lambda);
+    if (psi_rev) psi_rev[((size_t)(p >> 2) * Bp + env) * 4 + (p & 3)] = vr;
+    if (psi_tile) psi_tile[psi_tile_index(env, p, n_ptiles)] = vr;
+    if (psi64 && p < n_ap) psi64[(size_t)env * n_ap + p] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1  prologue: action -> actuators (AO_env.py:115-120).  One wave per env.
+//   a'_i = action_i / (i + 10);  var = a'^T G a'  (G = centred Gram, float64);  a'' = a' * target / sqrt(var)
+//   act_dm  [B][A] float64 (metres)         — deformable_mirror.actuators
+//   act_rev [A_PAD][Bp] float32             — 2 a''/lambda_wfs (revolutions of wfs phase per unit mode)
+//   act_tile (MFMA B-operand order) [env/32][A_PAD][32]
+// A zero action gives 0/0 = NaN exactly like numpy (documented in DESIGN.md).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_prologue(const float* __restrict__ action, const double* __restrict__ gram,
+                                                 double* __restrict__ act_dm, float* __restrict__ act_rev,
+                                                 float* __restrict__ act_tile, int A, int A_pad, int Bp,
+                                                 int sh_operation, double target, double two_over_lambda) {
+  const int env = blockIdx.x;
+  const int lane = threadIdx.x;
+  __shared__ double ap[256];
+  for (int i = lane; i < A; i += 64) {
+    const double a = (double)action[(size_t)env * A + i];
+    ap[i] = sh_operation ? a : a / (double)(i + 10);
+  }
+  __syncthreads();
+  double scale = 1.0;
+  if (!sh_operation) {
+    double part = 0;
+    for (int i = lane; i < A; i += 64) {
+      const double* grow = gram + (size_t)i * A;
+      double r = 0;
+      for (int j = 0; j < A; ++j) r = fma(grow[j], ap[j], r);
+      part = fma(ap[i], r, part);
+    }
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+    part = __shfl(part, 0, 64);
+    scale = target / sqrt(part);
+  }
+  for (int i = lane; i < A_pad; i += 64) {
+    const double a = (i < A) ? ap[i] * scale : 0.0;
+    if (i < A) act_dm[(size_t)env * A + i] = a;
+    const float ar = (float)(a * two_over_lambda);
+    act_rev[(size_t)i * Bp + env] = ar;
+    act_tile[((size_t)(env >> 5) * A_pad + i) * 32 + (env & 31)] = ar;
+  }
+}
+
+// actuators (metres, float64) -> the two fp32 operand layouts (used by reset / set_actuators)
+__global__ void k_load_actuators(const double* __restrict__ act_dm, float* __restrict__ act_rev,
+                                 float* __restrict__ act_tile, int B, int A, int A_pad, int Bp, double two_over_lambda) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * A_pad) return;
+  const int env = idx / A_pad, i = idx % A_pad;
+  const float ar = (i < A) ? (float)(act_dm[(size_t)env * A + i] * two_over_lambda) : 0.f;
+  act_rev[(size_t)i * Bp + env] = ar;
+  act_tile[((size_t)(env >> 5) * A_pad + i) * 32 + (env & 31)] = ar;
+}
+
+// AOEnv.reset bookkeeping (AO_env.py:79-83)
+__global__ void k_reset_state(const uint8_t* __restrict__ mask, double* __restrict__ act_dm, int32_t* __restrict__ t_render,
+                              int B, int A, int flatten) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * A) return;
+  const int env = idx / A, i = idx % A;
+  if (mask && !mask[env]) return;
+  if (flatten) act_dm[idx] = 0.0;
+  if (i == 0) t_render[env] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3a  fused pupil pass, VALU form.  lane = env (64 envs per wave), every per-pixel operand (mode row,
+// table row) is wave-uniform and comes through the scalar cache (s_load), the screen is one float4 per lane
+// per pixel quad.  Per (pixel, env): A_PAD fma (surface), 2 sincos, 2*(MRW+MRS) fma.
+//   grid = (pixel chunks, ceil(env groups / 4)), block = 4 waves = 4 env groups sharing the pixel range.
+//   partials[chunk][s][env] float64, s < NS.
+// ------------------------------------------------------------------------------------------------
+template <int A_PAD, int MRW, int MRS, int SINCOS>
+__global__ __launch_bounds__(256) void k_fused_valu(const float* __restrict__ modes, const float* __restrict__ tabs,
+                                                    const float4* __restrict__ psi4, const float* __restrict__ act_rev,
+                                                    double* __restrict__ partials, int n_quads, int Bp, int n_groups,
+                                                    int quads_per_chunk, float ratio) {
+  constexpr int NS = 2 * (MRW + MRS);
+  constexpr int TROW = (MRW + MRS + 3) & ~3;
+  constexpr int TQ = 8;  // quads per fp32 tile-sum before the float64 flush
+  const int lane = threadIdx.x & 63;
+  const int group = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (group >= n_groups) return;
+  const int env = group * 64 + lane;
+
+  float a[A_PAD];
+#pragma unroll
+  for (int k = 0; k < A_PAD; ++k) a[k] = act_rev[(size_t)k * Bp + env];
+
+  double acc[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) acc[i] = 0.0;
+
+  const int q0 = blockIdx.x * quads_per_chunk;
+  const int q1 = min(n_quads, q0 + quads_per_chunk);
+  for (int qb = q0; qb < q1; qb += TQ) {
+    float t[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) t[i] = 0.f;
+    const int qe = min(q1, qb + TQ);
+    for (int q = qb; q < qe; ++q) {
+      const float4 u4 = psi4[(size_t)q * Bp + env];
+      float u[4] = {u4.x, u4.y, u4.z, u4.w};
+      const float* __restrict__ mrow = modes + (size_t)q * 4 * A_PAD;
+#pragma unroll
+      for (int k = 0; k < A_PAD; ++k) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) u[j] = fmaf(mrow[j * A_PAD + k], a[k], u[j]);
+      }
+      const float* __restrict__ trow = tabs + (size_t)q * 4 * TROW;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float s, c;
+        sincos_rev<SINCOS>(u[j], s, c);
+#pragma unroll
+        for (int m = 0; m < MRW; ++m) {
+          const float g = trow[j * TROW + m];
+          t[2 * m] = fmaf(c, g, t[2 * m]);
+          t[2 * m + 1] = fmaf(s, g, t[2 * m + 1]);
+        }
+        sincos_rev<SINCOS>(u[j] * ratio, s, c);
+#pragma unroll
+        for (int m = 0; m < MRS; ++m) {
+          const float g = trow[j * TROW + MRW + m];
+          t[2 * (MRW + m)] = fmaf(c, g, t[2 * (MRW + m)]);
+          t[2 * (MRW + m) + 1] = fmaf(s, g, t[2 * (MRW + m) + 1]);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NS; ++i) acc[i] += (double)t[i];
+  }
+  double* out = partials + (size_t)blockIdx.x * NS * Bp + env;
+#pragma unroll
+  for (int i = 0; i < NS; ++i) out[(size_t)i * Bp] = acc[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3b  fused pupil pass, MFMA form.  One wave owns a 32-env tile and walks 32-pixel tiles:
+//     D[pixel i][env j] = psi[i][j] + sum_k Mt[i][k] * a[k][j]          (v_mfma_f32_32x32x2_f32, K = A_PAD)
+// so the accumulator is initialised with the screen tile and comes back as the wfs phase in revolutions.
+// C/D register map: lane l holds env j = l&31 and pixels i = (r&3) + 8*(r>>2) + 4*(l>>5), r < 16.
+//   psi_tile  [env tile][pixel tile][g=r>>2][lane][r&3]   -> one float4 per lane per g, 1 KiB per instruction
+//   modes_tile[pixel tile][kq][lane][4]: lane (i = l&31, h = l>>5), element e <-> mode k = 2*(4*kq+e) + h
+//   act_tile  [env tile][k][32]: B operand of k-step kk is act_tile[2*kk + h][j] = one coalesced dword load
+//   tabs_tile [pixel tile][g][h][MRW+MRS][4]: per-pixel tables, identical for the 32 lanes of a half wave;
+//             staged in LDS once per workgroup and read back with broadcast ds_read_b128.
+// grid = (pixel chunks, ceil(env tiles / WE)); block = 256 = WE env tiles x WP pixel sub-chunks (WE*WP = 4).
+// ------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int A_PAD, int MRW, int MRS, int SINCOS>
+__global__ __launch_bounds__(256) void k_fused_mfma(const f32x4* __restrict__ modes_tile, const f32x4* __restrict__ tabs_tile,
+                                                    const f32x4* __restrict__ psi_tile, const float* __restrict__ act_tile,
+                                                    double* __restrict__ partials, int n_ptiles, int n_etiles, int Bp,
+                                                    int tiles_per_chunk, int we, float ratio) {
+  constexpr int NS = 2 * (MRW + MRS);
+  constexpr int MR = MRW + MRS;
+  constexpr int NKQ = A_PAD / 8;
+  extern __shared__ f32x4 lds_tabs[];  // [tile in chunk][g][h][MR]
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int wp = 4 / we;                    // pixel sub-chunks per workgroup
+  const int w_e = wave % we, w_p = wave / we;
+  const int etile = blockIdx.y * we + w_e;
+  const int t0 = blockIdx.x * tiles_per_chunk;
+  const int t1 = min(n_ptiles, t0 + tiles_per_chunk);
+
+  // stage this chunk's tables (contiguous in global memory) into LDS
+  {
+    const int n4 = (t1 - t0) * 8 * MR;
+    const f32x4* src = tabs_tile + (size_t)t0 * 8 * MR;
+    for (int i = threadIdx.x; i < n4; i += 256) lds_tabs[i] = src[i];
+  }
+  __syncthreads();
+  if (etile >= n_etiles) return;
+
+  const int h = lane >> 5;
+  float b[A_PAD / 2];
+  {
+    const float* asrc = act_tile + (size_t)etile * A_PAD * 32;
+#pragma unroll
+    for (int kk = 0; kk < A_PAD / 2; ++kk) b[kk] = asrc[kk * 64 + lane];  // [2kk + h][lane&31]
+  }
+  double acc[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) acc[i] = 0.0;
+
+  // this wave's share of the chunk: tiles t0 + w_p, t0 + w_p + wp, ...
+  for (int t = t0 + w_p; t < t1; t += wp) {
+    f32x16 d;
+    {
+      const f32x4* ps = psi_tile + (((size_t)etile * n_ptiles + t) * 4) * 64 + lane;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 v = ps[g * 64];
+        d[4 * g + 0] = v[0]; d[4 * g + 1] = v[1]; d[4 * g + 2] = v[2]; d[4 * g + 3] = v[3];
+      }
+    }
+    {
+      const f32x4* ms = modes_tile + ((size_t)t * NKQ) * 64 + lane;
+#pragma unroll
+      for (int kq = 0; kq < NKQ; ++kq) {
+        const f32x4 av = ms[kq * 64];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], b[4 * kq + e], d, 0, 0, 0);
+      }
+    }
+    float ts[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) ts[i] = 0.f;
+    const f32x4* lt = lds_tabs + (size_t)(t - t0) * 8 * MR + h * MR;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float cw[4], sw[4], cs[4], ss[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float u = d[4 * g + r];
+        sincos_rev<SINCOS>(u, sw[r], cw[r]);
+        sincos_rev<SINCOS>(u * ratio, ss[r], cs[r]);
+      }
+#pragma unroll
+      for (int m = 0; m < MRW; ++m) {
+        const f32x4 gv = lt[(g * 2) * MR + m];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          ts[2 * m] = fmaf(cw[r], gv[r], ts[2 * m]);
+          ts[2 * m + 1] = fmaf(sw[r], gv[r], ts[2 * m + 1]);
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < MRS; ++m) {
+        const f32x4 gv = lt[(g * 2) * MR + MRW + m];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          ts[2 * (MRW + m)] = fmaf(cs[r], gv[r], ts[2 * (MRW + m)]);
+          ts[2 * (MRW + m) + 1] = fmaf(ss[r], gv[r], ts[2 * (MRW + m) + 1]);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NS; ++i) acc[i] += (double)ts[i];
+  }
+  // the two half waves hold different pixels of the same 32 envs: fold h=1 into h=0, then store
+  const int chunk = blockIdx.x * wp + w_p;
+  double* out = partials + (size_t)chunk * NS * Bp + (size_t)etile * 32 + (lane & 31);
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const double v = acc[i] + __shfl_down(acc[i], 32, 64);
+    if (h == 0) out[(size_t)i * Bp] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3c  float64 validation form (AOG_PRECISION_FP64): one workgroup per env, everything in float64 from
+// float64 tables; also the general path for shapes the fast kernels are not instantiated for.
+// ------------------------------------------------------------------------------------------------
+constexpr int kRefMaxSums = 2 * 80;
+
+__global__ __launch_bounds__(256) void k_fused_ref(const double* __restrict__ modes64, const double* __restrict__ tabs64,
+                                                   const double* __restrict__ psi64, const double* __restrict__ act_dm,
+                                                   double* __restrict__ partials, int n_ap, int A, int MRW, int MRS,
+                                                   int Bp, double lambda_wfs, double lambda_sci) {
+  __shared__ double sm[8];
+  __shared__ double sa[256];
+  const int env = blockIdx.x;
+  for (int i = threadIdx.x; i < A; i += blockDim.x) sa[i] = act_dm[(size_t)env * A + i];
+  __syncthreads();
+  const int MR = MRW + MRS;
+  const int NS = 2 * MR;
+  double acc[kRefMaxSums];
+  for (int i = 0; i < NS; ++i) acc[i] = 0;
+  for (int p = threadIdx.x; p < n_ap; p += blockDim.x) {
+    const double* mrow = modes64 + (size_t)p * A;
+    double surf = 0;
+    for (int k = 0; k < A; ++k) surf = fma(mrow[k], sa[k], surf);
+    const double theta = psi64[(size_t)env * n_ap + p] + 4.0 * M_PI * surf;  // achromatic phase (rad * m)
+    double sw, cw, ss, cs;
+    sincos(theta / lambda_wfs, &sw, &cw);
+    sincos(theta / lambda_sci, &ss, &cs);
+    const double* trow = tabs64 + (size_t)p * MR;
+    for (int m = 0; m < MRW; ++m) {
+      acc[2 * m] += cw * trow[m];
+      acc[2 * m + 1] += sw * trow[m];
+    }
+    for (int m = MRW; m < MR; ++m) {
+      acc[2 * m] += cs * trow[m];
+      acc[2 * m + 1] += ss * trow[m];
+    }
+  }
+  for (int i = 0; i < NS; ++i) {
+    const double v = block_reduce_sum(acc[i], sm);
+    if (threadIdx.x == 0) partials[(size_t)i * Bp + env] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K9  epilogue: chunk partials -> complex amplitudes -> observation, fiber power, Strehl, reward, done.
+// (AO_env.py:142-153, 468-503.)  One thread per env.
+// ------------------------------------------------------------------------------------------------
+struct EpilogueArgs {
+  const double* partials;
+  const double* wfs_coef;  // [n_out][MRW][2]
+  const double* sci_coef;  // [MRS][2]
+  float* obs_raw;
+  uint16_t* obs;
+  float* reward;
+  uint8_t* done;
+  float* power;
+  float* strehl;
+  int32_t* t_render;
+  int B, Bp, n_chunks, MRW, MRS, MRW_used, MRS_used, n_obs, n_fiber, reward_type, has_thr, max_steps, is_step;
+  double thr, ssim_peak, ssim_alpha;
+};
+
+__device__ inline double ssim_1d_delta_ref(const double* x, int n, double peak, int peak_idx) {
+  // skimage.metrics.structural_similarity, 1-D, win 7, uniform filter, sample covariance; the reference image
+  // is peak at peak_idx and 0 elsewhere (AO_env.py:491-495).  Mean over the interior windows.
+  const double C1 = (0.01 * peak) * (0.01 * peak), C2 = (0.03 * peak) * (0.03 * peak);
+  const double cov_norm = 7.0 / 6.0;
+  double sum = 0;
+  int cnt = 0;
+  for (int i = 3; i < n - 3; ++i) {
+    double ux = 0, uxx = 0, uy = 0, uyy = 0, uxy = 0;
+    for (int k = -3; k <= 3; ++k) {
+      const double a = x[i + k];
+      const double b = (i + k == peak_idx) ? peak : 0.0;
+      ux += a; uxx += a * a; uy += b; uyy += b * b; uxy += a * b;
+    }
+    ux /= 7; uxx /= 7; uy /= 7; uyy /= 7; uxy /= 7;
+    const double vx = cov_norm * (uxx - ux * ux), vy = cov_norm * (uyy - uy * uy), vxy = cov_norm * (uxy - ux * uy);
+    sum += ((2 * ux * uy + C1) * (2 * vxy + C2)) / ((ux * ux + uy * uy + C1) * (vx + vy + C2));
+    ++cnt;
+  }
+  return sum / cnt;
+}
+
+__global__ __launch_bounds__(64) void k_epilogue(EpilogueArgs p) {
+  const int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= p.B) return;
+  const int MR = p.MRW + p.MRS;
+  double U[80], V[80];
+  for (int m = 0; m < MR; ++m) {
+    double u = 0, v = 0;
+    for (int c = 0; c < p.n_chunks; ++c) {
+      const double* src = p.partials + ((size_t)c * 2 * MR + 2 * m) * p.Bp + env;
+      u += src[0];
+      v += src[p.Bp];
+    }
+    U[m] = u;
+    V[m] = v;
+  }
+  double obsv[64];
+  double power = 0;
+  const int n_out = p.n_obs + p.n_fiber;
+  for (int j = 0; j < n_out; ++j) {
+    double zr = 0, zi = 0;
+    const double* cf = p.wfs_coef + (size_t)j * p.MRW_used * 2;
+    for (int m = 0; m < p.MRW_used; ++m) {
+      zr += cf[2 * m] * U[m] - cf[2 * m + 1] * V[m];
+      zi += cf[2 * m] * V[m] + cf[2 * m + 1] * U[m];
+    }
+    const double pw = zr * zr + zi * zi;
+    if (j < p.n_obs) {
+      obsv[j] = pw;
+      if (p.obs_raw) p.obs_raw[(size_t)env * p.n_obs + j] = (float)pw;
+      if (p.obs) {
+        const _Float16 hv = (_Float16)pw;  // round-to-nearest-even from float64, like np.array(x, float16)
+        p.obs[(size_t)env * p.n_obs + j] = *reinterpret_cast<const uint16_t*>(&hv);
+      }
+    } else {
+      power += pw;
+    }
+  }
+  if (!p.is_step) return;
+  double zr = 0, zi = 0;
+  for (int m = 0; m < p.MRS_used; ++m) {
+    zr += p.sci_coef[2 * m] * U[p.MRW + m] - p.sci_coef[2 * m + 1] * V[p.MRW + m];
+    zi += p.sci_coef[2 * m] * V[p.MRW + m] + p.sci_coef[2 * m + 1] * U[p.MRW + m];
+  }
+  const double strehl = zr * zr + zi * zi;
+  double reward;
+  if (p.reward_type == 0) {
+    reward = -(100.0 - strehl * 100.0);
+  } else {
+    const double ssim = ssim_1d_delta_ref(obsv, p.n_obs, p.ssim_peak, p.n_obs / 2);
+    reward = p.ssim_alpha * power + (1.0 - p.ssim_alpha) * ssim;
+  }
+  if (p.has_thr && reward < p.thr) reward = -1.0;
+  const int tr = p.t_render[env] + 1;
+  p.t_render[env] = tr;
+  if (p.reward) p.reward[env] = (float)reward;
+  if (p.done) p.done[env] = (tr == p.max_steps) ? 1 : 0;
+  if (p.power) p.power[env] = (float)power;
+  if (p.strehl) p.strehl[env] = (float)strehl;
+}
+
+}  // namespace aog

@@ -1,0 +1,144 @@
+/*
+ * aogym.h — C-ABI of libaogym.so: the MI355X (gfx950) implementation of the AOEnv.step() hot path.
+ *
+ * The reference (payamparvizi/adaptive_optics_gym) is pure Python on top of hcipy; it has no FFI.
+ * The interface each entry point replaces is therefore a *Python* call site in
+ * gym_AO/envs/AO_env.py (cited per function).  The reference-side binding a maintainer would add is
+ * a ctypes stub; see INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative aog_status; it never throws, never exits;
+ *     aog_last_error() returns a thread-local message for the last failure on this thread.
+ *   - pointers named *_dev are device pointers owned by the CALLER (e.g. torch tensors); the library
+ *     owns only the handle, its constant tables and its per-environment state.
+ *   - `stream` is a hipStream_t passed as void*; all work is stream-ordered and asynchronous.
+ *   - one handle per device; a handle is not thread-safe; distinct handles are independent.
+ *   - there is no CPU fallback: creating a handle without a HIP device fails with AOG_ERR_HIP.
+ */
+#ifndef AOGYM_H
+#define AOGYM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AOG_ABI_VERSION 3
+
+typedef struct aog_env aog_env;
+
+typedef enum {
+  AOG_OK = 0,
+  AOG_ERR_INVALID = -1,     /* bad argument / unsupported configuration              */
+  AOG_ERR_HIP = -2,         /* a HIP runtime call failed (message has the HIP error) */
+  AOG_ERR_STATE = -3,       /* call order violated (e.g. step before upload_tables)  */
+  AOG_ERR_UNSUPPORTED = -4  /* valid in the reference, not built yet                 */
+} aog_status;
+
+enum { AOG_REWARD_STREHL = 0, AOG_REWARD_SMF_SSIM = 1 };           /* AO_env.py:476,487 */
+enum { AOG_PRECISION_FAST = 0, AOG_PRECISION_FP64 = 1 };           /* fp32 data / fp64 validation kernel */
+enum { AOG_KERNEL_AUTO = 0, AOG_KERNEL_VALU = 1, AOG_KERNEL_MFMA = 2 };
+
+/* Scalar configuration.  Mirrors AOEnv.__init__ kwargs (AO_env.py:17-29) and the constants fixed by
+ * parameters_init (AO_env.py:211-247) that the device path consumes. */
+typedef struct {
+  int32_t abi_version;          /* = AOG_ABI_VERSION                                            */
+  int32_t num_envs;             /* B: environments stepped in lock-step                         */
+  int32_t n_pupil;              /* N: pupil grid side (reference: 240, AO_env.py:216)            */
+  int32_t n_modes;              /* A = act_dim (AO_env.py:223)                                   */
+  int32_t obs_dim;              /* o (AO_env.py:236)                                             */
+  int32_t n_ap;                 /* aperture pixels (packed list length)                          */
+  int32_t n_wfs_tables;         /* real pupil-plane tables at lambda_wfs                         */
+  int32_t n_sci_tables;         /* real pupil-plane tables at lambda_sci                         */
+  int32_t n_fiber_modes;        /* guided LP modes (3 at V = 2.639)                              */
+  int32_t reward_type;          /* AOG_REWARD_*                                                  */
+  int32_t sh_operation;         /* 1: action = raw actuators (AO_env.py:115-116)                 */
+  int32_t max_steps;            /* timesteps_per_episode (AO_env.py:227)                         */
+  int32_t flat_mirror_start;    /* flat_mirror_start_per_episode (AO_env.py:79-80)               */
+  int32_t has_rew_threshold;    /* rew_threshold is not None (AO_env.py:500)                     */
+  int32_t precision;            /* AOG_PRECISION_*                                               */
+  int32_t kernel;               /* AOG_KERNEL_* (fast precision only)                            */
+  int32_t pixel_chunks;         /* 0 = auto; number of pixel chunks the fused kernel splits into */
+  int32_t reserved0;
+  double wavelength_wfs;        /* 1.5e-6 (AO_env.py:219)                                        */
+  double wavelength_sci;        /* 2.2e-6 (AO_env.py:220)                                        */
+  double surface_rms_target;    /* 0.1*wavelength_sci (AO_env.py:120)                            */
+  double rew_threshold;         /* used iff has_rew_threshold                                    */
+  double ssim_ref_peak;         /* 2.8 (AO_env.py:492)                                           */
+  double ssim_alpha;            /* 0.8 (AO_env.py:497)                                           */
+} aog_config;
+
+/* Host-precomputed constant tables (float64, HOST pointers; copied and converted by the call).
+ * They are what AOEnv.__init__ precomputes through hcipy (AO_env.py:42-68, 293-393).
+ *
+ *   field at lambda_wfs on packed aperture pixel p:  E_p = exp(i*phi_p)  (amplitude folded into tables)
+ *   U_m = sum_p cos(phi_p) g_m(p),  V_m = sum_p sin(phi_p) g_m(p)        (g = wfs_tables / sci_tables)
+ *   Z_j = sum_m coef[j][m] * (U_m + i V_m)
+ *   obs_raw[j] = |Z_j|^2  (j < o^2);  power = sum_k |Z_{o^2+k}|^2  (k < n_fiber_modes);
+ *   strehl = |Z_sci|^2.
+ */
+typedef struct {
+  const int32_t* ap_index;   /* [n_ap]  flat pupil index iy*N+ix of packed pixel p (row-major order) */
+  const double* modes;       /* [n_ap][n_modes]  DM mode matrix restricted to the aperture (metres of
+                                surface per unit actuator; AO_env.py:346-347,352-353)               */
+  const double* gram;        /* [n_modes][n_modes]  centred Gram matrix: std_grid(M a)^2 = a' G a     */
+  const double* wfs_tables;  /* [n_wfs_tables][n_ap]                                                 */
+  const double* sci_tables;  /* [n_sci_tables][n_ap]                                                 */
+  const double* wfs_coef;    /* [o^2 + n_fiber_modes][n_wfs_tables][2]  (re, im)                     */
+  const double* sci_coef;    /* [1][n_sci_tables][2]                                                 */
+} aog_tables;
+
+typedef struct {
+  int32_t abi_version, num_envs, num_envs_padded, n_ap, n_ap_padded, n_modes_padded;
+  int32_t pixel_chunks, kernel, n_sums, reserved;
+  int64_t device_bytes;      /* bytes of HBM the handle owns */
+} aog_info;
+
+int aog_abi_version(void);
+const char* aog_last_error(void);
+
+/* AOEnv.__init__ (AO_env.py:17-71): allocate the handle and its state on `device`. */
+int aog_create(const aog_config* cfg, int device, aog_env** out);
+void aog_destroy(aog_env* env);
+int aog_get_info(const aog_env* env, aog_info* out);
+
+/* The part of AOEnv.__init__ that goes through hcipy (pupil_simulation, incoming_wavefront,
+ * DM_function, fiber_coupling; AO_env.py:50-64). */
+int aog_upload_tables(aog_env* env, const aog_tables* tables);
+
+/* layer._achromatic_screen for envs [first, first+count) (hcipy InfiniteAtmosphericLayer state created at
+ * AO_env.py:370 / regenerated at AO_env.py:77).  psi_dev: [count][N][N] achromatic screens (phase * lambda,
+ * hcipy's unit), float64 or float32, row-major with x fastest.  The aperture mean of every screen is
+ * removed (all outputs are invariant to a global phase) before conversion to the internal fp32 layout. */
+int aog_set_screens_f64(aog_env* env, const double* psi_dev, int first, int count, void* stream);
+int aog_set_screens_f32(aog_env* env, const float* psi_dev, int first, int count, void* stream);
+
+/* deformable_mirror.actuators for all envs (metres; AO_env.py:116).  [B][A] float64 device pointers. */
+int aog_get_actuators(aog_env* env, double* act_dev, void* stream);
+int aog_set_actuators(aog_env* env, const double* act_dev, void* stream);
+
+/* AOEnv.reset (AO_env.py:74-103) for the envs with mask_dev[b] != 0 (NULL = all): flatten the mirror iff
+ * flat_mirror_start, zero the per-episode step counter, and return the observation of EVERY env
+ * (obs_raw_dev [B][o^2] float32 before the cast, obs_dev [B][o^2] IEEE half; either may be NULL). */
+int aog_reset(aog_env* env, const uint8_t* mask_dev, float* obs_raw_dev, uint16_t* obs_dev, void* stream);
+
+/* AOEnv.step (AO_env.py:106-153) incl. reward_function (AO_env.py:468-503).
+ *   action_dev  [B][A] float32
+ *   obs_raw_dev [B][o^2] float32 (wf.power before the float16 cast, AO_env.py:142)   nullable
+ *   obs_dev     [B][o^2] IEEE half (AO_env.py:153)                                   nullable
+ *   reward_dev  [B] float32;  done_dev [B] uint8;  power_dev [B] float32 (info["power"])
+ *   strehl_dev  [B] float32 (Strehl ratio in [0,1]; nullable) */
+int aog_step(aog_env* env, const float* action_dev, float* obs_raw_dev, uint16_t* obs_dev, float* reward_dev,
+             uint8_t* done_dev, float* power_dev, float* strehl_dev, void* stream);
+
+/* Microseconds-resolution timing of the dominant (fused) kernel of the most recent aog_step/aog_reset calls,
+ * measured with HIP events on the stream the kernel was launched on.  Enable, run steps, then read the
+ * mean duration (ms) and the number of launches averaged. */
+int aog_profile_enable(aog_env* env, int enable);
+int aog_profile_read(aog_env* env, double* mean_ms, int* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AOGYM_H */
