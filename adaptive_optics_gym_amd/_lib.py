@@ -1,0 +1,89 @@
+"""ctypes binding of ``libaogym.so`` (the C-ABI declared in ``include/aogym.h``).
+
+There is no CPU fallback: if the shared library is missing the import of the env classes still works (so
+CPU-only tooling can inspect them) but the first call raises ``RuntimeError`` naming the build command.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libaogym.so")
+ABI_VERSION = 3
+
+AOG_REWARD = {"strehl_ratio": 0, "smf_ssim": 1}
+AOG_PRECISION = {"fast": 0, "fp64": 1}
+AOG_KERNEL = {"auto": 0, "valu": 1, "mfma": 2}
+
+
+class AogConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "abi_version", "num_envs", "n_pupil", "n_modes", "obs_dim", "n_ap", "n_wfs_tables", "n_sci_tables",
+        "n_fiber_modes", "reward_type", "sh_operation", "max_steps", "flat_mirror_start", "has_rew_threshold",
+        "precision", "kernel", "pixel_chunks", "reserved0")] + [(n, C.c_double) for n in (
+        "wavelength_wfs", "wavelength_sci", "surface_rms_target", "rew_threshold", "ssim_ref_peak", "ssim_alpha")]
+
+
+class AogTables(C.Structure):
+    _fields_ = [("ap_index", C.POINTER(C.c_int32))] + [(n, C.POINTER(C.c_double)) for n in (
+        "modes", "gram", "wfs_tables", "sci_tables", "wfs_coef", "sci_coef")]
+
+
+class AogInfo(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "abi_version", "num_envs", "num_envs_padded", "n_ap", "n_ap_padded", "n_modes_padded", "pixel_chunks",
+        "kernel", "n_sums", "reserved")] + [("device_bytes", C.c_int64)]
+
+
+# every symbol include/aogym.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "aog_abi_version": (C.c_int, []),
+    "aog_last_error": (C.c_char_p, []),
+    "aog_create": (C.c_int, [C.POINTER(AogConfig), C.c_int, C.POINTER(C.c_void_p)]),
+    "aog_destroy": (None, [C.c_void_p]),
+    "aog_get_info": (C.c_int, [C.c_void_p, C.POINTER(AogInfo)]),
+    "aog_upload_tables": (C.c_int, [C.c_void_p, C.POINTER(AogTables)]),
+    "aog_set_screens_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "aog_set_screens_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "aog_get_actuators": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "aog_set_actuators": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "aog_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "aog_step": (C.c_int, [C.c_void_p] * 9),
+    "aog_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "aog_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and type the shared library.  Raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built. Run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (or adaptive_optics_gym_amd/build.py) — there is no CPU fallback for the device path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.aog_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libaogym.so ABI {lib.aog_abi_version()} != binding ABI {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+class AogError(RuntimeError):
+    pass
+
+
+def check(rc: int):
+    if rc != 0:
+        msg = load().aog_last_error().decode("utf-8", "replace")
+        if "win_size exceeds image extent" in msg:
+            raise ValueError(msg)  # what skimage raises in the reference for smf_ssim with obs_dim=2 (AO_env.py:495)
+        raise AogError(f"libaogym error {rc}: {msg}")

@@ -1,0 +1,280 @@
+"""``BatchedAOEnv`` — B independent adaptive-optics environments stepped in lock-step on one MI355X.
+
+Host-side mirror of the reference's ``AOEnv`` (``/root/reference/gym_AO/envs/AO_env.py``): same constructor
+keywords, same ``reset``/``step`` semantics, but tensors carry a leading env dimension and live on the GPU.
+All arithmetic of ``reset``/``step`` runs in ``libaogym.so`` (hand-written HIP, called through the C-ABI of
+``include/aogym.h``); PyTorch only owns the buffers and the stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .atmosphere_host import cn_squared_from_fried_parameter, screen_numpy, screens_torch
+from .optics_host import HostTables, build_tables
+from .params import OpticalParams, coerce_velocity
+from .spaces import make_box
+
+
+def _dptr(arr, ctype):
+    return arr.ctypes.data_as(C.POINTER(ctype))
+
+
+class BatchedAOEnv:
+    """Constructor keywords = AOEnv's (AO_env.py:17-29) plus:
+
+    num_envs            B
+    device              torch device (default ``cuda:0``)
+    num_pupil_pixels    pupil grid side N (reference: 240)
+    seed                seed of the screen generator (env e uses seed + e for ``screen_source='numpy'``)
+    screen_source       'torch' (batched rocFFT synthesis on the GPU) | 'numpy' (hcipy draw order, float64, host)
+    screens             optional [B, N, N] achromatic screens to use instead of generating them
+    precision           'fast' (fp32 data, float64 accumulators) | 'fp64' (validation kernel)
+    kernel              'auto' | 'mfma' | 'valu'
+    """
+
+    def __init__(self, num_envs=1, device=None, atm_type="quasi_static", atm_vel=0, atm_fried=0.15,
+                 act_type="num_actuators", act_dim=64, obs_dim=2, rew_type="strehl_ratio", rew_threshold=None,
+                 timesteps_per_episode=20, flat_mirror_start_per_episode=True, SH_operation=False, *,
+                 num_pupil_pixels=240, seed=None, screen_source="torch", screen_oversampling=16, screens=None,
+                 precision="fast", kernel="auto", pixel_chunks=0, rng=None, verbose=True, params=None):
+        import torch
+
+        self._torch = torch
+        self.lib = _lib.load()  # raises if the HIP extension is missing — no CPU fallback
+        if not torch.cuda.is_available():
+            raise RuntimeError("BatchedAOEnv needs a HIP device (torch.cuda.is_available() is False); there is no CPU path")
+        self.device = torch.device(device if device is not None else "cuda:0")
+        if self.device.type != "cuda":
+            raise RuntimeError("BatchedAOEnv runs on a HIP device only")
+        if rew_type not in _lib.AOG_REWARD:
+            # the reference leaves `reward` undefined in this case (AO_env.py:476,487); raise something clear instead
+            raise ValueError("rew_type must be 'strehl_ratio' or 'smf_ssim'")
+        if atm_type not in ("quasi_static", "semi_dynamic", "dynamic"):
+            raise ValueError("atm_type must be 'quasi_static', 'semi_dynamic' or 'dynamic'")
+
+        self.num_envs = int(num_envs)
+        self.atm_type = atm_type
+        self.rew_type = rew_type
+        self.act_type = act_type
+        self.flat_mirror_start_per_episode = bool(flat_mirror_start_per_episode)
+        self.rew_threshold = rew_threshold
+        self.SH_operation = bool(SH_operation)
+        self.velocity = coerce_velocity(atm_type, atm_vel, verbose)
+        self.fried_parameter = atm_fried
+        self.params = params if params is not None else OpticalParams(num_pupil_pixels=int(num_pupil_pixels))
+        self.num_pupil_pixels = self.params.num_pupil_pixels
+        self.num_modes = int(act_dim)
+        self.obs_dim = int(obs_dim)
+        self.num_focal_pixels_fiber_subsample = int(obs_dim)
+        self.max_steps = timesteps_per_episode
+        self.delta_t = self.params.delta_t
+        self.wavelength_wfs = self.params.wavelength_wfs
+        self.wavelength_sci = self.params.wavelength_sci
+        self.timestep = 0
+        self.episode_no = 0
+        self.seed = seed
+        self.screen_source = screen_source
+        self.screen_oversampling = int(screen_oversampling)
+        self._rng = rng
+        self._episode_returns = None
+
+        if atm_type == "dynamic":
+            raise NotImplementedError("dynamic atmosphere (hcipy InfiniteAtmosphericLayer extrusion) is not built yet")
+        if self.SH_operation:
+            raise NotImplementedError("Shack-Hartmann operation (AO_env.py:254-290, 396-465) is not built yet")
+
+        self.observation_space = make_box(-1, 1, (self.obs_dim ** 2,), np.float16)  # AO_env.py:45
+        self.action_space = make_box(-1, 1, (self.num_modes,), np.float16)          # AO_env.py:46
+
+        self.tables: HostTables = build_tables(self.params, act_type, self.num_modes, self.obs_dim)
+        t = self.tables
+        cfg = _lib.AogConfig()
+        cfg.abi_version = _lib.ABI_VERSION
+        cfg.num_envs = self.num_envs
+        cfg.n_pupil = self.num_pupil_pixels
+        cfg.n_modes = self.num_modes
+        cfg.obs_dim = self.obs_dim
+        cfg.n_ap = t.n_ap
+        cfg.n_wfs_tables = t.wfs_tables.shape[0]
+        cfg.n_sci_tables = t.sci_tables.shape[0]
+        cfg.n_fiber_modes = t.n_fiber_modes
+        cfg.reward_type = _lib.AOG_REWARD[rew_type]
+        cfg.sh_operation = int(self.SH_operation)
+        cfg.max_steps = int(timesteps_per_episode)
+        cfg.flat_mirror_start = int(self.flat_mirror_start_per_episode)
+        cfg.has_rew_threshold = int(rew_threshold is not None)
+        cfg.precision = _lib.AOG_PRECISION[precision]
+        cfg.kernel = _lib.AOG_KERNEL[kernel]
+        cfg.pixel_chunks = int(pixel_chunks)
+        cfg.wavelength_wfs = self.params.wavelength_wfs
+        cfg.wavelength_sci = self.params.wavelength_sci
+        cfg.surface_rms_target = self.params.action_rms_fraction * self.params.wavelength_sci
+        cfg.rew_threshold = float(rew_threshold) if rew_threshold is not None else 0.0
+        cfg.ssim_ref_peak = self.params.ssim_ref_peak
+        cfg.ssim_alpha = self.params.ssim_alpha
+        self._handle = C.c_void_p()
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        _lib.check(self.lib.aog_create(C.byref(cfg), dev_index, C.byref(self._handle)))
+
+        keep = dict(
+            ap=np.ascontiguousarray(t.ap_index, dtype=np.int32),
+            modes=np.ascontiguousarray(t.modes, dtype=np.float64),
+            gram=np.ascontiguousarray(t.gram, dtype=np.float64),
+            wt=np.ascontiguousarray(t.wfs_tables, dtype=np.float64),
+            st=np.ascontiguousarray(t.sci_tables, dtype=np.float64),
+            wc=np.ascontiguousarray(np.stack([t.wfs_coef.real, t.wfs_coef.imag], axis=-1), dtype=np.float64),
+            sc=np.ascontiguousarray(np.stack([t.sci_coef.real, t.sci_coef.imag], axis=-1), dtype=np.float64),
+        )
+        tabs = _lib.AogTables(_dptr(keep["ap"], C.c_int32), _dptr(keep["modes"], C.c_double), _dptr(keep["gram"], C.c_double),
+                              _dptr(keep["wt"], C.c_double), _dptr(keep["st"], C.c_double), _dptr(keep["wc"], C.c_double),
+                              _dptr(keep["sc"], C.c_double))
+        _lib.check(self.lib.aog_upload_tables(self._handle, C.byref(tabs)))
+        self.info = _lib.AogInfo()
+        _lib.check(self.lib.aog_get_info(self._handle, C.byref(self.info)))
+
+        # atmosphere (AO_env.py:361-370)
+        self.Cn_squared = cn_squared_from_fried_parameter(self.fried_parameter, self.params.wavelength_sci)
+        if self._rng is not None or screen_source == "numpy":
+            # hcipy draws the wind direction and the two extrusion stencils before the screen;
+            # consume them so the legacy numpy stream stays aligned with the reference's
+            for e in range(self.num_envs):
+                r = self._env_rng(e)
+                r.rand()
+                r.geometric(0.5, self.num_pupil_pixels)
+                r.geometric(0.5, self.num_pupil_pixels)
+        if screens is not None:
+            self.set_screens(screens)
+        else:
+            self._generate_screens(first_call=True)
+
+    # ------------------------------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _env_rng(self, e):
+        if self._rng is not None:
+            return self._rng
+        if self.seed is None:
+            return np.random
+        if not hasattr(self, "_rngs"):
+            self._rngs = {}
+        if e not in self._rngs:
+            self._rngs[e] = np.random.RandomState(self.seed + e)
+        return self._rngs[e]
+
+    def _generate_screens(self, first_call=False, mask=None):
+        torch = self._torch
+        p = self.params
+        if self._rng is not None or self.screen_source == "numpy":
+            for e in range(self.num_envs):
+                if mask is not None and not bool(mask[e]):
+                    continue
+                psi = screen_numpy(p.num_pupil_pixels, p.pupil_pixel, self.Cn_squared, p.outer_scale, self._env_rng(e),
+                                   self.screen_oversampling)
+                self.set_screens(psi[None], first=e)
+        else:
+            if not hasattr(self, "_gen"):
+                self._gen = torch.Generator(device=self.device)
+                self._gen.manual_seed(1234 if self.seed is None else int(self.seed))
+            psi = screens_torch(self.num_envs, p.num_pupil_pixels, p.pupil_pixel, self.Cn_squared, p.outer_scale,
+                                self.device, self._gen, self.screen_oversampling)
+            if mask is None:
+                self.set_screens(psi)
+            else:
+                for e in np.flatnonzero(np.asarray(mask.cpu() if hasattr(mask, "cpu") else mask)):
+                    self.set_screens(psi[e:e + 1], first=int(e))
+
+    def set_screens(self, screens, first=0):
+        """Install achromatic screens (hcipy's ``layer._achromatic_screen``: phase * lambda) for envs
+        [first, first + len(screens)).  numpy or torch, float32 or float64, shape [k, N, N] or [k, N*N]."""
+        torch = self._torch
+        if isinstance(screens, np.ndarray):
+            screens = torch.from_numpy(np.ascontiguousarray(screens))
+        N = self.num_pupil_pixels
+        screens = screens.reshape(-1, N, N)
+        if screens.dtype not in (torch.float32, torch.float64):
+            screens = screens.to(torch.float64)
+        screens = screens.to(self.device).contiguous()
+        fn = self.lib.aog_set_screens_f64 if screens.dtype == torch.float64 else self.lib.aog_set_screens_f32
+        _lib.check(fn(self._handle, C.c_void_p(screens.data_ptr()), int(first), int(screens.shape[0]), self._stream()))
+        # the kernel is stream-ordered; keep the source alive until it has run
+        torch.cuda.current_stream(self.device).synchronize()
+
+    # ------------------------------------------------------------------------------------------------
+    def reset(self, mask=None, seed=None, options=None):
+        """AOEnv.reset (AO_env.py:74-103) for every env (or those selected by ``mask``).  ``seed``/``options`` are
+        accepted and ignored exactly like the reference.  Returns (obs [B, o^2] float16, {})."""
+        torch = self._torch
+        m = None
+        if mask is not None:
+            m = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
+        if self.atm_type == "semi_dynamic":
+            self._generate_screens(mask=m)  # layer.reset() (AO_env.py:76-77)
+        n = self.obs_dim ** 2
+        obs = torch.empty((self.num_envs, n), dtype=torch.float16, device=self.device)
+        obs_raw = torch.empty((self.num_envs, n), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.aog_reset(self._handle, C.c_void_p(m.data_ptr()) if m is not None else None,
+                                      C.c_void_p(obs_raw.data_ptr()), C.c_void_p(obs.data_ptr()), self._stream()))
+        self.last_obs_raw = obs_raw
+        return obs, {}
+
+    def step(self, actions):
+        """AOEnv.step (AO_env.py:106-153).  ``actions``: [B, A] float32 tensor on the device.
+        Returns (obs float16 [B, o^2], reward float32 [B], done bool [B], trunc bool [B] (all False),
+        {"power": [B] float32, "obs_raw": [B, o^2] float32, "strehl": [B] float32})."""
+        torch = self._torch
+        a = torch.as_tensor(actions, device=self.device)
+        if a.dtype != torch.float32:
+            a = a.to(torch.float32)
+        a = a.reshape(self.num_envs, self.num_modes).contiguous()
+        n = self.obs_dim ** 2
+        B = self.num_envs
+        obs = torch.empty((B, n), dtype=torch.float16, device=self.device)
+        obs_raw = torch.empty((B, n), dtype=torch.float32, device=self.device)
+        reward = torch.empty((B,), dtype=torch.float32, device=self.device)
+        done = torch.empty((B,), dtype=torch.uint8, device=self.device)
+        power = torch.empty((B,), dtype=torch.float32, device=self.device)
+        strehl = torch.empty((B,), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.aog_step(self._handle, C.c_void_p(a.data_ptr()), C.c_void_p(obs_raw.data_ptr()),
+                                     C.c_void_p(obs.data_ptr()), C.c_void_p(reward.data_ptr()), C.c_void_p(done.data_ptr()),
+                                     C.c_void_p(power.data_ptr()), C.c_void_p(strehl.data_ptr()), self._stream()))
+        self.timestep += 1
+        self.last_obs_raw = obs_raw
+        trunc = torch.zeros((B,), dtype=torch.bool, device=self.device)
+        return obs, reward, done.to(torch.bool), trunc, {"power": power, "obs_raw": obs_raw, "strehl": strehl}
+
+    # ------------------------------------------------------------------------------------------------
+    def get_actuators(self):
+        """deformable_mirror.actuators of every env, [B, A] float64 (metres)."""
+        torch = self._torch
+        out = torch.empty((self.num_envs, self.num_modes), dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.aog_get_actuators(self._handle, C.c_void_p(out.data_ptr()), self._stream()))
+        return out
+
+    def set_actuators(self, act):
+        torch = self._torch
+        a = torch.as_tensor(act, device=self.device).to(torch.float64).reshape(self.num_envs, self.num_modes).contiguous()
+        _lib.check(self.lib.aog_set_actuators(self._handle, C.c_void_p(a.data_ptr()), self._stream()))
+        torch.cuda.current_stream(self.device).synchronize()
+
+    def profile(self, enable=True):
+        _lib.check(self.lib.aog_profile_enable(self._handle, int(bool(enable))))
+
+    def profile_read(self):
+        ms, n = C.c_double(), C.c_int()
+        _lib.check(self.lib.aog_profile_read(self._handle, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def close(self):
+        h, self._handle = getattr(self, "_handle", None), None
+        if h:
+            self.lib.aog_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,68 @@
+"""``AOEnv`` — drop-in for the reference's ``gym_AO.envs.AOEnv`` (``/root/reference/gym_AO/envs/AO_env.py:16``):
+same constructor keywords and defaults (AO_env.py:17-29), same ``reset()``/``step()`` tuples (AO_env.py:103,153),
+numpy in / numpy out, one environment.  It is the B = 1 view of ``BatchedAOEnv``: all arithmetic runs in the HIP
+library; there is no CPU path.
+
+The single-env wrapper draws its phase screen from the process-global legacy ``np.random`` stream in hcipy's
+order (wind direction, two stencil draws, 2 x (16 N)^2 normals), so ``np.random.seed(s)`` before construction
+plays the same role as in the reference.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from ..batched_env import BatchedAOEnv
+from ..spaces import env_base
+
+
+class AOEnv(env_base()):
+    metadata = {"render_modes": []}
+
+    def __init__(self, atm_type="quasi_static", atm_vel=0, atm_fried=0.15, act_type="num_actuators", act_dim=64,
+                 obs_dim=2, rew_type="strehl_ratio", rew_threshold=None, timesteps_per_episode=20,
+                 flat_mirror_start_per_episode=True, SH_operation=False, *, num_pupil_pixels=240, device=None,
+                 screens=None, precision="fast", kernel="auto", rng=np.random, verbose=True):
+        super().__init__()
+        self._env = BatchedAOEnv(1, device, atm_type, atm_vel, atm_fried, act_type, act_dim, obs_dim, rew_type,
+                                 rew_threshold, timesteps_per_episode, flat_mirror_start_per_episode, SH_operation,
+                                 num_pupil_pixels=num_pupil_pixels, screen_source="numpy", screens=screens,
+                                 precision=precision, kernel=kernel, rng=rng, verbose=verbose)
+        e = self._env
+        self.atm_type, self.rew_type, self.act_type = e.atm_type, e.rew_type, e.act_type
+        self.flat_mirror_start_per_episode = e.flat_mirror_start_per_episode
+        self.rew_threshold, self.SH_operation = e.rew_threshold, e.SH_operation
+        self.observation_space, self.action_space = e.observation_space, e.action_space
+        self.num_modes, self.max_steps = e.num_modes, e.max_steps
+        self.num_focal_pixels_fiber_subsample = e.obs_dim
+        self.wavelength_wfs, self.wavelength_sci, self.delta_t = e.wavelength_wfs, e.wavelength_sci, e.delta_t
+        self.velocity, self.fried_parameter = e.velocity, e.fried_parameter
+        self.timestep = 0          # AO_env.py:70 — monotone across episodes
+        self.episode_no = 0        # AO_env.py:71
+        self.timestep_render = 0
+
+    def reset(self, seed=None, options=None):
+        obs, info = self._env.reset()
+        self.timestep_render = 0
+        self.last_obs_raw = self._env.last_obs_raw[0].cpu().numpy()
+        return obs[0].cpu().numpy(), {}
+
+    def step(self, action):
+        a = np.asarray(action, dtype=np.float32).reshape(1, self.num_modes)
+        obs, reward, done, trunc, info = self._env.step(a)
+        self.timestep += 1
+        self.timestep_render += 1
+        d = bool(done[0].item())
+        if d:
+            self.episode_no += 1
+        self.last_obs_raw = info["obs_raw"][0].cpu().numpy()
+        self.last_strehl = float(info["strehl"][0].item())
+        return obs[0].cpu().numpy(), float(reward[0].item()), d, False, {"power": float(info["power"][0].item())}
+
+    def render(self, close=False):
+        raise NotImplementedError("render() (matplotlib UI, AO_env.py:156-194) is outside the device hot path")
+
+    def SH_step(self):
+        raise NotImplementedError("Shack-Hartmann baseline (AO_env.py:254-290) is not built yet")
+
+    def close(self):
+        self._env.close()
