@@ -1,0 +1,317 @@
+"""Parity tests proper (run with -m gpu on an MI355X): the HIP path, called through the C-ABI, against the CPU
+oracle on the same seeded inputs, against the committed golden fixtures, and — at BASELINE.json's full size —
+through size-independent properties.
+
+Tolerances (north_star): Strehl ratio and observations within 1e-5 relative *before* the float16 cast
+(``obs_raw``); after the cast equality up to 1 float16 ulp; mode ("actuator") indexing bit-exact (CPU test
+``test_mode_matrix_and_indexing_match_oracle``); ``done`` exact.
+"""
+import ast
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from helpers import actions_for, run_oracle, smooth_screens
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+KERNELS = [("fast", "mfma"), ("fast", "valu"), ("fp64", "auto")]
+
+
+def _torch():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
+def _loaded_native():
+    from adaptive_optics_gym_amd import _lib
+
+    assert os.path.exists(_lib.LIB_PATH)
+    with open("/proc/self/maps") as f:
+        assert "libaogym.so" in f.read(), "the HIP extension is not the code that ran"
+
+
+def _ulp16_equal(a, b):
+    a = np.asarray(a, dtype=np.float16).view(np.int16).astype(np.int32)
+    b = np.asarray(b, dtype=np.float16).view(np.int16).astype(np.int32)
+    return np.all(np.abs(a - b) <= 1)
+
+
+def _drive(env, acts, torch):
+    """Mirror of helpers.run_oracle on the device env: [T, B, A] actions, reset after done."""
+    out = {k: [] for k in ("obs_raw", "obs", "reward", "done", "power", "strehl")}
+    env.reset()
+    obs0 = env.last_obs_raw.cpu().numpy().astype(np.float64)
+    for t in range(acts.shape[0]):
+        obs, r, d, tr, info = env.step(torch.from_numpy(acts[t]).to(env.device))
+        out["obs_raw"].append(info["obs_raw"].cpu().numpy().astype(np.float64))
+        out["obs"].append(obs.cpu().numpy())
+        out["reward"].append(r.cpu().numpy().astype(np.float64))
+        out["done"].append(d.cpu().numpy())
+        out["power"].append(info["power"].cpu().numpy().astype(np.float64))
+        out["strehl"].append(info["strehl"].cpu().numpy().astype(np.float64))
+        assert tr.dtype == torch.bool and not bool(tr.any())
+        if bool(d.all()):
+            env.reset()
+    res = {k: np.stack(v) for k, v in out.items()}
+    res["obs0"] = obs0
+    return res
+
+
+def _compare(got, ref, strehl_reward):
+    np.testing.assert_allclose(got["obs0"], ref["obs0"], rtol=RTOL)
+    np.testing.assert_allclose(got["obs_raw"], ref["obs_raw"], rtol=RTOL)
+    np.testing.assert_allclose(got["power"], ref["power"], rtol=RTOL)
+    assert _ulp16_equal(got["obs"], ref["obs"])
+    np.testing.assert_array_equal(got["done"], ref["done"].astype(bool))
+    if strehl_reward:
+        np.testing.assert_allclose(got["strehl"], ref["strehl"], rtol=RTOL)
+        np.testing.assert_allclose(got["reward"], ref["reward"], rtol=0, atol=100 * RTOL)  # reward = 100 (S - 1)
+    else:
+        np.testing.assert_allclose(got["reward"], ref["reward"], rtol=RTOL, atol=1e-7)
+
+
+@pytest.mark.parametrize("precision,kernel", KERNELS)
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))),
+                         ids=lambda p: os.path.basename(p)[:-4])
+def test_golden_fixtures(path, precision, kernel):
+    torch = _torch()
+    from adaptive_optics_gym_amd import BatchedAOEnv
+
+    z = np.load(path)
+    kw = ast.literal_eval(str(z["kw"]))
+    scr, acts = z["screens"], z["actions"]
+    env = BatchedAOEnv(scr.shape[0], "cuda:0", num_pupil_pixels=scr.shape[1], screens=scr, precision=precision,
+                       kernel=kernel, verbose=False, **kw)
+    got = _drive(env, acts, torch)
+    ref = {k[4:]: z[k] for k in z.files if k.startswith("exp_")}
+    _compare(got, ref, kw["rew_type"] == "strehl_ratio")
+    _loaded_native()
+    env.close()
+
+
+@pytest.mark.parametrize("precision,kernel", KERNELS)
+@pytest.mark.parametrize("N,B,A,o,act_type,rew", [
+    (64, 5, 64, 2, "num_actuators", "strehl_ratio"),      # ragged batch: not a multiple of 32 / 64
+    (64, 33, 6, 5, "zernike", "smf_ssim"),
+    (128, 2, 6, 2, "zernike", "strehl_ratio"),            # BASELINE configs[0] geometry
+    (50, 1, 3, 4, "num_actuators", "strehl_ratio"),       # B = 1, odd sizes, A < 8
+    (240, 2, 64, 2, "num_actuators", "strehl_ratio"),     # the reference's hard-coded pupil size
+])
+def test_live_oracle_parity(N, B, A, o, act_type, rew, precision, kernel):
+    torch = _torch()
+    from adaptive_optics_gym_amd import BatchedAOEnv
+
+    T = 3
+    scr = smooth_screens(B, N, seed=N + B)
+    acts = np.stack([actions_for(B, A, 7 * s + N) for s in range(T)])
+    kw = dict(act_type=act_type, act_dim=A, obs_dim=o, rew_type=rew, timesteps_per_episode=2)
+    ref = run_oracle(scr[: min(B, 3)], acts[:, : min(B, 3)], **kw)
+    env = BatchedAOEnv(B, "cuda:0", num_pupil_pixels=N, screens=scr, precision=precision, kernel=kernel, verbose=False, **kw)
+    got = _drive(env, acts, torch)
+    got = {k: (v[:, : min(B, 3)] if k != "obs0" else v[: min(B, 3)]) for k, v in got.items()}
+    _compare(got, ref, rew == "strehl_ratio")
+    env.close()
+
+
+def test_strong_turbulence_von_karman_screens_parity():
+    """Real von Karman screens (tens of radians peak-to-valley at the sensing wavelength): exercises the exact
+    range reduction and the piston removal."""
+    torch = _torch()
+    from adaptive_optics_gym_amd import BatchedAOEnv
+    from adaptive_optics_gym_amd.atmosphere_host import cn_squared_from_fried_parameter, screen_numpy
+
+    N, B, A = 96, 2, 64
+    cn2 = cn_squared_from_fried_parameter(0.10, 2.2e-6)
+    scr = np.stack([screen_numpy(N, 0.5 / N, cn2, 10.0, np.random.RandomState(s), 16) + 3e-5 for s in range(B)])
+    assert np.ptp(scr[0]) / 1.5e-6 > 20
+    acts = np.stack([actions_for(B, A, s) for s in range(2)])
+    kw = dict(act_dim=A, obs_dim=2, timesteps_per_episode=5)
+    ref = run_oracle(scr, acts, **kw)
+    for precision, kernel in KERNELS:
+        env = BatchedAOEnv(B, "cuda:0", num_pupil_pixels=N, screens=scr, precision=precision, kernel=kernel, verbose=False, **kw)
+        _compare(_drive(env, acts, torch), ref, True)
+        env.close()
+
+
+def test_hardware_sincos_variant_parity(monkeypatch):
+    torch = _torch()
+    from adaptive_optics_gym_amd import BatchedAOEnv
+
+    monkeypatch.setenv("AOG_SINCOS", "hw")
+    N, B, A = 64, 4, 64
+    scr = smooth_screens(B, N, 5)
+    acts = np.stack([actions_for(B, A, s) for s in range(2)])
+    kw = dict(act_dim=A, obs_dim=2, timesteps_per_episode=5)
+    ref = run_oracle(scr, acts, **kw)
+    for kernel in ("mfma", "valu"):
+        env = BatchedAOEnv(B, "cuda:0", num_pupil_pixels=N, screens=scr, kernel=kernel, verbose=False, **kw)
+        _compare(_drive(env, acts, torch), ref, True)
+        env.close()
+
+
+def test_full_size_properties_config2():
+    """BASELINE configs[1] (B=1024, N=256, A=64, o=2): fast kernels vs the float64 device kernel on every env,
+    action-scale invariance, Strehl in [0, 1], B=1 == env 0 of the batch, lock-step done."""
+    torch = _torch()
+    from adaptive_optics_gym_amd import BatchedAOEnv
+    from adaptive_optics_gym_amd.atmosphere_host import cn_squared_from_fried_parameter, screens_torch
+
+    N, B, A = 256, 1024, 64
+    dev = torch.device("cuda:0")
+    g = torch.Generator(dev).manual_seed(1234)
+    scr = screens_torch(B, N, 0.5 / N, cn_squared_from_fried_parameter(0.2, 2.2e-6), 10.0, dev, g, oversampling=4)
+    a = torch.randn((B, A), device=dev, generator=g) * 0.7071
+    kw = dict(act_dim=A, obs_dim=2, atm_fried=0.2, timesteps_per_episode=2, num_pupil_pixels=N, verbose=False)
+    ref = BatchedAOEnv(B, dev, screens=scr, precision="fp64", **kw)
+    ref.reset()
+    r_obs0 = ref.last_obs_raw.double()
+    _, r_rew, r_done, _, r_info = ref.step(a)
+    for kernel in ("mfma", "valu"):
+        env = BatchedAOEnv(B, dev, screens=scr, kernel=kernel, **kw)
+        env.reset()
+        assert torch.max(torch.abs(env.last_obs_raw.double() / r_obs0 - 1)) < RTOL
+        obs, rew, done, _, info = env.step(a)
+        assert torch.max(torch.abs(info["obs_raw"].double() / r_info["obs_raw"].double() - 1)) < RTOL
+        assert torch.max(torch.abs(info["strehl"].double() / r_info["strehl"].double() - 1)) < RTOL
+        assert torch.max(torch.abs(info["power"].double() / r_info["power"].double() - 1)) < RTOL
+        assert float(info["strehl"].min()) >= 0 and float(info["strehl"].max()) <= 1
+        assert not bool(done.any())
+        # second step ends the 2-step episode for every env; scaled action gives the same result (AO_env.py:119-120)
+        obs2, rew2, done2, _, info2 = env.step(a * 3.0)
+        assert bool(done2.all())
+        assert torch.max(torch.abs(info2["obs_raw"].double() / info["obs_raw"].double() - 1)) < 2e-6
+        # B = 1 env built on screen 0 equals env 0 of the batch
+        one = BatchedAOEnv(1, dev, screens=scr[:1], kernel=kernel, **kw)
+        one.reset()
+        _, _, _, _, i1 = one.step(a[:1])
+        assert torch.max(torch.abs(i1["obs_raw"].double() / info["obs_raw"][:1].double() - 1)) < 2e-6
+        assert abs(float(i1["strehl"][0]) - float(info["strehl"][0])) < 1e-6
+        one.close()
+        env.close()
+    ref.close()
+
+
+def test_zero_action_is_nan_like_numpy_and_other_envs_unaffected():
+    torch = _torch()
+    from adaptive_optics_gym_amd import BatchedAOEnv
+
+    N, B, A = 48, 3, 16
+    scr = smooth_screens(B, N, 9)
+    env = BatchedAOEnv(B, "cuda:0", num_pupil_pixels=N, act_dim=A, obs_dim=2, screens=scr, verbose=False)
+    env.reset()
+    a = torch.from_numpy(actions_for(B, A, 3)).cuda()
+    a[1] = 0                                     # AO_env.py:120 divides by std(surface) = 0
+    obs, rew, done, _, info = env.step(a)
+    assert bool(torch.isnan(info["obs_raw"][1]).all()) and bool(torch.isnan(rew[1]))
+    assert not bool(torch.isnan(info["obs_raw"][[0, 2]]).any())
+    env.close()
+
+
+def test_masked_reset_and_actuator_state():
+    torch = _torch()
+    from adaptive_optics_gym_amd import BatchedAOEnv
+
+    N, B, A = 48, 4, 16
+    scr = smooth_screens(B, N, 2)
+    env = BatchedAOEnv(B, "cuda:0", num_pupil_pixels=N, act_dim=A, obs_dim=2, screens=scr, timesteps_per_episode=3, verbose=False)
+    obs_flat, _ = env.reset()
+    a = torch.from_numpy(actions_for(B, A, 1)).cuda()
+    env.step(a)
+    act = env.get_actuators()
+    assert act.dtype == torch.float64 and act.shape == (B, A) and float(act.abs().min()) > 0
+    mask = torch.tensor([1, 0, 0, 1], dtype=torch.uint8)
+    obs_m, _ = env.reset(mask=mask)
+    act2 = env.get_actuators()
+    assert float(act2[[0, 3]].abs().max()) == 0 and torch.equal(act2[[1, 2]], act[[1, 2]])
+    assert torch.equal(obs_m[[0, 3]], obs_flat[[0, 3]]) and not torch.equal(obs_m[[1, 2]], obs_flat[[1, 2]])
+    # per-env episode counters: envs 0,3 restart, envs 1,2 are one step into their episode
+    d = [env.step(a)[2].cpu().tolist() for _ in range(3)]
+    assert d == [[False] * 4, [False, True, True, False], [True, False, False, True]]
+    env.close()
+
+
+def test_single_env_gym_api_and_seeded_screen_chain():
+    """``AOEnv`` (the drop-in) built from the process-global numpy RNG == the oracle built from the same seed:
+    checks the hcipy draw order end to end (direction, stencils, 2 x (16 N)^2 normals), incl. a semi_dynamic reset."""
+    _torch()
+    from adaptive_optics_gym_amd.envs import AOEnv
+    from oracle.ao_env_oracle import AOEnvOracle
+
+    kw = dict(atm_type="semi_dynamic", atm_vel=5, atm_fried=0.15, act_type="zernike", act_dim=6, obs_dim=2,
+              timesteps_per_episode=2, num_pupil_pixels=24, verbose=False)
+    np.random.seed(123)
+    env = AOEnv(**kw)
+    np.random.seed(123)
+    ref = AOEnvOracle(**kw)
+    assert env.observation_space.shape == (4,) and env.action_space.shape == (6,)
+    assert env.observation_space.dtype == np.float16
+    a = np.array([0.3, -1.2, 0.5, 0.9, -0.1, 0.2], dtype=np.float32)
+    for ep in range(2):
+        o, info = env.reset()
+        ro, _ = ref.reset()
+        assert o.dtype == np.float16 and o.shape == (4,) and info == {}
+        np.testing.assert_allclose(env.last_obs_raw, ref.last_obs_raw, rtol=RTOL)
+        for t in range(2):
+            o, r, d, tr, info = env.step(a)
+            ro, rr, rd, _, rinfo = ref.step(a)
+            assert isinstance(r, float) and isinstance(d, bool) and tr is False and set(info) == {"power"}
+            np.testing.assert_allclose(env.last_obs_raw, ref.last_obs_raw, rtol=RTOL)
+            np.testing.assert_allclose(r, rr, atol=1e-3)
+            np.testing.assert_allclose(info["power"], rinfo["power"], rtol=RTOL)
+            assert d == rd == (t == 1)
+    assert env.timestep == 4 and env.episode_no == 2
+    env.close()
+
+
+def test_reward_threshold_ssim_guard_and_unsupported_raise():
+    torch = _torch()
+    from adaptive_optics_gym_amd import BatchedAOEnv
+
+    N = 32
+    scr = smooth_screens(2, N, 4)
+    with pytest.raises(ValueError):
+        BatchedAOEnv(2, "cuda:0", num_pupil_pixels=N, rew_type="nope", screens=scr, verbose=False)
+    env = BatchedAOEnv(2, "cuda:0", num_pupil_pixels=N, act_dim=6, act_type="zernike", obs_dim=2, rew_type="smf_ssim",
+                       screens=scr, verbose=False)
+    env.reset()                                   # reset works in the reference too; step raises (AO_env.py:495)
+    with pytest.raises(ValueError, match="win_size exceeds image extent"):
+        env.step(torch.ones(2, 6, device="cuda"))
+    env.close()
+    env = BatchedAOEnv(2, "cuda:0", num_pupil_pixels=N, act_dim=6, act_type="zernike", obs_dim=2, rew_threshold=-1e-9,
+                       screens=scr, verbose=False)
+    env.reset()
+    _, r, _, _, _ = env.step(torch.ones(2, 6, device="cuda"))
+    assert r.cpu().tolist() == [-1.0, -1.0]       # Strehl reward is always < 0 -> clipped to -1.0 (AO_env.py:500-501)
+    env.close()
+
+
+def test_device_sincos_accuracy():
+    """The fused kernels' sin/cos (polynomial and hardware forms) against float64, through a tiny 1-mode env:
+    obs of a pure-piston-free tilt screen has a closed form, so compare the fast kernel with the fp64 kernel
+    over a sweep of screen amplitudes up to +-60 rad."""
+    torch = _torch()
+    from adaptive_optics_gym_amd import BatchedAOEnv
+
+    N, B = 40, 8
+    yy, xx = np.mgrid[0:N, 0:N]
+    scr = np.stack([(xx - N / 2) * (k + 1) * 2.5e-7 * 1.5 + (yy * yy) * 1e-9 * k for k in range(B)])
+    a = torch.ones(B, 4, device="cuda")
+    kw = dict(act_dim=4, act_type="zernike", obs_dim=3, num_pupil_pixels=N, screens=scr, verbose=False)
+    ref = BatchedAOEnv(B, "cuda:0", precision="fp64", **kw)
+    ref.reset()
+    _, _, _, _, ri = ref.step(a)
+    for kernel in ("mfma", "valu"):
+        env = BatchedAOEnv(B, "cuda:0", kernel=kernel, **kw)
+        env.reset()
+        _, _, _, _, i = env.step(a)
+        scale = ri["obs_raw"].double().max(dim=1, keepdim=True).values
+        assert float(((i["obs_raw"].double() - ri["obs_raw"].double()).abs() / scale).max()) < 2e-6
+        assert float((i["strehl"].double() - ri["strehl"].double()).abs().max()) < 2e-6
+        env.close()
+    ref.close()
