@@ -121,19 +121,28 @@ void launch_valu(aog_env* e, hipStream_t s) {
 
 template <int A_PAD, int MRW, int SC>
 void launch_mfma(aog_env* e, hipStream_t s) {
-  dim3 grid(e->mfma_chunks_x, (e->n_etiles + e->mfma_we - 1) / e->mfma_we);
+  aog::MfmaGeom g;
+  g.n_ptiles = e->n_ptiles;
+  g.n_etiles = e->n_etiles;
+  g.Bp = e->Bp;
+  g.P = e->mfma_chunks_x;
+  g.we = e->mfma_we;
+  g.wg_y = (e->n_etiles + e->mfma_we - 1) / e->mfma_we;
+  g.max_tiles = e->mfma_tpc;
+  dim3 grid(round_up(g.P, 8) * g.wg_y);
   const float ratio = (float)(e->cfg.wavelength_wfs / e->cfg.wavelength_sci);
   const size_t lds = (size_t)e->mfma_tpc * 8 * (MRW + 1) * 16;
   hipLaunchKernelGGL((aog::k_fused_mfma<A_PAD, MRW, 1, SC>), grid, dim3(256), lds, s,
                      reinterpret_cast<const aog::f32x4*>(e->modes_tile), reinterpret_cast<const aog::f32x4*>(e->tabs_tile),
-                     reinterpret_cast<const aog::f32x4*>(e->psi_tile), e->act_tile, e->partials, e->n_ptiles, e->n_etiles,
-                     e->Bp, e->mfma_tpc, e->mfma_we, ratio);
+                     reinterpret_cast<const aog::f32x4*>(e->psi_tile), e->act_tile, e->partials, g, ratio);
 }
 
 template <int A_PAD, int MRW>
 void launch_fast2(aog_env* e, hipStream_t s) {
   if (e->kernel == AOG_KERNEL_MFMA) {
-    if (e->sincos_hw) launch_mfma<A_PAD, MRW, 1>(e, s); else launch_mfma<A_PAD, MRW, 0>(e, s);
+    if (e->sincos_hw == 2) launch_mfma<A_PAD, MRW, 2>(e, s);
+    else if (e->sincos_hw == 1) launch_mfma<A_PAD, MRW, 1>(e, s);
+    else launch_mfma<A_PAD, MRW, 0>(e, s);
   } else {
     if (e->sincos_hw) launch_valu<A_PAD, MRW, 1>(e, s); else launch_valu<A_PAD, MRW, 0>(e, s);
   }
@@ -214,7 +223,12 @@ int launch_epilogue(aog_env* e, bool is_step, float* obs_raw, uint16_t* obs, flo
   p.thr = e->cfg.rew_threshold;
   p.ssim_peak = e->cfg.ssim_ref_peak;
   p.ssim_alpha = e->cfg.ssim_alpha;
-  hipLaunchKernelGGL(aog::k_epilogue, dim3((e->B + 63) / 64), dim3(64), 0, s, p);
+  const int NS = 2 * (p.MRW + p.MRS);
+  const int nw = std::max(1, std::min(16, NS));
+  const size_t lds = (size_t)(NS + p.n_obs) * 64 * sizeof(double);
+  if (lds > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(aog::k_epilogue), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(aog::k_epilogue, dim3((e->B + 63) / 64), dim3(64 * nw), lds, s, p);
   HIP_TRY(hipGetLastError());
   return AOG_OK;
 }
@@ -280,7 +294,10 @@ int aog_create(const aog_config* cfg, int device, aog_env** out) {
   e->n_obs = cfg->obs_dim * cfg->obs_dim;
   e->n_out = e->n_obs + cfg->n_fiber_modes;
   e->sincos_hw = 0;
-  if (const char* sc = getenv("AOG_SINCOS")) e->sincos_hw = (strcmp(sc, "hw") == 0) ? 1 : 0;
+  // sin/cos flavour of the fast kernels: "hw" (default; v_sin_f32/v_cos_f32 after the exact reduction),
+  // "hwraw" (same instructions on the unreduced revolutions), "poly" (degree-7/8 polynomial)
+  e->sincos_hw = 1;
+  if (const char* sc = getenv("AOG_SINCOS")) e->sincos_hw = strcmp(sc, "poly") == 0 ? 0 : (strcmp(sc, "hwraw") == 0 ? 2 : 1);
 
   if (cfg->precision == AOG_PRECISION_FAST) {
     e->A_pad = pick_pad(e->A, kApadOpts, 5);
@@ -303,12 +320,14 @@ int aog_create(const aog_config* cfg, int device, aog_env** out) {
     e->mfma_we = e->n_etiles >= 4 ? 4 : (e->n_etiles >= 2 ? 2 : 1);
     const int wp = 4 / e->mfma_we;
     const int wg_y = (e->n_etiles + e->mfma_we - 1) / e->mfma_we;
-    int Pm = cfg->pixel_chunks > 0 ? cfg->pixel_chunks : std::max(1, (256 * 2 + wg_y - 1) / wg_y);
-    int tpc = std::max(wp, (e->n_ptiles + Pm - 1) / Pm);
-    const int max_tpc = (int)(60 * 1024 / (8 * (e->MRW + 1) * 16));  // keep the table stage <= 60 KiB of LDS
-    tpc = std::min(tpc, std::max(wp, max_tpc));
-    e->mfma_tpc = tpc;
-    e->mfma_chunks_x = (e->n_ptiles + tpc - 1) / tpc;
+    // P pixel chunks (proportional split of the tiles), 2 workgroups per CU when the batch allows; the table stage of a
+    // chunk must fit 60 KiB of LDS
+    int Pm = cfg->pixel_chunks > 0 ? cfg->pixel_chunks : std::max(1, (256 * 2) / wg_y);
+    const int max_tpc = std::max(1, (int)(60 * 1024 / (8 * (e->MRW + 1) * 16)));
+    Pm = std::max(Pm, (e->n_ptiles + max_tpc - 1) / max_tpc);
+    Pm = std::min(Pm, e->n_ptiles);
+    e->mfma_chunks_x = Pm;
+    e->mfma_tpc = (e->n_ptiles + Pm - 1) / Pm;  // max tiles of any chunk: ceil(n/P)
     e->n_chunks = e->kernel == AOG_KERNEL_MFMA ? e->mfma_chunks_x * wp : e->valu_chunks;
   } else {
     e->A_pad = round_up(e->A, 8);

@@ -205,14 +205,14 @@ __global__ __launch_bounds__(256) void k_fused_valu(const float* __restrict__ mo
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float s, c;
-        sincos_rev<SINCOS>(u[j], s, c);
+        sincos_rev<(SINCOS == 2 ? 1 : SINCOS)>(u[j], s, c);
 #pragma unroll
         for (int m = 0; m < MRW; ++m) {
           const float g = trow[j * TROW + m];
           t[2 * m] = fmaf(c, g, t[2 * m]);
           t[2 * m + 1] = fmaf(s, g, t[2 * m + 1]);
         }
-        sincos_rev<SINCOS>(u[j] * ratio, s, c);
+        sincos_rev<(SINCOS == 2 ? 1 : SINCOS)>(u[j] * ratio, s, c);
 #pragma unroll
         for (int m = 0; m < MRS; ++m) {
           const float g = trow[j * TROW + MRW + m];
@@ -244,75 +244,60 @@ __global__ __launch_bounds__(256) void k_fused_valu(const float* __restrict__ mo
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// SINCOS: 0 polynomial, 1 hardware v_sin/v_cos after the exact reduction, 2 hardware v_sin/v_cos on the raw
+// revolutions (the instruction takes fract() itself; |u| stays far below its +-256 domain).
 template <int A_PAD, int MRW, int MRS, int SINCOS>
-__global__ __launch_bounds__(256) void k_fused_mfma(const f32x4* __restrict__ modes_tile, const f32x4* __restrict__ tabs_tile,
-                                                    const f32x4* __restrict__ psi_tile, const float* __restrict__ act_tile,
-                                                    double* __restrict__ partials, int n_ptiles, int n_etiles, int Bp,
-                                                    int tiles_per_chunk, int we, float ratio) {
-  constexpr int NS = 2 * (MRW + MRS);
-  constexpr int MR = MRW + MRS;
-  constexpr int NKQ = A_PAD / 8;
-  extern __shared__ f32x4 lds_tabs[];  // [tile in chunk][g][h][MR]
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int wp = 4 / we;                    // pixel sub-chunks per workgroup
-  const int w_e = wave % we, w_p = wave / we;
-  const int etile = blockIdx.y * we + w_e;
-  const int t0 = blockIdx.x * tiles_per_chunk;
-  const int t1 = min(n_ptiles, t0 + tiles_per_chunk);
+struct MfmaTile {
+  static constexpr int NS = 2 * (MRW + MRS);
+  static constexpr int MR = MRW + MRS;
+  static constexpr int NKQ = A_PAD / 8;
 
-  // stage this chunk's tables (contiguous in global memory) into LDS
-  {
-    const int n4 = (t1 - t0) * 8 * MR;
-    const f32x4* src = tabs_tile + (size_t)t0 * 8 * MR;
-    for (int i = threadIdx.x; i < n4; i += 256) lds_tabs[i] = src[i];
-  }
-  __syncthreads();
-  if (etile >= n_etiles) return;
-
-  const int h = lane >> 5;
-  float b[A_PAD / 2];
-  {
-    const float* asrc = act_tile + (size_t)etile * A_PAD * 32;
-#pragma unroll
-    for (int kk = 0; kk < A_PAD / 2; ++kk) b[kk] = asrc[kk * 64 + lane];  // [2kk + h][lane&31]
-  }
-  double acc[NS];
-#pragma unroll
-  for (int i = 0; i < NS; ++i) acc[i] = 0.0;
-
-  // this wave's share of the chunk: tiles t0 + w_p, t0 + w_p + wp, ...
-  for (int t = t0 + w_p; t < t1; t += wp) {
+  static __device__ __forceinline__ f32x16 load_psi(const f32x4* __restrict__ psi_tile, size_t tile_index, int lane) {
+    const f32x4* ps = psi_tile + (tile_index * 4) * 64 + lane;
     f32x16 d;
-    {
-      const f32x4* ps = psi_tile + (((size_t)etile * n_ptiles + t) * 4) * 64 + lane;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 v = ps[g * 64];
-        d[4 * g + 0] = v[0]; d[4 * g + 1] = v[1]; d[4 * g + 2] = v[2]; d[4 * g + 3] = v[3];
-      }
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 v = ps[g * 64];
+      d[4 * g + 0] = v[0]; d[4 * g + 1] = v[1]; d[4 * g + 2] = v[2]; d[4 * g + 3] = v[3];
     }
-    {
-      const f32x4* ms = modes_tile + ((size_t)t * NKQ) * 64 + lane;
+    return d;
+  }
+
+  // D = psi + Mt a  for pixel tile t (32 MFMAs at A_PAD = 64)
+  static __device__ __forceinline__ f32x16 chain(f32x16 d, const f32x4* __restrict__ modes_tile, int t, int lane,
+                                                 const float (&b)[A_PAD / 2]) {
+    const f32x4* ms = modes_tile + ((size_t)t * NKQ) * 64 + lane;
 #pragma unroll
-      for (int kq = 0; kq < NKQ; ++kq) {
-        const f32x4 av = ms[kq * 64];
+    for (int kq = 0; kq < NKQ; ++kq) {
+      const f32x4 av = ms[kq * 64];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) d = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], b[4 * kq + e], d, 0, 0, 0);
-      }
+      for (int e = 0; e < 4; ++e) d = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], b[4 * kq + e], d, 0, 0, 0);
     }
+    return d;
+  }
+
+  // phases of one finished tile -> the NS running sums
+  static __device__ __forceinline__ void reduce(const f32x16& d, const f32x4* lt /* lds row of (tile, h) */, float ratio,
+                                                double (&acc)[NS]) {
     float ts[NS];
 #pragma unroll
     for (int i = 0; i < NS; ++i) ts[i] = 0.f;
-    const f32x4* lt = lds_tabs + (size_t)(t - t0) * 8 * MR + h * MR;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       float cw[4], sw[4], cs[4], ss[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float u = d[4 * g + r];
-        sincos_rev<SINCOS>(u, sw[r], cw[r]);
-        sincos_rev<SINCOS>(u * ratio, ss[r], cs[r]);
+        if constexpr (SINCOS == 2) {
+          sw[r] = __builtin_amdgcn_sinf(u);
+          cw[r] = __builtin_amdgcn_cosf(u);
+          const float us = u * ratio;
+          ss[r] = __builtin_amdgcn_sinf(us);
+          cs[r] = __builtin_amdgcn_cosf(us);
+        } else {
+          sincos_rev<SINCOS>(u, sw[r], cw[r]);
+          sincos_rev<SINCOS>(u * ratio, ss[r], cs[r]);
+        }
       }
 #pragma unroll
       for (int m = 0; m < MRW; ++m) {
@@ -336,13 +321,132 @@ __global__ __launch_bounds__(256) void k_fused_mfma(const f32x4* __restrict__ mo
 #pragma unroll
     for (int i = 0; i < NS; ++i) acc[i] += (double)ts[i];
   }
+};
+
+// Launch geometry of k_fused_mfma (host side fills it; see aog_create):
+//   1-D grid of 8 * ceil(P/8) * wg_y workgroups.  Workgroup L runs on XCD L % 8 (round-robin dispatch, speed only):
+//   xcd = L & 7, j = L >> 3, env group = j % wg_y, pixel chunk c = (j / wg_y) * 8 + xcd, so the wg_y workgroups that
+//   share a pixel chunk (= the same mode-matrix and table tiles) sit on ONE XCD back to back and each XCD's L2 only ever
+//   sees 1/8 of the mode matrix.  Chunk c owns pixel tiles [c*n_ptiles/P, (c+1)*n_ptiles/P).
+#ifndef AOG_SCHED_PIPELINE
+#define AOG_SCHED_PIPELINE 0
+#endif
+
+struct MfmaGeom {
+  int n_ptiles, n_etiles, Bp, P, wg_y, we, max_tiles;
+};
+
+template <int A_PAD, int MRW, int MRS, int SINCOS>
+__global__ __launch_bounds__(256) void k_fused_mfma(const f32x4* __restrict__ modes_tile, const f32x4* __restrict__ tabs_tile,
+                                                    const f32x4* __restrict__ psi_tile, const float* __restrict__ act_tile,
+                                                    double* __restrict__ partials, MfmaGeom geo, float ratio) {
+  using T = MfmaTile<A_PAD, MRW, MRS, SINCOS>;
+  constexpr int NS = T::NS;
+  constexpr int MR = T::MR;
+  constexpr int NKQ = T::NKQ;
+  extern __shared__ f32x4 lds_tabs[];  // [tile in chunk][g][h][MR]
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int L = blockIdx.x;
+  const int j = L >> 3;
+  const int c = (j / geo.wg_y) * 8 + (L & 7);
+  if (c >= geo.P) return;  // whole workgroup: no barrier has been reached yet
+  const int we = geo.we, wp = 4 / we;                    // env tiles / pixel sub-chunks per workgroup
+  const int w_e = wave % we, w_p = wave / we;
+  const int etile = (j % geo.wg_y) * we + w_e;
+  const int t0 = (int)(((long long)c * geo.n_ptiles) / geo.P);
+  const int t1 = (int)(((long long)(c + 1) * geo.n_ptiles) / geo.P);
+
+  // stage this chunk's tables (contiguous in global memory) into LDS
+  {
+    const int n4 = (t1 - t0) * 8 * MR;
+    const f32x4* src = tabs_tile + (size_t)t0 * 8 * MR;
+    for (int i = threadIdx.x; i < n4; i += 256) lds_tabs[i] = src[i];
+  }
+  __syncthreads();
+  if (etile >= geo.n_etiles) return;
+
+  const int h = lane >> 5;
+  float b[A_PAD / 2];
+  {
+    const float* asrc = act_tile + (size_t)etile * A_PAD * 32;
+#pragma unroll
+    for (int kk = 0; kk < A_PAD / 2; ++kk) b[kk] = asrc[kk * 64 + lane];  // [2kk + h][lane&31]
+  }
+  double acc[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) acc[i] = 0.0;
+
+  // This wave's tiles: t0 + w_p + i*wp, i < n.  Software pipeline, all inside one wave:
+  //   stage i issues  (a) the screen tile of i+1 (consumed at the END of this stage, after the chain),
+  //                   (b) the mode tile of i+2 (consumed by the next stage's chain),
+  //   then runs the 32-MFMA chain of tile i+1 from a zero accumulator next to the sincos/accumulate VALU work of
+  //   tile i, and finally forms  d(i+1) = chain + screen.  Loads therefore have a full stage (~2k cycles) to land.
+  const int first = t0 + w_p;
+  const int n = first < t1 ? (t1 - first + wp - 1) / wp : 0;
+  if (n > 0) {
+    const size_t psi_base = (size_t)etile * geo.n_ptiles;
+    const int last = first + (n - 1) * wp;
+    auto load_modes = [&](f32x4 (&m)[NKQ], int t) {
+      const f32x4* ms = modes_tile + ((size_t)min(t, last) * NKQ) * 64 + lane;
+#pragma unroll
+      for (int kq = 0; kq < NKQ; ++kq) m[kq] = ms[kq * 64];
+    };
+    auto chain = [&](const f32x4 (&m)[NKQ]) {
+      f32x16 d = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kq = 0; kq < NKQ; ++kq) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d = __builtin_amdgcn_mfma_f32_32x32x2f32(m[kq][e], b[4 * kq + e], d, 0, 0, 0);
+      }
+      return d;
+    };
+    auto lds_row = [&](int t) { return lds_tabs + (size_t)(t - t0) * 8 * MR + h * MR; };
+
+    f32x4 mA[NKQ], mB[NKQ];
+    load_modes(mA, first);
+    load_modes(mB, first + wp);
+    f32x16 d = chain(mA) + T::load_psi(psi_tile, psi_base + first, lane);
+    // stage(i): d = phases of tile i, mcur = modes of tile i+1 (resident), mnext <- modes of tile i+2
+    auto stage = [&](int t, const f32x4 (&mcur)[NKQ], f32x4 (&mnext)[NKQ]) {
+      const f32x16 p = T::load_psi(psi_tile, psi_base + min(t + wp, last), lane);
+      f32x4 mtmp[NKQ];
+      load_modes(mtmp, t + 2 * wp);
+      f32x16 dn = chain(mcur);
+      T::reduce(d, lds_row(t), ratio, acc);
+      d = dn + p;
+#pragma unroll
+      for (int kq = 0; kq < NKQ; ++kq) mnext[kq] = mtmp[kq];
+      if constexpr (AOG_SCHED_PIPELINE) {
+        // ask the scheduler for: 1 MFMA, then its share of the vector work, for every link of the chain
+        constexpr int kValuPerMfma = (16 * (2 * MR + (SINCOS == 0 ? 60 : (SINCOS == 1 ? 9 : 5))) + 3 * NS + 16) / (4 * NKQ);
+#pragma unroll
+        for (int q = 0; q < 4 * NKQ; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, kValuPerMfma, 0);  // VALU (incl. transcendentals)
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);             // DS read
+        }
+      }
+    };
+    int i = 0;
+    int t = first;
+    for (; i + 2 < n; i += 2, t += 2 * wp) {
+      stage(t, mB, mA);        // consumes modes of tile i+1 (mB), refills mA with tile i+2
+      stage(t + wp, mA, mB);   // consumes modes of tile i+2 (mA), refills mB with tile i+3
+    }
+    if (i + 1 < n) {           // two tiles left: i (in d) and i+1 (modes in mB)
+      stage(t, mB, mA);
+      t += wp;
+    }
+    T::reduce(d, lds_row(t), ratio, acc);
+  }
   // the two half waves hold different pixels of the same 32 envs: fold h=1 into h=0, then store
-  const int chunk = blockIdx.x * wp + w_p;
-  double* out = partials + (size_t)chunk * NS * Bp + (size_t)etile * 32 + (lane & 31);
+  const int chunk = c * wp + w_p;
+  double* out = partials + (size_t)chunk * NS * geo.Bp + (size_t)etile * 32 + (lane & 31);
 #pragma unroll
   for (int i = 0; i < NS; ++i) {
     const double v = acc[i] + __shfl_down(acc[i], 32, 64);
-    if (h == 0) out[(size_t)i * Bp] = v;
+    if (h == 0) out[(size_t)i * geo.Bp] = v;
   }
 }
 
@@ -408,7 +512,7 @@ struct EpilogueArgs {
   double thr, ssim_peak, ssim_alpha;
 };
 
-__device__ inline double ssim_1d_delta_ref(const double* x, int n, double peak, int peak_idx) {
+__device__ inline double ssim_1d_delta_ref(const double* x, int stride, int n, double peak, int peak_idx) {
   // skimage.metrics.structural_similarity, 1-D, win 7, uniform filter, sample covariance; the reference image
   // is peak at peak_idx and 0 elsewhere (AO_env.py:491-495).  Mean over the interior windows.
   const double C1 = (0.01 * peak) * (0.01 * peak), C2 = (0.03 * peak) * (0.03 * peak);
@@ -418,7 +522,7 @@ __device__ inline double ssim_1d_delta_ref(const double* x, int n, double peak, 
   for (int i = 3; i < n - 3; ++i) {
     double ux = 0, uxx = 0, uy = 0, uyy = 0, uxy = 0;
     for (int k = -3; k <= 3; ++k) {
-      const double a = x[i + k];
+      const double a = x[(size_t)(i + k) * stride];
       const double b = (i + k == peak_idx) ? peak : 0.0;
       ux += a; uxx += a * a; uy += b; uyy += b * b; uxy += a * b;
     }
@@ -430,34 +534,46 @@ __device__ inline double ssim_1d_delta_ref(const double* x, int n, double peak, 
   return sum / cnt;
 }
 
-__global__ __launch_bounds__(64) void k_epilogue(EpilogueArgs p) {
-  const int env = blockIdx.x * blockDim.x + threadIdx.x;
-  if (env >= p.B) return;
+// block = 64 env lanes x (blockDim.x/64) waves; wave w reduces sums s = w, w+nw, ... over the chunk slabs
+// (coalesced 512-B rows, 4 independent accumulators), the sums meet in LDS, wave 0 finishes one env per lane.
+// dynamic LDS: (NS + n_obs) * 64 doubles.
+__global__ __launch_bounds__(1024) void k_epilogue(EpilogueArgs p) {
+  extern __shared__ double sm[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int env = blockIdx.x * 64 + lane;  // < Bp: padded envs read defined (ignored) slabs
   const int MR = p.MRW + p.MRS;
-  double U[80], V[80];
-  for (int m = 0; m < MR; ++m) {
-    double u = 0, v = 0;
-    for (int c = 0; c < p.n_chunks; ++c) {
-      const double* src = p.partials + ((size_t)c * 2 * MR + 2 * m) * p.Bp + env;
-      u += src[0];
-      v += src[p.Bp];
+  const int NS = 2 * MR;
+  const size_t cstride = (size_t)NS * p.Bp;
+  for (int s = wave; s < NS; s += nw) {
+    const double* src = p.partials + (size_t)s * p.Bp + env;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    int c = 0;
+    for (; c + 4 <= p.n_chunks; c += 4) {
+      a0 += src[(size_t)c * cstride];
+      a1 += src[(size_t)(c + 1) * cstride];
+      a2 += src[(size_t)(c + 2) * cstride];
+      a3 += src[(size_t)(c + 3) * cstride];
     }
-    U[m] = u;
-    V[m] = v;
+    for (; c < p.n_chunks; ++c) a0 += src[(size_t)c * cstride];
+    sm[s * 64 + lane] = (a0 + a1) + (a2 + a3);
   }
-  double obsv[64];
+  __syncthreads();
+  if (wave != 0 || env >= p.B) return;
+  const double* U = sm + lane;             // U_m = U[(2m) * 64], V_m = U[(2m + 1) * 64]
+  double* obsv = sm + (size_t)NS * 64 + lane;  // obsv[j * 64]
   double power = 0;
   const int n_out = p.n_obs + p.n_fiber;
   for (int j = 0; j < n_out; ++j) {
     double zr = 0, zi = 0;
     const double* cf = p.wfs_coef + (size_t)j * p.MRW_used * 2;
     for (int m = 0; m < p.MRW_used; ++m) {
-      zr += cf[2 * m] * U[m] - cf[2 * m + 1] * V[m];
-      zi += cf[2 * m] * V[m] + cf[2 * m + 1] * U[m];
+      const double u = U[(2 * m) * 64], v = U[(2 * m + 1) * 64];
+      zr += cf[2 * m] * u - cf[2 * m + 1] * v;
+      zi += cf[2 * m] * v + cf[2 * m + 1] * u;
     }
     const double pw = zr * zr + zi * zi;
     if (j < p.n_obs) {
-      obsv[j] = pw;
+      obsv[(size_t)j * 64] = pw;
       if (p.obs_raw) p.obs_raw[(size_t)env * p.n_obs + j] = (float)pw;
       if (p.obs) {
         const _Float16 hv = (_Float16)pw;  // round-to-nearest-even from float64, like np.array(x, float16)
@@ -470,15 +586,16 @@ __global__ __launch_bounds__(64) void k_epilogue(EpilogueArgs p) {
   if (!p.is_step) return;
   double zr = 0, zi = 0;
   for (int m = 0; m < p.MRS_used; ++m) {
-    zr += p.sci_coef[2 * m] * U[p.MRW + m] - p.sci_coef[2 * m + 1] * V[p.MRW + m];
-    zi += p.sci_coef[2 * m] * V[p.MRW + m] + p.sci_coef[2 * m + 1] * U[p.MRW + m];
+    const double u = U[(2 * (p.MRW + m)) * 64], v = U[(2 * (p.MRW + m) + 1) * 64];
+    zr += p.sci_coef[2 * m] * u - p.sci_coef[2 * m + 1] * v;
+    zi += p.sci_coef[2 * m] * v + p.sci_coef[2 * m + 1] * u;
   }
   const double strehl = zr * zr + zi * zi;
   double reward;
   if (p.reward_type == 0) {
     reward = -(100.0 - strehl * 100.0);
   } else {
-    const double ssim = ssim_1d_delta_ref(obsv, p.n_obs, p.ssim_peak, p.n_obs / 2);
+    const double ssim = ssim_1d_delta_ref(obsv, 64, p.n_obs, p.ssim_peak, p.n_obs / 2);
     reward = p.ssim_alpha * power + (1.0 - p.ssim_alpha) * ssim;
   }
   if (p.has_thr && reward < p.thr) reward = -1.0;

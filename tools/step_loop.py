@@ -1,0 +1,31 @@
+"""Minimal driver for profiling: config-2 shaped batch, a few steps, nothing else on the GPU after setup."""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from adaptive_optics_gym_amd import BatchedAOEnv
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--B", type=int, default=1024); ap.add_argument("--N", type=int, default=256)
+ap.add_argument("--A", type=int, default=64); ap.add_argument("--o", type=int, default=2)
+ap.add_argument("--steps", type=int, default=20); ap.add_argument("--kernel", default="auto")
+ap.add_argument("--chunks", type=int, default=0); ap.add_argument("--act_type", default="num_actuators")
+args = ap.parse_args()
+dev = torch.device("cuda:0")
+g = torch.Generator(dev).manual_seed(1)
+# cheap synthetic screens (smooth random, a few rad rms): the fused kernel's cost does not depend on their spectrum
+scr = torch.nn.functional.interpolate(torch.randn(args.B, 1, 16, 16, device=dev, generator=g), size=(args.N, args.N),
+                                      mode="bicubic").squeeze(1) * 2e-6
+env = BatchedAOEnv(args.B, dev, num_pupil_pixels=args.N, act_dim=args.A, obs_dim=args.o, act_type=args.act_type,
+                   timesteps_per_episode=1000000, kernel=args.kernel, pixel_chunks=args.chunks, screens=scr, verbose=False)
+a = torch.randn(args.B, args.A, device=dev, generator=g) * 0.7071
+env.reset()
+for _ in range(3): env.step(a)
+torch.cuda.synchronize()
+env.profile(True)
+t0 = time.perf_counter()
+for _ in range(args.steps): env.step(a)
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+ms, n = env.profile_read()
+print(f"B={args.B} N={args.N} A={args.A} o={args.o} kernel={env.info.kernel} chunks={env.info.pixel_chunks} "
+      f"wall {args.B*args.steps/dt/1e6:.3f} Msteps/s  fused {ms*1e3:.1f} us -> {args.B/ms/1e3:.3f} Msteps/s", flush=True)
