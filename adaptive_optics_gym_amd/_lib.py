@@ -50,6 +50,7 @@ SYMBOLS = {
     "aog_set_actuators": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "aog_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "aog_step": (C.c_int, [C.c_void_p] * 9),
+    "aog_selftest_sincos": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "aog_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "aog_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
 }

@@ -1,6 +1,7 @@
 // libaogym.so — C-ABI (include/aogym.h) over the gfx950 kernels in aogym_kernels.h.
 // Host side only: argument checking, table conversion/upload, launch geometry, stream-ordered launches.
-#include "../../include/aogym.h"
+#define AOG_MAIN_TU 1
+#include "aogym_internal.h"
 #include "aogym_kernels.h"
 
 #include <algorithm>
@@ -32,7 +33,7 @@ int fail(int code, const char* fmt, ...) {
       return fail(AOG_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
   } while (0)
 
-inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+using aog_host::round_up;
 
 struct DevBuf {
   void* p = nullptr;
@@ -41,49 +42,6 @@ struct DevBuf {
 
 }  // namespace
 
-struct aog_env {
-  aog_config cfg{};
-  int device = 0;
-  bool tables_ready = false;
-  bool screens_ready = false;
-  int B = 0, Bp = 0, A = 0, A_pad = 0, n_ap = 0, n_ap_pad = 0, n_quads = 0, n_ptiles = 0, n_etiles = 0;
-  int MRW = 0, MRS = 0;          // padded table counts of the fast kernels
-  int MRW_used = 0, MRS_used = 0;
-  int n_obs = 0, n_out = 0;
-  int kernel = AOG_KERNEL_VALU;  // resolved
-  int sincos_hw = 0;
-  // launch geometry
-  int valu_chunks = 0, valu_qpc = 0;
-  int mfma_we = 1, mfma_chunks_x = 0, mfma_tpc = 0;
-  int n_chunks = 0;              // partial slabs the epilogue sums
-  int64_t dev_bytes = 0;
-  // constant tables
-  int32_t* ap_index = nullptr;
-  float* modes_f32 = nullptr;    // [n_ap_pad][A_pad]
-  float* modes_tile = nullptr;   // [n_ptiles][A_pad/8][64][4]
-  float* tabs_f32 = nullptr;     // [n_ap_pad][TROW]
-  float* tabs_tile = nullptr;    // [n_ptiles][4][2][MRW+MRS][4]
-  double* gram = nullptr;        // [A][A]
-  double* wfs_coef = nullptr;    // [n_out][MRW_used][2]
-  double* sci_coef = nullptr;    // [MRS_used][2]
-  double* modes64 = nullptr;     // validation: [n_ap][A]
-  double* tabs64 = nullptr;      // validation: [n_ap][MRW_used+MRS_used]
-  // state
-  float* psi_rev = nullptr;      // [n_quads][Bp][4]
-  float* psi_tile = nullptr;     // [Bp/32][n_ptiles][4][64][4]
-  double* psi64 = nullptr;       // validation: [B][n_ap]
-  double* act_dm = nullptr;      // [B][A]
-  float* act_rev = nullptr;      // [A_pad][Bp]
-  float* act_tile = nullptr;     // [Bp/32][A_pad][32]
-  int32_t* t_render = nullptr;   // [B]
-  double* partials = nullptr;
-  size_t partial_elems = 0;
-  // profiling of the fused kernel
-  bool profile = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
-  size_t events_used = 0;
-  std::vector<void*> allocs;
-};
 
 namespace {
 
@@ -105,66 +63,15 @@ int pick_pad(int v, const int* opts, int n) {
   return -1;
 }
 
-const int kApadOpts[] = {8, 16, 32, 64, 128};
-const int kMrwOpts[] = {8, 12, 20, 28};
-
-// ---- fused kernel dispatch -------------------------------------------------------------------------
-template <int A_PAD, int MRW, int SC>
-void launch_valu(aog_env* e, hipStream_t s) {
-  const int n_groups = e->Bp / 64;
-  dim3 grid(e->valu_chunks, (n_groups + 3) / 4);
-  const float ratio = (float)(e->cfg.wavelength_wfs / e->cfg.wavelength_sci);
-  hipLaunchKernelGGL((aog::k_fused_valu<A_PAD, MRW, 1, SC>), grid, dim3(256), 0, s, e->modes_f32, e->tabs_f32,
-                     reinterpret_cast<const float4*>(e->psi_rev), e->act_rev, e->partials, e->n_quads, e->Bp, n_groups,
-                     e->valu_qpc, ratio);
-}
-
-template <int A_PAD, int MRW, int SC>
-void launch_mfma(aog_env* e, hipStream_t s) {
-  aog::MfmaGeom g;
-  g.n_ptiles = e->n_ptiles;
-  g.n_etiles = e->n_etiles;
-  g.Bp = e->Bp;
-  g.P = e->mfma_chunks_x;
-  g.we = e->mfma_we;
-  g.wg_y = (e->n_etiles + e->mfma_we - 1) / e->mfma_we;
-  g.max_tiles = e->mfma_tpc;
-  dim3 grid(round_up(g.P, 8) * g.wg_y);
-  const float ratio = (float)(e->cfg.wavelength_wfs / e->cfg.wavelength_sci);
-  const size_t lds = (size_t)e->mfma_tpc * 8 * (MRW + 1) * 16;
-  hipLaunchKernelGGL((aog::k_fused_mfma<A_PAD, MRW, 1, SC>), grid, dim3(256), lds, s,
-                     reinterpret_cast<const aog::f32x4*>(e->modes_tile), reinterpret_cast<const aog::f32x4*>(e->tabs_tile),
-                     reinterpret_cast<const aog::f32x4*>(e->psi_tile), e->act_tile, e->partials, g, ratio);
-}
-
-template <int A_PAD, int MRW>
-void launch_fast2(aog_env* e, hipStream_t s) {
-  if (e->kernel == AOG_KERNEL_MFMA) {
-    if (e->sincos_hw == 2) launch_mfma<A_PAD, MRW, 2>(e, s);
-    else if (e->sincos_hw == 1) launch_mfma<A_PAD, MRW, 1>(e, s);
-    else launch_mfma<A_PAD, MRW, 0>(e, s);
-  } else {
-    if (e->sincos_hw) launch_valu<A_PAD, MRW, 1>(e, s); else launch_valu<A_PAD, MRW, 0>(e, s);
-  }
-}
-
-template <int A_PAD>
-void launch_fast1(aog_env* e, hipStream_t s) {
-  switch (e->MRW) {
-    case 8: launch_fast2<A_PAD, 8>(e, s); break;
-    case 12: launch_fast2<A_PAD, 12>(e, s); break;
-    case 20: launch_fast2<A_PAD, 20>(e, s); break;
-    default: launch_fast2<A_PAD, 28>(e, s); break;
-  }
-}
+const int kApadOpts[] = {16, 32, 64, 128};
+const int kMrwOpts[] = {7, 12, 20, 28};
 
 void launch_fast(aog_env* e, hipStream_t s) {
   switch (e->A_pad) {
-    case 8: launch_fast1<8>(e, s); break;
-    case 16: launch_fast1<16>(e, s); break;
-    case 32: launch_fast1<32>(e, s); break;
-    case 64: launch_fast1<64>(e, s); break;
-    default: launch_fast1<128>(e, s); break;
+    case 16: aog_host::launch_fused_apad16(e, s); break;
+    case 32: aog_host::launch_fused_apad32(e, s); break;
+    case 64: aog_host::launch_fused_apad64(e, s); break;
+    default: aog_host::launch_fused_apad128(e, s); break;
   }
 }
 
@@ -294,13 +201,14 @@ int aog_create(const aog_config* cfg, int device, aog_env** out) {
   e->n_obs = cfg->obs_dim * cfg->obs_dim;
   e->n_out = e->n_obs + cfg->n_fiber_modes;
   e->sincos_hw = 0;
-  // sin/cos flavour of the fast kernels: "hw" (default; v_sin_f32/v_cos_f32 after the exact reduction),
-  // "hwraw" (same instructions on the unreduced revolutions), "poly" (degree-7/8 polynomial)
+  // sin/cos flavour of the fast kernels: "hwraw" (default; v_sin_f32/v_cos_f32 on the revolutions, the instruction
+  // reduces them itself), "hw" (same instructions after an explicit exact reduction), "poly" (degree-7/8 polynomial)
   e->sincos_hw = 1;
+  if (const char* ab = getenv("AOG_ABLATE")) e->ablate = atoi(ab);
   if (const char* sc = getenv("AOG_SINCOS")) e->sincos_hw = strcmp(sc, "poly") == 0 ? 0 : (strcmp(sc, "hwraw") == 0 ? 2 : 1);
 
   if (cfg->precision == AOG_PRECISION_FAST) {
-    e->A_pad = pick_pad(e->A, kApadOpts, 5);
+    e->A_pad = pick_pad(e->A, kApadOpts, 4);
     e->MRW = pick_pad(e->MRW_used, kMrwOpts, 4);
     e->MRS = 1;
     if (e->A_pad < 0 || e->MRW < 0 || e->MRS_used != 1) {
@@ -347,13 +255,13 @@ int aog_create(const aog_config* cfg, int device, aog_env** out) {
   TRY_ALLOC(dev_alloc(e, &e->sci_coef, (size_t)e->MRS_used * 2));
   TRY_ALLOC(dev_alloc(e, &e->act_dm, (size_t)e->B * e->A));
   TRY_ALLOC(dev_alloc(e, &e->act_rev, (size_t)e->A_pad * e->Bp));
-  TRY_ALLOC(dev_alloc(e, &e->act_tile, (size_t)e->n_etiles * e->A_pad * 32));
+  TRY_ALLOC(dev_alloc(e, &e->act16, (size_t)e->n_etiles * e->A_pad * 32 * 2));
   TRY_ALLOC(dev_alloc(e, &e->t_render, e->B));
   TRY_ALLOC(dev_alloc(e, &e->partials, e->partial_elems));
   if (cfg->precision == AOG_PRECISION_FAST) {
     const int TROW = round_up(e->MRW + e->MRS, 4);
     TRY_ALLOC(dev_alloc(e, &e->modes_f32, (size_t)e->n_ap_pad * e->A_pad));
-    TRY_ALLOC(dev_alloc(e, &e->modes_tile, (size_t)e->n_ap_pad * e->A_pad));
+    TRY_ALLOC(dev_alloc(e, &e->modes16, (size_t)e->n_ap_pad * e->A_pad * 2));
     TRY_ALLOC(dev_alloc(e, &e->tabs_f32, (size_t)e->n_ap_pad * TROW));
     TRY_ALLOC(dev_alloc(e, &e->tabs_tile, (size_t)e->n_ap_pad * (e->MRW + e->MRS)));
     TRY_ALLOC(dev_alloc(e, &e->psi_rev, (size_t)e->n_quads * e->Bp * 4));
@@ -419,15 +327,21 @@ int aog_upload_tables(aog_env* e, const aog_tables* t) {
     }
     HIP_TRY(hipMemcpy(e->tabs64, tb.data(), sizeof(double) * tb.size(), hipMemcpyHostToDevice));
   } else {
-    const int Ap = e->A_pad, MR = e->MRW + e->MRS, TROW = round_up(MR, 4), NKQ = Ap / 8;
-    std::vector<float> mf((size_t)e->n_ap_pad * Ap, 0.f), mt((size_t)e->n_ap_pad * Ap, 0.f);
+    const int Ap = e->A_pad, MR = e->MRW + e->MRS, TROW = round_up(MR, 4);
+    std::vector<float> mf((size_t)e->n_ap_pad * Ap, 0.f);
+    std::vector<_Float16> m16((size_t)e->n_ap_pad * Ap * 2, (_Float16)0.f);
+    const int nstep = Ap / 16;
     for (int p = 0; p < n_ap; ++p)
       for (int k = 0; k < A; ++k) {
         const float v = (float)t->modes[(size_t)p * A + k];
         mf[(size_t)p * Ap + k] = v;
-        // modes_tile[pt][kq][lane = 32*h + i][el], mode k = 2*(4*kq + el) + h
-        const int pt = p >> 5, i = p & 31, h = k & 1, kk = k >> 1, kq = kk >> 2, el = kk & 3;
-        mt[(((size_t)pt * NKQ + kq) * 64 + (h * 32 + i)) * 4 + el] = v;
+        // modes16[pt][s][hi|lo][lane = 32*h + i][el], mode k = 16 s + 8 h + el
+        _Float16 hi, lo;
+        aog::split_f16(v * aog::kModeScale, hi, lo);
+        const int pt = p >> 5, i = p & 31, sidx = k >> 4, h = (k >> 3) & 1, el = k & 7;
+        const size_t base = (((size_t)pt * nstep + sidx) * 2) * 64 + (h * 32 + i);
+        m16[base * 8 + el] = hi;
+        m16[(base + 64) * 8 + el] = lo;
       }
     std::vector<float> tf((size_t)e->n_ap_pad * TROW, 0.f), tt((size_t)e->n_ap_pad * MR, 0.f);
     auto tab = [&](int m, int p) -> float {
@@ -444,7 +358,7 @@ int aog_upload_tables(aog_env* e, const aog_tables* t) {
         tt[((((size_t)pt * 4 + g) * 2 + h) * MR + m) * 4 + r] = v;
       }
     HIP_TRY(hipMemcpy(e->modes_f32, mf.data(), sizeof(float) * mf.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(e->modes_tile, mt.data(), sizeof(float) * mt.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->modes16, m16.data(), sizeof(_Float16) * m16.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->tabs_f32, tf.data(), sizeof(float) * tf.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->tabs_tile, tt.data(), sizeof(float) * tt.size(), hipMemcpyHostToDevice));
   }
@@ -474,7 +388,7 @@ int aog_set_actuators(aog_env* e, const double* act_dev, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   HIP_TRY(hipMemcpyAsync(e->act_dm, act_dev, sizeof(double) * e->B * e->A, hipMemcpyDeviceToDevice, s));
   const int n = e->B * e->A_pad;
-  hipLaunchKernelGGL(aog::k_load_actuators, dim3((n + 255) / 256), dim3(256), 0, s, e->act_dm, e->act_rev, e->act_tile,
+  hipLaunchKernelGGL(aog::k_load_actuators, dim3((n + 255) / 256), dim3(256), 0, s, e->act_dm, e->act_rev, e->act16,
                      e->B, e->A, e->A_pad, e->Bp, 2.0 / e->cfg.wavelength_wfs);
   HIP_TRY(hipGetLastError());
   return AOG_OK;
@@ -490,7 +404,7 @@ int aog_reset(aog_env* e, const uint8_t* mask, float* obs_raw, uint16_t* obs, vo
     hipLaunchKernelGGL(aog::k_reset_state, dim3((n + 255) / 256), dim3(256), 0, s, mask, e->act_dm, e->t_render, e->B, e->A,
                        e->cfg.flat_mirror_start);
     const int n2 = e->B * e->A_pad;
-    hipLaunchKernelGGL(aog::k_load_actuators, dim3((n2 + 255) / 256), dim3(256), 0, s, e->act_dm, e->act_rev, e->act_tile,
+    hipLaunchKernelGGL(aog::k_load_actuators, dim3((n2 + 255) / 256), dim3(256), 0, s, e->act_dm, e->act_rev, e->act16,
                        e->B, e->A, e->A_pad, e->Bp, 2.0 / e->cfg.wavelength_wfs);
     HIP_TRY(hipGetLastError());
   }
@@ -507,12 +421,21 @@ int aog_step(aog_env* e, const float* action, float* obs_raw, uint16_t* obs, flo
     return fail(AOG_ERR_INVALID, "win_size exceeds image extent (smf_ssim needs obs_dim**2 >= 7; AO_env.py:495)");
   HIP_TRY(hipSetDevice(e->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(aog::k_prologue, dim3(e->B), dim3(64), 0, s, action, e->gram, e->act_dm, e->act_rev, e->act_tile, e->A,
+  hipLaunchKernelGGL(aog::k_prologue, dim3(e->B), dim3(64), 0, s, action, e->gram, e->act_dm, e->act_rev, e->act16, e->A,
                      e->A_pad, e->Bp, e->cfg.sh_operation, e->cfg.surface_rms_target, 2.0 / e->cfg.wavelength_wfs);
   HIP_TRY(hipGetLastError());
   int rc = launch_fused(e, s);
   if (rc != AOG_OK) return rc;
   return launch_epilogue(e, true, obs_raw, obs, reward, done, power, strehl, s);
+}
+
+int aog_selftest_sincos(const float* u_dev, float* sin_dev, float* cos_dev, int n, int flavour, void* stream) {
+  if (!u_dev || !sin_dev || !cos_dev || n < 0 || flavour < 0 || flavour > 2) return fail(AOG_ERR_INVALID, "aog_selftest_sincos: bad argument");
+  if (n == 0) return AOG_OK;
+  hipLaunchKernelGGL(aog::k_selftest_sincos, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), u_dev, sin_dev,
+                     cos_dev, n, flavour);
+  HIP_TRY(hipGetLastError());
+  return AOG_OK;
 }
 
 int aog_profile_enable(aog_env* e, int enable) {

@@ -1,0 +1,64 @@
+// Internal (non-ABI) declarations shared by the translation units of libaogym.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <utility>
+#include <vector>
+
+#include "../../include/aogym.h"
+
+struct aog_env {
+  aog_config cfg{};
+  int device = 0;
+  bool tables_ready = false;
+  bool screens_ready = false;
+  int B = 0, Bp = 0, A = 0, A_pad = 0, n_ap = 0, n_ap_pad = 0, n_quads = 0, n_ptiles = 0, n_etiles = 0;
+  int MRW = 0, MRS = 0;          // padded table counts of the fast kernels
+  int MRW_used = 0, MRS_used = 0;
+  int n_obs = 0, n_out = 0;
+  int kernel = AOG_KERNEL_VALU;  // resolved
+  int sincos_hw = 0;
+  int ablate = 0;  // AOG_ABLATE diagnostic (timing only; results are wrong by construction)
+  // launch geometry
+  int valu_chunks = 0, valu_qpc = 0;
+  int mfma_we = 1, mfma_chunks_x = 0, mfma_tpc = 0;
+  int n_chunks = 0;              // partial slabs the epilogue sums
+  int64_t dev_bytes = 0;
+  // constant tables
+  int32_t* ap_index = nullptr;
+  float* modes_f32 = nullptr;    // [n_ap_pad][A_pad]
+  _Float16* modes16 = nullptr;   // [n_ptiles][A_pad/16][hi|lo][64][8]
+  float* tabs_f32 = nullptr;     // [n_ap_pad][TROW]
+  float* tabs_tile = nullptr;    // [n_ptiles][4][2][MRW+MRS][4]
+  double* gram = nullptr;        // [A][A]
+  double* wfs_coef = nullptr;    // [n_out][MRW_used][2]
+  double* sci_coef = nullptr;    // [MRS_used][2]
+  double* modes64 = nullptr;     // validation: [n_ap][A]
+  double* tabs64 = nullptr;      // validation: [n_ap][MRW_used+MRS_used]
+  // state
+  float* psi_rev = nullptr;      // [n_quads][Bp][4]
+  float* psi_tile = nullptr;     // [Bp/32][n_ptiles][4][64][4]
+  double* psi64 = nullptr;       // validation: [B][n_ap]
+  double* act_dm = nullptr;      // [B][A]
+  float* act_rev = nullptr;      // [A_pad][Bp]
+  _Float16* act16 = nullptr;     // [Bp/32][A_pad/16][hi|lo][64][8]
+  int32_t* t_render = nullptr;   // [B]
+  double* partials = nullptr;
+  size_t partial_elems = 0;
+  // profiling of the fused kernel
+  bool profile = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  size_t events_used = 0;
+  std::vector<void*> allocs;
+};
+
+namespace aog_host {
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+// Fused-kernel launchers, one translation unit per padded mode count so the build parallelises
+// (fused_inst.hip compiled with -DAOG_INST_APAD=16|32|64|128).
+void launch_fused_apad16(aog_env* e, hipStream_t s);
+void launch_fused_apad32(aog_env* e, hipStream_t s);
+void launch_fused_apad64(aog_env* e, hipStream_t s);
+void launch_fused_apad128(aog_env* e, hipStream_t s);
+}  // namespace aog_host

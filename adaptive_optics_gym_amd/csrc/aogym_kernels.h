@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <utility>
+
 namespace aog {
 
 constexpr float kLog2Dummy = 0.f;
@@ -93,17 +95,31 @@ __global__ __launch_bounds__(256) void k_pack_screens(const T* __restrict__ psi,
   }
 }
 
+// one actuator value (revolutions) -> the hi/lo f16 B-operand layout of k_fused_mfma:
+//   act16[env tile][s = i/16][hi|lo][lane = 32*((i/8)&1) + env%32][i%8]   (A_pad is a multiple of 16 for this layout)
+__device__ __forceinline__ void store_act16(_Float16* __restrict__ act16, int env, int i, int A_pad, float ar) {
+  if (act16 == nullptr || (A_pad & 15)) return;
+  const float sc = ar * 256.0f;  // kActScale
+  const _Float16 hi = (_Float16)sc;
+  const _Float16 lo = (_Float16)((sc - (float)hi) * 2048.0f);
+  const int s = i >> 4, h = (i >> 3) & 1, e = i & 7, nstep = A_pad >> 4;
+  const size_t base = (((size_t)(env >> 5) * nstep + s) * 2) * 64 + (h * 32 + (env & 31));
+  act16[base * 8 + e] = hi;
+  act16[(base + 64) * 8 + e] = lo;
+}
+
 // ------------------------------------------------------------------------------------------------
 // K1  prologue: action -> actuators (AO_env.py:115-120).  One wave per env.
 //   a'_i = action_i / (i + 10);  var = a'^T G a'  (G = centred Gram, float64);  a'' = a' * target / sqrt(var)
 //   act_dm  [B][A] float64 (metres)         — deformable_mirror.actuators
 //   act_rev [A_PAD][Bp] float32             — 2 a''/lambda_wfs (revolutions of wfs phase per unit mode)
-//   act_tile (MFMA B-operand order) [env/32][A_PAD][32]
+//   act16   (MFMA B-operand order, hi/lo f16 halves) [env/32][A_PAD/16][hi|lo][64 lanes][8]
 // A zero action gives 0/0 = NaN exactly like numpy (documented in DESIGN.md).
 // ------------------------------------------------------------------------------------------------
+#ifdef AOG_MAIN_TU
 __global__ __launch_bounds__(64) void k_prologue(const float* __restrict__ action, const double* __restrict__ gram,
                                                  double* __restrict__ act_dm, float* __restrict__ act_rev,
-                                                 float* __restrict__ act_tile, int A, int A_pad, int Bp,
+                                                 _Float16* __restrict__ act16, int A, int A_pad, int Bp,
                                                  int sh_operation, double target, double two_over_lambda) {
   const int env = blockIdx.x;
   const int lane = threadIdx.x;
@@ -131,22 +147,26 @@ __global__ __launch_bounds__(64) void k_prologue(const float* __restrict__ actio
     if (i < A) act_dm[(size_t)env * A + i] = a;
     const float ar = (float)(a * two_over_lambda);
     act_rev[(size_t)i * Bp + env] = ar;
-    act_tile[((size_t)(env >> 5) * A_pad + i) * 32 + (env & 31)] = ar;
+    store_act16(act16, env, i, A_pad, ar);
   }
 }
+#endif  // AOG_MAIN_TU
 
 // actuators (metres, float64) -> the two fp32 operand layouts (used by reset / set_actuators)
+#ifdef AOG_MAIN_TU
 __global__ void k_load_actuators(const double* __restrict__ act_dm, float* __restrict__ act_rev,
-                                 float* __restrict__ act_tile, int B, int A, int A_pad, int Bp, double two_over_lambda) {
+                                 _Float16* __restrict__ act16, int B, int A, int A_pad, int Bp, double two_over_lambda) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= B * A_pad) return;
   const int env = idx / A_pad, i = idx % A_pad;
   const float ar = (i < A) ? (float)(act_dm[(size_t)env * A + i] * two_over_lambda) : 0.f;
   act_rev[(size_t)i * Bp + env] = ar;
-  act_tile[((size_t)(env >> 5) * A_pad + i) * 32 + (env & 31)] = ar;
+  store_act16(act16, env, i, A_pad, ar);
 }
+#endif  // AOG_MAIN_TU
 
 // AOEnv.reset bookkeeping (AO_env.py:79-83)
+#ifdef AOG_MAIN_TU
 __global__ void k_reset_state(const uint8_t* __restrict__ mask, double* __restrict__ act_dm, int32_t* __restrict__ t_render,
                               int B, int A, int flatten) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -156,6 +176,7 @@ __global__ void k_reset_state(const uint8_t* __restrict__ mask, double* __restri
   if (flatten) act_dm[idx] = 0.0;
   if (i == 0) t_render[env] = 0;
 }
+#endif  // AOG_MAIN_TU
 
 // ------------------------------------------------------------------------------------------------
 // K3a  fused pupil pass, VALU form.  lane = env (64 envs per wave), every per-pixel operand (mode row,
@@ -231,119 +252,133 @@ __global__ __launch_bounds__(256) void k_fused_valu(const float* __restrict__ mo
 
 // ------------------------------------------------------------------------------------------------
 // K3b  fused pupil pass, MFMA form.  One wave owns a 32-env tile and walks 32-pixel tiles:
-//     D[pixel i][env j] = psi[i][j] + sum_k Mt[i][k] * a[k][j]          (v_mfma_f32_32x32x2_f32, K = A_PAD)
-// so the accumulator is initialised with the screen tile and comes back as the wfs phase in revolutions.
+//     D[pixel i][env j] = psi[i][j] + sum_k Mt[i][k] * a[k][j]                         (K = A_PAD modes)
+// The contraction runs on the f16 matrix cores with BOTH operands split in two halves that together carry
+// fp32 precision:   x = x_hi + 2^-11 x_lo,  x_hi = half(x),  x_lo = half((x - x_hi) * 2^11)   (|x - x_hi - 2^-11 x_lo| <= 2^-24 |x|)
+//     D1 = Mh.ah           D2 = Mh.al + Ml.ah           u = psi + c1 D1 + c2 D2        (the 2^-22 Ml.al term is dropped)
+// = 3 x v_mfma_f32_32x32x16_f16 per 16 modes, products exact in fp32, fp32 accumulation.  Unlike v_mfma_f32_32x32x2_f32
+// (which was measured NOT to overlap with vector instructions: fused = vector-only + matrix-only time, profiles/r01), the
+// f16 matrix pipe co-executes with the VALU, so the kernel is bounded by its sincos/accumulate vector work.
 // C/D register map: lane l holds env j = l&31 and pixels i = (r&3) + 8*(r>>2) + 4*(l>>5), r < 16.
-//   psi_tile  [env tile][pixel tile][g=r>>2][lane][r&3]   -> one float4 per lane per g, 1 KiB per instruction
-//   modes_tile[pixel tile][kq][lane][4]: lane (i = l&31, h = l>>5), element e <-> mode k = 2*(4*kq+e) + h
-//   act_tile  [env tile][k][32]: B operand of k-step kk is act_tile[2*kk + h][j] = one coalesced dword load
-//   tabs_tile [pixel tile][g][h][MRW+MRS][4]: per-pixel tables, identical for the 32 lanes of a half wave;
-//             staged in LDS once per workgroup and read back with broadcast ds_read_b128.
-// grid = (pixel chunks, ceil(env tiles / WE)); block = 256 = WE env tiles x WP pixel sub-chunks (WE*WP = 4).
+//   psi_tile   [env tile][pixel tile][g=r>>2][lane][r&3]        one float4 per lane per g, 1 KiB per instruction
+//   modes16    [pixel tile][s][hi|lo][lane][8 halfs]: lane (pixel i = l&31, h = l>>5), element e <-> mode 16 s + 8 h + e
+//   act16      [env tile][s][hi|lo][lane][8 halfs]:   lane (env j = l&31, h),          element e <-> mode 16 s + 8 h + e
+//   tabs_tile  [pixel tile][g][h][MRW+MRS][4]: per-pixel tables, identical for the 32 lanes of a half wave;
+//              staged in LDS once per workgroup and read back with broadcast ds_read_b128.
 // ------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// Operands are pre-scaled into the middle of the f16 range so that neither half is ever subnormal for values that matter:
+//   modes (|M| <= 1) by 2^14, actuators in revolutions (|a| < 255) by 2^8;  u = psi + 2^-22 D1 + 2^-33 D2.
+constexpr float kLoScale = 2048.0f;                  // 2^11
+constexpr float kModeScale = 16384.0f;               // 2^14
+constexpr float kActScale = 256.0f;                  // 2^8
+constexpr float kD1Unscale = 1.0f / (16384.0f * 256.0f);           // 2^-22
+constexpr float kD2Unscale = 1.0f / (16384.0f * 256.0f * 2048.0f); // 2^-33
 
-// SINCOS: 0 polynomial, 1 hardware v_sin/v_cos after the exact reduction, 2 hardware v_sin/v_cos on the raw
-// revolutions (the instruction takes fract() itself; |u| stays far below its +-256 domain).
-template <int A_PAD, int MRW, int MRS, int SINCOS>
-struct MfmaTile {
-  static constexpr int NS = 2 * (MRW + MRS);
-  static constexpr int MR = MRW + MRS;
-  static constexpr int NKQ = A_PAD / 8;
-
-  static __device__ __forceinline__ f32x16 load_psi(const f32x4* __restrict__ psi_tile, size_t tile_index, int lane) {
-    const f32x4* ps = psi_tile + (tile_index * 4) * 64 + lane;
-    f32x16 d;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x4 v = ps[g * 64];
-      d[4 * g + 0] = v[0]; d[4 * g + 1] = v[1]; d[4 * g + 2] = v[2]; d[4 * g + 3] = v[3];
-    }
-    return d;
-  }
-
-  // D = psi + Mt a  for pixel tile t (32 MFMAs at A_PAD = 64)
-  static __device__ __forceinline__ f32x16 chain(f32x16 d, const f32x4* __restrict__ modes_tile, int t, int lane,
-                                                 const float (&b)[A_PAD / 2]) {
-    const f32x4* ms = modes_tile + ((size_t)t * NKQ) * 64 + lane;
-#pragma unroll
-    for (int kq = 0; kq < NKQ; ++kq) {
-      const f32x4 av = ms[kq * 64];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) d = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], b[4 * kq + e], d, 0, 0, 0);
-    }
-    return d;
-  }
-
-  // phases of one finished tile -> the NS running sums
-  static __device__ __forceinline__ void reduce(const f32x16& d, const f32x4* lt /* lds row of (tile, h) */, float ratio,
-                                                double (&acc)[NS]) {
-    float ts[NS];
-#pragma unroll
-    for (int i = 0; i < NS; ++i) ts[i] = 0.f;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      float cw[4], sw[4], cs[4], ss[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float u = d[4 * g + r];
-        if constexpr (SINCOS == 2) {
-          sw[r] = __builtin_amdgcn_sinf(u);
-          cw[r] = __builtin_amdgcn_cosf(u);
-          const float us = u * ratio;
-          ss[r] = __builtin_amdgcn_sinf(us);
-          cs[r] = __builtin_amdgcn_cosf(us);
-        } else {
-          sincos_rev<SINCOS>(u, sw[r], cw[r]);
-          sincos_rev<SINCOS>(u * ratio, ss[r], cs[r]);
-        }
-      }
-#pragma unroll
-      for (int m = 0; m < MRW; ++m) {
-        const f32x4 gv = lt[(g * 2) * MR + m];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          ts[2 * m] = fmaf(cw[r], gv[r], ts[2 * m]);
-          ts[2 * m + 1] = fmaf(sw[r], gv[r], ts[2 * m + 1]);
-        }
-      }
-#pragma unroll
-      for (int m = 0; m < MRS; ++m) {
-        const f32x4 gv = lt[(g * 2) * MR + MRW + m];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          ts[2 * (MRW + m)] = fmaf(cs[r], gv[r], ts[2 * (MRW + m)]);
-          ts[2 * (MRW + m) + 1] = fmaf(ss[r], gv[r], ts[2 * (MRW + m) + 1]);
-        }
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < NS; ++i) acc[i] += (double)ts[i];
-  }
-};
+// x (already multiplied by its operand scale) -> hi + 2^-11 lo
+__device__ __host__ inline void split_f16(float x, _Float16& hi, _Float16& lo) {
+  hi = (_Float16)x;
+  lo = (_Float16)((x - (float)hi) * kLoScale);
+}
 
 // Launch geometry of k_fused_mfma (host side fills it; see aog_create):
 //   1-D grid of 8 * ceil(P/8) * wg_y workgroups.  Workgroup L runs on XCD L % 8 (round-robin dispatch, speed only):
 //   xcd = L & 7, j = L >> 3, env group = j % wg_y, pixel chunk c = (j / wg_y) * 8 + xcd, so the wg_y workgroups that
 //   share a pixel chunk (= the same mode-matrix and table tiles) sit on ONE XCD back to back and each XCD's L2 only ever
 //   sees 1/8 of the mode matrix.  Chunk c owns pixel tiles [c*n_ptiles/P, (c+1)*n_ptiles/P).
-#ifndef AOG_SCHED_PIPELINE
-#define AOG_SCHED_PIPELINE 0
-#endif
-
 struct MfmaGeom {
   int n_ptiles, n_etiles, Bp, P, wg_y, we, max_tiles;
 };
 
+// ---- compile-time interleave plan -------------------------------------------------------------------------------
+// The vector work of one finished tile is cut into micro-ops
+//   SC(i)    sincos of accumulator register i at both wavelengths            (i = 4g + r, 16 per tile)
+//   TB(g,m)  table m against the 4 pixels of register group g: 1 ds_read_b128 + 8 fma   (4 * MR per tile)
+//   FL(f)    flush a third of the fp32 tile sums into the float64 running sums           (3 per tile)
+// in an order that keeps SC of group g+1 ahead of TB of group g+1.  Slot 0 (no MFMA) takes LEAD_PCT % of the issue
+// cost — the time the next tile's mode/screen loads need to land — and the rest is dealt evenly behind the NM matrix
+// instructions of the NEXT tile's contraction.  sched_barrier(0) between slots pins the plan.
+template <int K>
+struct IC { static constexpr int v = K; };
+template <int... Is, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) { (f(IC<Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
 template <int A_PAD, int MRW, int MRS, int SINCOS>
-__global__ __launch_bounds__(256) void k_fused_mfma(const f32x4* __restrict__ modes_tile, const f32x4* __restrict__ tabs_tile,
-                                                    const f32x4* __restrict__ psi_tile, const float* __restrict__ act_tile,
+struct Plan {
+  static constexpr int MR = MRW + MRS, NS = 2 * MR;
+  static constexpr int NSTEP = A_PAD / 16;   // K=16 steps
+  static constexpr int NM = 3 * NSTEP;       // matrix instructions per tile
+  static constexpr int NSLOT = NM + 1;
+  static constexpr int LEAD_PCT = 40;
+  static constexpr int PREFETCH_CAP = 4;
+  static constexpr int U_SC = SINCOS == 0 ? 44 : (SINCOS == 1 ? 13 : 9);
+  static constexpr int U_TB = 9, N_FL = 3, U_FL = NS;
+  static constexpr int N_OPS = 16 + 4 * MR + N_FL;
+  struct Table {
+    int type[N_OPS], a[N_OPS], b[N_OPS];
+    int first[NSLOT + 1];  // ops [first[k], first[k+1]) run in slot k
+    int max_tb;            // most TB ops in any slot
+  };
+  static constexpr Table make() {
+    Table t{};
+    int o = 0;
+    for (int j = 0; j < 4; ++j) { t.type[o] = 0; t.a[o] = j; t.b[o] = 0; ++o; }
+    for (int g = 0; g < 4; ++g) {
+      int j = 0;
+      for (int m = 0; m < MR; ++m) {
+        t.type[o] = 1; t.a[o] = g; t.b[o] = m; ++o;
+        while (g < 3 && j < 4 && (m + 1) * 4 >= (j + 1) * MR) { t.type[o] = 0; t.a[o] = 4 * (g + 1) + j; t.b[o] = 0; ++o; ++j; }
+      }
+    }
+    for (int f = 0; f < N_FL; ++f) { t.type[o] = 2; t.a[o] = f; t.b[o] = 0; ++o; }
+    long long total = 0;
+    for (int i = 0; i < N_OPS; ++i) total += t.type[i] == 0 ? U_SC : (t.type[i] == 1 ? U_TB : U_FL);
+    const long long lead = total * LEAD_PCT / 100;
+    long long cum = 0;
+    int k = 0;
+    t.first[0] = 0;
+    for (int i = 0; i < N_OPS; ++i) {
+      int slot = cum < lead ? 0 : 1 + (int)((cum - lead) * NM / (total - lead));
+      if (slot > NSLOT - 1) slot = NSLOT - 1;
+      while (k < slot) { ++k; t.first[k] = i; }
+      cum += t.type[i] == 0 ? U_SC : (t.type[i] == 1 ? U_TB : U_FL);
+    }
+    while (k < NSLOT) { ++k; t.first[k] = N_OPS; }
+    t.max_tb = 1;  // rows are read one slot ahead only in slots with at most PREFETCH_CAP table ops
+    for (int q = 0; q < NSLOT; ++q) {
+      int c = 0;
+      for (int i = t.first[q]; i < t.first[q + 1]; ++i) c += t.type[i] == 1;
+      if (c <= PREFETCH_CAP && c > t.max_tb) t.max_tb = c;
+    }
+    return t;
+  }
+  static constexpr Table T = make();
+  // index (0-based) of TB op i among the TB ops of its own slot
+  static constexpr int tb_rank(int i, int k) {
+    int c = 0;
+    for (int q = T.first[k]; q < i; ++q) c += T.type[q] == 1;
+    return c;
+  }
+  static constexpr bool slot_prefetches(int k) {
+    int c = 0;
+    for (int q = T.first[k]; q < T.first[k + 1]; ++q) c += T.type[q] == 1;
+    return c <= PREFETCH_CAP;
+  }
+};
+
+// ABL (diagnostic builds only, never the product path): 1 = skip the matrix instructions, 2 = skip the vector work,
+// 3 = matrix instructions only with no global loads inside the loop, 4 = global loads only
+template <int A_PAD, int MRW, int MRS, int SINCOS, int ABL = 0>
+__global__ __launch_bounds__(256, (MRW <= 12 ? 2 : 1)) void k_fused_mfma(const f16x8* __restrict__ modes16, const f32x4* __restrict__ tabs_tile,
+                                                    const f32x4* __restrict__ psi_tile, const f16x8* __restrict__ act16,
                                                     double* __restrict__ partials, MfmaGeom geo, float ratio) {
-  using T = MfmaTile<A_PAD, MRW, MRS, SINCOS>;
-  constexpr int NS = T::NS;
-  constexpr int MR = T::MR;
-  constexpr int NKQ = T::NKQ;
+  using PL = Plan<A_PAD, MRW, MRS, SINCOS>;
+  constexpr int NS = PL::NS, MR = PL::MR, NSTEP = PL::NSTEP, NM = PL::NM, NSLOT = PL::NSLOT;
+  constexpr int MAXTB = PL::T.max_tb;
   extern __shared__ f32x4 lds_tabs[];  // [tile in chunk][g][h][MR]
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -367,78 +402,156 @@ __global__ __launch_bounds__(256) void k_fused_mfma(const f32x4* __restrict__ mo
   if (etile >= geo.n_etiles) return;
 
   const int h = lane >> 5;
-  float b[A_PAD / 2];
+  f16x8 bh[NSTEP], bl[NSTEP];   // actuators of this env tile, hi / lo halves (B operand)
   {
-    const float* asrc = act_tile + (size_t)etile * A_PAD * 32;
+    const f16x8* asrc = act16 + ((size_t)etile * NSTEP * 2) * 64 + lane;
 #pragma unroll
-    for (int kk = 0; kk < A_PAD / 2; ++kk) b[kk] = asrc[kk * 64 + lane];  // [2kk + h][lane&31]
+    for (int s = 0; s < NSTEP; ++s) {
+      bh[s] = asrc[(2 * s) * 64];
+      bl[s] = asrc[(2 * s + 1) * 64];
+    }
   }
   double acc[NS];
 #pragma unroll
   for (int i = 0; i < NS; ++i) acc[i] = 0.0;
+  float ts[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) ts[i] = 0.f;
 
-  // This wave's tiles: t0 + w_p + i*wp, i < n.  Software pipeline, all inside one wave:
-  //   stage i issues  (a) the screen tile of i+1 (consumed at the END of this stage, after the chain),
-  //                   (b) the mode tile of i+2 (consumed by the next stage's chain),
-  //   then runs the 32-MFMA chain of tile i+1 from a zero accumulator next to the sincos/accumulate VALU work of
-  //   tile i, and finally forms  d(i+1) = chain + screen.  Loads therefore have a full stage (~2k cycles) to land.
+  // This wave's tiles: t0 + w_p + i*wp, i < n.  Stage i (all inside one wave):
+  //   issue the loads of tile i+1 (screen + mode halves), run slot 0 of tile i's vector work while they land, then the
+  //   NM matrix instructions of tile i+1 with the rest of tile i's vector work dealt behind them, then
+  //   d(i+1) = screen + D1 + 2^-11 D2.
   const int first = t0 + w_p;
   const int n = first < t1 ? (t1 - first + wp - 1) / wp : 0;
   if (n > 0) {
     const size_t psi_base = (size_t)etile * geo.n_ptiles;
     const int last = first + (n - 1) * wp;
-    auto load_modes = [&](f32x4 (&m)[NKQ], int t) {
-      const f32x4* ms = modes_tile + ((size_t)min(t, last) * NKQ) * 64 + lane;
+    auto load_modes = [&](f16x8 (&mh)[NSTEP], f16x8 (&ml)[NSTEP], int t) {
+      const f16x8* ms = modes16 + ((size_t)min(t, last) * NSTEP * 2) * 64 + lane;
 #pragma unroll
-      for (int kq = 0; kq < NKQ; ++kq) m[kq] = ms[kq * 64];
+      for (int s = 0; s < NSTEP; ++s) {
+        mh[s] = ms[(2 * s) * 64];
+        ml[s] = ms[(2 * s + 1) * 64];
+      }
     };
-    auto chain = [&](const f32x4 (&m)[NKQ]) {
-      f32x16 d = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto load_psi = [&](int t) {
+      const f32x4* ps = psi_tile + ((psi_base + min(t, last)) * 4) * 64 + lane;
+      f32x16 d;
 #pragma unroll
-      for (int kq = 0; kq < NKQ; ++kq) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) d = __builtin_amdgcn_mfma_f32_32x32x2f32(m[kq][e], b[4 * kq + e], d, 0, 0, 0);
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 v = ps[g * 64];
+        d[4 * g + 0] = v[0]; d[4 * g + 1] = v[1]; d[4 * g + 2] = v[2]; d[4 * g + 3] = v[3];
       }
       return d;
     };
-    auto lds_row = [&](int t) { return lds_tabs + (size_t)(t - t0) * 8 * MR + h * MR; };
+    // matrix instruction q of a tile: s = q / 3; (Mh.ah -> D1), (Mh.al -> D2), (Ml.ah -> D2)
+    auto mfma_q = [&](auto qc, const f16x8 (&mh)[NSTEP], const f16x8 (&ml)[NSTEP], f32x16& d1, f32x16& d2) {
+      constexpr int q = decltype(qc)::v, s = q / 3, w = q % 3;
+      if constexpr (w == 0) d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[s], bh[s], d1, 0, 0, 0);
+      else if constexpr (w == 1) d2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[s], bl[s], d2, 0, 0, 0);
+      else d2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ml[s], bh[s], d2, 0, 0, 0);
+    };
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-    f32x4 mA[NKQ], mB[NKQ];
-    load_modes(mA, first);
-    load_modes(mB, first + wp);
-    f32x16 d = chain(mA) + T::load_psi(psi_tile, psi_base + first, lane);
-    // stage(i): d = phases of tile i, mcur = modes of tile i+1 (resident), mnext <- modes of tile i+2
-    auto stage = [&](int t, const f32x4 (&mcur)[NKQ], f32x4 (&mnext)[NKQ]) {
-      const f32x16 p = T::load_psi(psi_tile, psi_base + min(t + wp, last), lane);
-      f32x4 mtmp[NKQ];
-      load_modes(mtmp, t + 2 * wp);
-      f32x16 dn = chain(mcur);
-      T::reduce(d, lds_row(t), ratio, acc);
-      d = dn + p;
+    f32x16 d;                      // phases (revolutions at lambda_wfs) of the tile being reduced
+    float sw[2][4], cw[2][4], ss[2][4], cs[2][4];  // sincos of two register groups in flight
+    f32x4 gvb[2][MAXTB];           // table rows read one slot ahead
+
+    // one micro-op of the plan, on tile `d` with table rows at `lt`; k < 0: unplanned (rows read in place)
+    auto run_op = [&](auto oc, auto kc, const f32x4* lt) {
+      constexpr int o = decltype(oc)::v, k = decltype(kc)::v;
+      constexpr int type = PL::T.type[o], a = PL::T.a[o], bb = PL::T.b[o];
+      if constexpr (type == 0) {
+        constexpr int g = a >> 2, r = a & 3, par = g & 1;
+        const float u = d[a];
+        if constexpr (SINCOS == 2) {
+          sw[par][r] = __builtin_amdgcn_sinf(u);
+          cw[par][r] = __builtin_amdgcn_cosf(u);
+          const float us = u * ratio;
+          ss[par][r] = __builtin_amdgcn_sinf(us);
+          cs[par][r] = __builtin_amdgcn_cosf(us);
+        } else {
+          sincos_rev<SINCOS>(u, sw[par][r], cw[par][r]);
+          sincos_rev<SINCOS>(u * ratio, ss[par][r], cs[par][r]);
+        }
+      } else if constexpr (type == 1) {
+        constexpr int g = a, m = bb, par = g & 1;
+        f32x4 gv;
+        if constexpr (k >= 0 && PL::slot_prefetches(k >= 0 ? k : 0)) gv = gvb[k & 1][PL::tb_rank(o, k >= 0 ? k : 0)];
+        else gv = lt[(g * 2) * MR + m];
 #pragma unroll
-      for (int kq = 0; kq < NKQ; ++kq) mnext[kq] = mtmp[kq];
-      if constexpr (AOG_SCHED_PIPELINE) {
-        // ask the scheduler for: 1 MFMA, then its share of the vector work, for every link of the chain
-        constexpr int kValuPerMfma = (16 * (2 * MR + (SINCOS == 0 ? 60 : (SINCOS == 1 ? 9 : 5))) + 3 * NS + 16) / (4 * NKQ);
+        for (int r = 0; r < 4; ++r) {
+          const float cc = m < MRW ? cw[par][r] : cs[par][r];
+          const float sn = m < MRW ? sw[par][r] : ss[par][r];
+          ts[2 * m] = fmaf(cc, gv[r], ts[2 * m]);
+          ts[2 * m + 1] = fmaf(sn, gv[r], ts[2 * m + 1]);
+        }
+      } else {
+        constexpr int lo = a * NS / PL::N_FL, hi = (a + 1) * NS / PL::N_FL;
 #pragma unroll
-        for (int q = 0; q < 4 * NKQ; ++q) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             // MFMA
-          __builtin_amdgcn_sched_group_barrier(0x002, kValuPerMfma, 0);  // VALU (incl. transcendentals)
-          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);             // DS read
+        for (int i = lo; i < hi; ++i) {
+          acc[i] += (double)ts[i];
+          ts[i] = 0.f;
         }
       }
     };
-    int i = 0;
-    int t = first;
-    for (; i + 2 < n; i += 2, t += 2 * wp) {
-      stage(t, mB, mA);        // consumes modes of tile i+1 (mB), refills mA with tile i+2
-      stage(t + wp, mA, mB);   // consumes modes of tile i+2 (mA), refills mB with tile i+3
+    // table rows of slot k's TB ops -> gvb[k & 1]
+    auto fetch_rows = [&](auto kc, const f32x4* lt) {
+      constexpr int k = decltype(kc)::v;
+      if constexpr (PL::slot_prefetches(k)) {
+        static_for<PL::T.first[k + 1] - PL::T.first[k]>([&](auto qc) {
+          constexpr int o = PL::T.first[k] + decltype(qc)::v;
+          if constexpr (PL::T.type[o] == 1) gvb[k & 1][PL::tb_rank(o, k)] = lt[(PL::T.a[o] * 2) * MR + PL::T.b[o]];
+        });
+      }
+    };
+    auto run_slot = [&](auto kc, const f32x4* lt) {
+      constexpr int k = decltype(kc)::v;
+      static_for<PL::T.first[k + 1] - PL::T.first[k]>([&](auto qc) { run_op(IC<PL::T.first[k] + decltype(qc)::v>{}, kc, lt); });
+    };
+    auto reduce_plain = [&](const f32x4* lt) {
+      static_for<PL::N_OPS>([&](auto oc) { run_op(oc, IC<-1>{}, lt); });
+    };
+    auto lds_row = [&](int t) { return lds_tabs + (size_t)(t - t0) * 8 * MR + h * MR; };
+
+    f16x8 mh[NSTEP], ml[NSTEP];
+    {  // first tile: nothing to overlap with
+      load_modes(mh, ml, first);
+      f32x16 d1 = zero16, d2 = zero16;
+      static_for<NM>([&](auto qc) { mfma_q(qc, mh, ml, d1, d2); });
+      d = d1 * kD1Unscale + (load_psi(first) + d2 * kD2Unscale);
     }
-    if (i + 1 < n) {           // two tiles left: i (in d) and i+1 (modes in mB)
-      stage(t, mB, mA);
-      t += wp;
+    for (int i = 0, t = first; i + 1 < n; ++i, t += wp) {
+      f32x16 d1 = zero16, d2 = zero16, p;
+      if constexpr (ABL == 3) {
+        p = d;
+      } else {
+        p = load_psi(t + wp);             // consumed at the end of the stage
+        load_modes(mh, ml, t + wp);       // consumed from slot 1 on
+      }
+      const f32x4* lt = lds_row(t);
+      if constexpr (ABL == 0 || ABL == 1) {
+        fetch_rows(IC<0>{}, lt);
+        fetch_rows(IC<1>{}, lt);
+        run_slot(IC<0>{}, lt);
+      } else {
+        acc[0] += (double)d[0];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<NM>([&](auto qc) {
+        constexpr int q = decltype(qc)::v, k = q + 1;
+        if constexpr (ABL != 1 && ABL != 4) mfma_q(qc, mh, ml, d1, d2);
+        else asm volatile("" ::"v"(mh[q / 3]), "v"(ml[q / 3]));
+        if constexpr (ABL == 0 || ABL == 1) {
+          if constexpr (k + 1 < NSLOT) fetch_rows(IC<k + 1>{}, lt);
+          run_slot(IC<k>{}, lt);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      d = d1 * kD1Unscale + (p + d2 * kD2Unscale);
     }
-    T::reduce(d, lds_row(t), ratio, acc);
+    reduce_plain(lds_row(last));
   }
   // the two half waves hold different pixels of the same 32 envs: fold h=1 into h=0, then store
   const int chunk = c * wp + w_p;
@@ -456,6 +569,7 @@ __global__ __launch_bounds__(256) void k_fused_mfma(const f32x4* __restrict__ mo
 // ------------------------------------------------------------------------------------------------
 constexpr int kRefMaxSums = 2 * 80;
 
+#ifdef AOG_MAIN_TU
 __global__ __launch_bounds__(256) void k_fused_ref(const double* __restrict__ modes64, const double* __restrict__ tabs64,
                                                    const double* __restrict__ psi64, const double* __restrict__ act_dm,
                                                    double* __restrict__ partials, int n_ap, int A, int MRW, int MRS,
@@ -492,6 +606,7 @@ __global__ __launch_bounds__(256) void k_fused_ref(const double* __restrict__ mo
     if (threadIdx.x == 0) partials[(size_t)i * Bp + env] = v;
   }
 }
+#endif  // AOG_MAIN_TU
 
 // ------------------------------------------------------------------------------------------------
 // K9  epilogue: chunk partials -> complex amplitudes -> observation, fiber power, Strehl, reward, done.
@@ -537,6 +652,7 @@ __device__ inline double ssim_1d_delta_ref(const double* x, int stride, int n, d
 // block = 64 env lanes x (blockDim.x/64) waves; wave w reduces sums s = w, w+nw, ... over the chunk slabs
 // (coalesced 512-B rows, 4 independent accumulators), the sums meet in LDS, wave 0 finishes one env per lane.
 // dynamic LDS: (NS + n_obs) * 64 doubles.
+#ifdef AOG_MAIN_TU
 __global__ __launch_bounds__(1024) void k_epilogue(EpilogueArgs p) {
   extern __shared__ double sm[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -606,5 +722,20 @@ __global__ __launch_bounds__(1024) void k_epilogue(EpilogueArgs p) {
   if (p.power) p.power[env] = (float)power;
   if (p.strehl) p.strehl[env] = (float)strehl;
 }
+#endif  // AOG_MAIN_TU
+
+// self-test hook: the three sin/cos flavours of the fused kernels on caller-supplied revolutions
+#ifdef AOG_MAIN_TU
+__global__ void k_selftest_sincos(const float* __restrict__ u, float* __restrict__ s, float* __restrict__ c, int n, int flavour) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float sv, cv;
+  if (flavour == 0) sincos_rev<0>(u[i], sv, cv);
+  else if (flavour == 1) sincos_rev<1>(u[i], sv, cv);
+  else { sv = __builtin_amdgcn_sinf(u[i]); cv = __builtin_amdgcn_cosf(u[i]); }
+  s[i] = sv;
+  c[i] = cv;
+}
+#endif  // AOG_MAIN_TU
 
 }  // namespace aog

@@ -132,6 +132,10 @@ int aog_reset(aog_env* env, const uint8_t* mask_dev, float* obs_raw_dev, uint16_
 int aog_step(aog_env* env, const float* action_dev, float* obs_raw_dev, uint16_t* obs_dev, float* reward_dev,
              uint8_t* done_dev, float* power_dev, float* strehl_dev, void* stream);
 
+/* Self-test hook: sin(2 pi u), cos(2 pi u) for n float32 revolutions u_dev with the fused kernels' device code.
+ * flavour 0 = polynomial, 1 = v_sin_f32/v_cos_f32 after the exact reduction, 2 = v_sin_f32/v_cos_f32 on raw input. */
+int aog_selftest_sincos(const float* u_dev, float* sin_dev, float* cos_dev, int n, int flavour, void* stream);
+
 /* Microseconds-resolution timing of the dominant (fused) kernel of the most recent aog_step/aog_reset calls,
  * measured with HIP events on the stream the kernel was launched on.  Enable, run steps, then read the
  * mean duration (ms) and the number of launches averaged. */
