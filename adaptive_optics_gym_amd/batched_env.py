@@ -80,6 +80,7 @@ class BatchedAOEnv:
         self.screen_oversampling = int(screen_oversampling)
         self._rng = rng
         self._episode_returns = None
+        self._trunc = None
 
         if atm_type == "dynamic":
             raise NotImplementedError("dynamic atmosphere (hcipy InfiniteAtmosphericLayer extrusion) is not built yet")
@@ -232,19 +233,23 @@ class BatchedAOEnv:
         a = a.reshape(self.num_envs, self.num_modes).contiguous()
         n = self.obs_dim ** 2
         B = self.num_envs
+        # three allocations per step: fp32 block (obs_raw | reward | power | strehl), fp16 obs, uint8 done
+        f32 = torch.empty((B * (n + 3),), dtype=torch.float32, device=self.device)
+        obs_raw = f32[: B * n].view(B, n)
+        reward = f32[B * n: B * (n + 1)]
+        power = f32[B * (n + 1): B * (n + 2)]
+        strehl = f32[B * (n + 2):]
         obs = torch.empty((B, n), dtype=torch.float16, device=self.device)
-        obs_raw = torch.empty((B, n), dtype=torch.float32, device=self.device)
-        reward = torch.empty((B,), dtype=torch.float32, device=self.device)
         done = torch.empty((B,), dtype=torch.uint8, device=self.device)
-        power = torch.empty((B,), dtype=torch.float32, device=self.device)
-        strehl = torch.empty((B,), dtype=torch.float32, device=self.device)
-        _lib.check(self.lib.aog_step(self._handle, C.c_void_p(a.data_ptr()), C.c_void_p(obs_raw.data_ptr()),
-                                     C.c_void_p(obs.data_ptr()), C.c_void_p(reward.data_ptr()), C.c_void_p(done.data_ptr()),
-                                     C.c_void_p(power.data_ptr()), C.c_void_p(strehl.data_ptr()), self._stream()))
+        base = f32.data_ptr()
+        _lib.check(self.lib.aog_step(self._handle, C.c_void_p(a.data_ptr()), C.c_void_p(base), C.c_void_p(obs.data_ptr()),
+                                     C.c_void_p(base + 4 * B * n), C.c_void_p(done.data_ptr()),
+                                     C.c_void_p(base + 4 * B * (n + 1)), C.c_void_p(base + 4 * B * (n + 2)), self._stream()))
         self.timestep += 1
         self.last_obs_raw = obs_raw
-        trunc = torch.zeros((B,), dtype=torch.bool, device=self.device)
-        return obs, reward, done.to(torch.bool), trunc, {"power": power, "obs_raw": obs_raw, "strehl": strehl}
+        if self._trunc is None:
+            self._trunc = torch.zeros((B,), dtype=torch.bool, device=self.device)
+        return obs, reward, done.view(torch.bool), self._trunc, {"power": power, "obs_raw": obs_raw, "strehl": strehl}
 
     # ------------------------------------------------------------------------------------------------
     def get_actuators(self):

@@ -131,11 +131,8 @@ int launch_epilogue(aog_env* e, bool is_step, float* obs_raw, uint16_t* obs, flo
   p.ssim_peak = e->cfg.ssim_ref_peak;
   p.ssim_alpha = e->cfg.ssim_alpha;
   const int NS = 2 * (p.MRW + p.MRS);
-  const int nw = std::max(1, std::min(16, NS));
-  const size_t lds = (size_t)(NS + p.n_obs) * 64 * sizeof(double);
-  if (lds > 64 * 1024)
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(aog::k_epilogue), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(aog::k_epilogue, dim3((e->B + 63) / 64), dim3(64 * nw), lds, s, p);
+  const size_t lds = (size_t)(NS + p.n_obs) * aog::kEpiEnvs * sizeof(double);
+  hipLaunchKernelGGL(aog::k_epilogue, dim3((e->Bp + aog::kEpiEnvs - 1) / aog::kEpiEnvs), dim3(256), lds, s, p);
   HIP_TRY(hipGetLastError());
   return AOG_OK;
 }
@@ -200,10 +197,9 @@ int aog_create(const aog_config* cfg, int device, aog_env** out) {
   e->MRS_used = cfg->n_sci_tables;
   e->n_obs = cfg->obs_dim * cfg->obs_dim;
   e->n_out = e->n_obs + cfg->n_fiber_modes;
-  e->sincos_hw = 0;
   // sin/cos flavour of the fast kernels: "hwraw" (default; v_sin_f32/v_cos_f32 on the revolutions, the instruction
   // reduces them itself), "hw" (same instructions after an explicit exact reduction), "poly" (degree-7/8 polynomial)
-  e->sincos_hw = 1;
+  e->sincos_hw = 2;
   if (const char* ab = getenv("AOG_ABLATE")) e->ablate = atoi(ab);
   if (const char* sc = getenv("AOG_SINCOS")) e->sincos_hw = strcmp(sc, "poly") == 0 ? 0 : (strcmp(sc, "hwraw") == 0 ? 2 : 1);
 

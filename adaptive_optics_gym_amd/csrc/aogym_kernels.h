@@ -649,14 +649,15 @@ __device__ inline double ssim_1d_delta_ref(const double* x, int stride, int n, d
   return sum / cnt;
 }
 
-// block = 64 env lanes x (blockDim.x/64) waves; wave w reduces sums s = w, w+nw, ... over the chunk slabs
-// (coalesced 512-B rows, 4 independent accumulators), the sums meet in LDS, wave 0 finishes one env per lane.
-// dynamic LDS: (NS + n_obs) * 64 doubles.
+// block = 16 envs x 16 sum slots (256 threads, grid = ceil(Bp/16)): thread (e, q) reduces sums s = q, q+16, ... over the
+// chunk slabs (4 independent accumulators, 128-B coalesced rows), the sums meet in LDS, then the 16 threads with q == 0
+// finish one env each.  dynamic LDS: (NS + n_obs) * 16 doubles.
+constexpr int kEpiEnvs = 16;
 #ifdef AOG_MAIN_TU
-__global__ __launch_bounds__(1024) void k_epilogue(EpilogueArgs p) {
+__global__ __launch_bounds__(256) void k_epilogue(EpilogueArgs p) {
   extern __shared__ double sm[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  const int env = blockIdx.x * 64 + lane;  // < Bp: padded envs read defined (ignored) slabs
+  const int lane = threadIdx.x & (kEpiEnvs - 1), wave = threadIdx.x / kEpiEnvs, nw = blockDim.x / kEpiEnvs;
+  const int env = blockIdx.x * kEpiEnvs + lane;  // < Bp: padded envs read defined (ignored) slabs
   const int MR = p.MRW + p.MRS;
   const int NS = 2 * MR;
   const size_t cstride = (size_t)NS * p.Bp;
@@ -671,25 +672,25 @@ __global__ __launch_bounds__(1024) void k_epilogue(EpilogueArgs p) {
       a3 += src[(size_t)(c + 3) * cstride];
     }
     for (; c < p.n_chunks; ++c) a0 += src[(size_t)c * cstride];
-    sm[s * 64 + lane] = (a0 + a1) + (a2 + a3);
+    sm[s * kEpiEnvs + lane] = (a0 + a1) + (a2 + a3);
   }
   __syncthreads();
   if (wave != 0 || env >= p.B) return;
-  const double* U = sm + lane;             // U_m = U[(2m) * 64], V_m = U[(2m + 1) * 64]
-  double* obsv = sm + (size_t)NS * 64 + lane;  // obsv[j * 64]
+  const double* U = sm + lane;             // U_m = U[(2m) * kEpiEnvs], V_m = U[(2m + 1) * kEpiEnvs]
+  double* obsv = sm + (size_t)NS * kEpiEnvs + lane;  // obsv[j * kEpiEnvs]
   double power = 0;
   const int n_out = p.n_obs + p.n_fiber;
   for (int j = 0; j < n_out; ++j) {
     double zr = 0, zi = 0;
     const double* cf = p.wfs_coef + (size_t)j * p.MRW_used * 2;
     for (int m = 0; m < p.MRW_used; ++m) {
-      const double u = U[(2 * m) * 64], v = U[(2 * m + 1) * 64];
+      const double u = U[(2 * m) * kEpiEnvs], v = U[(2 * m + 1) * kEpiEnvs];
       zr += cf[2 * m] * u - cf[2 * m + 1] * v;
       zi += cf[2 * m] * v + cf[2 * m + 1] * u;
     }
     const double pw = zr * zr + zi * zi;
     if (j < p.n_obs) {
-      obsv[(size_t)j * 64] = pw;
+      obsv[(size_t)j * kEpiEnvs] = pw;
       if (p.obs_raw) p.obs_raw[(size_t)env * p.n_obs + j] = (float)pw;
       if (p.obs) {
         const _Float16 hv = (_Float16)pw;  // round-to-nearest-even from float64, like np.array(x, float16)
@@ -702,7 +703,7 @@ __global__ __launch_bounds__(1024) void k_epilogue(EpilogueArgs p) {
   if (!p.is_step) return;
   double zr = 0, zi = 0;
   for (int m = 0; m < p.MRS_used; ++m) {
-    const double u = U[(2 * (p.MRW + m)) * 64], v = U[(2 * (p.MRW + m) + 1) * 64];
+    const double u = U[(2 * (p.MRW + m)) * kEpiEnvs], v = U[(2 * (p.MRW + m) + 1) * kEpiEnvs];
     zr += p.sci_coef[2 * m] * u - p.sci_coef[2 * m + 1] * v;
     zi += p.sci_coef[2 * m] * v + p.sci_coef[2 * m + 1] * u;
   }
@@ -711,7 +712,7 @@ __global__ __launch_bounds__(1024) void k_epilogue(EpilogueArgs p) {
   if (p.reward_type == 0) {
     reward = -(100.0 - strehl * 100.0);
   } else {
-    const double ssim = ssim_1d_delta_ref(obsv, 64, p.n_obs, p.ssim_peak, p.n_obs / 2);
+    const double ssim = ssim_1d_delta_ref(obsv, kEpiEnvs, p.n_obs, p.ssim_peak, p.n_obs / 2);
     reward = p.ssim_alpha * power + (1.0 - p.ssim_alpha) * ssim;
   }
   if (p.has_thr && reward < p.thr) reward = -1.0;

@@ -205,13 +205,18 @@ def main():
                        "batch_per_gpu": B, "global_batch": world * B, "n_pupil": w["n_pupil"], "act_dim": w["act_dim"],
                        "obs_dim": w["obs_dim"], "kernel": {1: "valu", 2: "mfma"}.get(env.info.kernel, "ref"),
                        "parallelism": f"envs sharded over {world} GPU(s), no data-path collective"},
-            "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach_tf / FP32_PEAK_TFLOPS, "traffic": traffic, "kernel": "k_fused_mfma",
-                         "kernel_ms": kernel_ms, "launches_timed": launches, "flops_per_env_step": flops_step,
-                         "note": "fp32 MFMA (v_mfma_f32_32x32x2_f32) + fp32 VALU share the 157.3 TFLOP/s peak; this is the "
-                                 "binding roof of the fused kernel (HBM view in roofline_hbm)"},
-            "roofline_hbm": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "bytes_per_env_step": bytes_step},
+            "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_fused_mfma",
+                         "kernel_ms": kernel_ms, "launches_timed": launches, "bytes_per_env_step": bytes_step,
+                         "note": "algorithmic bytes (SURVEY.md 8d: 282,913 B per env-step) x 1024 envs per launch / mean "
+                                 "HIP-event duration of the fused kernel; traffic = PMC (2*FETCH_SIZE + WRITE_SIZE) KiB per "
+                                 "launch from profiles/traffic_latest.json; 6.29 TB/s is the measured copy ceiling"},
+            "roofline_fp32": {"bound": "valu", "achieved": ach_tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": ach_tf / FP32_PEAK_TFLOPS, "flops_per_env_step": flops_step,
+                              "note": "SURVEY.md 8d algorithmic flops priced at the fp32 vector/MFMA peak; the surface "
+                                      "contraction (2*A*n_ap of them) actually runs as 3 f16 MFMAs per 16 modes, so this "
+                                      "fraction overstates fp32 pipe use — the kernel is bound by its sincos/accumulate "
+                                      "vector work, then by HBM"},
         }
         if not args.no_parity:
             result["parity"] = strehl_check(env, screens, torch)

@@ -27,7 +27,7 @@ if args.stats:
                   "| kernel | calls | avg ns | min ns | max ns | % of GPU time |", "|---|---|---|---|---|---|"]
         for r in rows:
             n = r["Name"]
-            if "aog::" in n or float(r["Percentage"]) > 3:
+            if "aog::" in n or "3aog" in n or float(r["Percentage"]) > 3:
                 lines.append(f"| `{n[:90]}` | {r['Calls']} | {float(r['AverageNs']):.0f} | {r['MinNs']} | {r['MaxNs']} | {float(r['Percentage']):.2f} |")
         lines.append("")
 traffic = None
@@ -38,7 +38,7 @@ if args.pmc:
             agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     lines += ["## PMC (separate `--pmc` passes with `--kernel-trace` only; mean per dispatch)", ""]
     for k, v in agg.items():
-        if "aog::" not in k:
+        if "aog::" not in k and "3aog" not in k:
             continue
         lines.append(f"### `{k[:100]}`")
         lines.append("")
