@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libaogym.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 AOG_REWARD = {"strehl_ratio": 0, "smf_ssim": 1}
 AOG_PRECISION = {"fast": 0, "fp64": 1}
@@ -21,13 +21,21 @@ class AogConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "abi_version", "num_envs", "n_pupil", "n_modes", "obs_dim", "n_ap", "n_wfs_tables", "n_sci_tables",
         "n_fiber_modes", "reward_type", "sh_operation", "max_steps", "flat_mirror_start", "has_rew_threshold",
-        "precision", "kernel", "pixel_chunks", "reserved0")] + [(n, C.c_double) for n in (
+        "precision", "kernel", "pixel_chunks", "atm_dynamic")] + [(n, C.c_double) for n in (
         "wavelength_wfs", "wavelength_sci", "surface_rms_target", "rew_threshold", "ssim_ref_peak", "ssim_alpha")]
 
 
 class AogTables(C.Structure):
     _fields_ = [("ap_index", C.POINTER(C.c_int32))] + [(n, C.POINTER(C.c_double)) for n in (
         "modes", "gram", "wfs_tables", "sci_tables", "wfs_coef", "sci_coef")]
+
+
+class AogLayerTables(C.Structure):
+    _fields_ = [("nz_vertical", C.c_int32), ("nz_horizontal", C.c_int32),
+                ("stencil_vertical", C.POINTER(C.c_int32)), ("stencil_horizontal", C.POINTER(C.c_int32)),
+                ("A_vertical", C.POINTER(C.c_double)), ("B_vertical", C.POINTER(C.c_double)),
+                ("A_horizontal", C.POINTER(C.c_double)), ("B_horizontal", C.POINTER(C.c_double)),
+                ("sqrt_cn_squared", C.c_double), ("pixel_pitch", C.c_double), ("delta_t", C.c_double)]
 
 
 class AogInfo(C.Structure):
@@ -46,6 +54,11 @@ SYMBOLS = {
     "aog_upload_tables": (C.c_int, [C.c_void_p, C.POINTER(AogTables)]),
     "aog_set_screens_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "aog_set_screens_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "aog_upload_layer": (C.c_int, [C.c_void_p, C.POINTER(AogLayerTables)]),
+    "aog_set_wind": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "aog_set_extrusion_noise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "aog_set_rng_seed": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "aog_get_screens_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "aog_get_actuators": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "aog_set_actuators": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "aog_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -12,7 +12,8 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .atmosphere_host import cn_squared_from_fried_parameter, screen_numpy, screens_torch
+from .atmosphere_host import (build_layer_tables, cn_squared_from_fried_parameter, integer_shifts, screen_numpy,
+                              screens_torch)
 from .optics_host import HostTables, build_tables
 from .params import OpticalParams, coerce_velocity
 from .spaces import make_box
@@ -82,14 +83,13 @@ class BatchedAOEnv:
         self._episode_returns = None
         self._trunc = None
 
-        if atm_type == "dynamic":
-            raise NotImplementedError("dynamic atmosphere (hcipy InfiniteAtmosphericLayer extrusion) is not built yet")
         if self.SH_operation:
             raise NotImplementedError("Shack-Hartmann operation (AO_env.py:254-290, 396-465) is not built yet")
 
         self.observation_space = make_box(-1, 1, (self.obs_dim ** 2,), np.float16)  # AO_env.py:45
         self.action_space = make_box(-1, 1, (self.num_modes,), np.float16)          # AO_env.py:46
 
+        self.Cn_squared = cn_squared_from_fried_parameter(self.fried_parameter, self.params.wavelength_sci)
         self.tables: HostTables = build_tables(self.params, act_type, self.num_modes, self.obs_dim)
         t = self.tables
         cfg = _lib.AogConfig()
@@ -110,6 +110,7 @@ class BatchedAOEnv:
         cfg.precision = _lib.AOG_PRECISION[precision]
         cfg.kernel = _lib.AOG_KERNEL[kernel]
         cfg.pixel_chunks = int(pixel_chunks)
+        cfg.atm_dynamic = int(atm_type == "dynamic")
         cfg.wavelength_wfs = self.params.wavelength_wfs
         cfg.wavelength_sci = self.params.wavelength_sci
         cfg.surface_rms_target = self.params.action_rms_fraction * self.params.wavelength_sci
@@ -137,15 +138,30 @@ class BatchedAOEnv:
         _lib.check(self.lib.aog_get_info(self._handle, C.byref(self.info)))
 
         # atmosphere (AO_env.py:361-370)
-        self.Cn_squared = cn_squared_from_fried_parameter(self.fried_parameter, self.params.wavelength_sci)
-        if self._rng is not None or screen_source == "numpy":
-            # hcipy draws the wind direction and the two extrusion stencils before the screen;
-            # consume them so the legacy numpy stream stays aligned with the reference's
+        # hcipy's construction order: wind direction (rand), the two stencil draws (geometric x2), then
+        # the screen normals.  Host-RNG mode consumes the numpy stream in that order; env 0's draws define the stencils /
+        # AR matrices shared by the whole batch (for B = 1 this is exactly the reference's layer).
+        self._host_rng = self._rng is not None or screen_source == "numpy"
+        N = self.num_pupil_pixels
+        theta = np.zeros(self.num_envs)
+        layer = None
+        if self._host_rng:
             for e in range(self.num_envs):
                 r = self._env_rng(e)
-                r.rand()
-                r.geometric(0.5, self.num_pupil_pixels)
-                r.geometric(0.5, self.num_pupil_pixels)
+                theta[e] = r.rand() * 2 * np.pi
+                if e == 0 and self.atm_type == "dynamic":
+                    layer = build_layer_tables(N, self.params.pupil_pixel, self.params.outer_scale, r)
+                else:
+                    r.geometric(0.5, N)
+                    r.geometric(0.5, N)
+        else:
+            trng = np.random.RandomState(1234 if seed is None else int(seed))
+            theta = trng.rand(self.num_envs) * 2 * np.pi
+            if self.atm_type == "dynamic":
+                layer = build_layer_tables(N, self.params.pupil_pixel, self.params.outer_scale, trng)
+        self.velocity_vectors = float(self.velocity) * np.stack([np.cos(theta), np.sin(theta)], axis=1)  # [B, 2] m/s
+        if self.atm_type == "dynamic":
+            self._upload_layer(layer)
         if screens is not None:
             self.set_screens(screens)
         else:
@@ -187,6 +203,48 @@ class BatchedAOEnv:
             else:
                 for e in np.flatnonzero(np.asarray(mask.cpu() if hasattr(mask, "cpu") else mask)):
                     self.set_screens(psi[e:e + 1], first=int(e))
+
+    def _upload_layer(self, layer):
+        torch = self._torch
+        self._layer = layer  # keep the host arrays alive during the call
+        lt = _lib.AogLayerTables(
+            int(layer["stencil_vertical"].size), int(layer["stencil_horizontal"].size),
+            _dptr(layer["stencil_vertical"], C.c_int32), _dptr(layer["stencil_horizontal"], C.c_int32),
+            _dptr(layer["A_vertical"], C.c_double), _dptr(layer["B_vertical"], C.c_double),
+            _dptr(layer["A_horizontal"], C.c_double), _dptr(layer["B_horizontal"], C.c_double),
+            float(np.sqrt(self.Cn_squared)), float(self.params.pupil_pixel), float(self.params.delta_t))
+        _lib.check(self.lib.aog_upload_layer(self._handle, C.byref(lt)))
+        v = torch.from_numpy(np.ascontiguousarray(self.velocity_vectors)).to(self.device)
+        _lib.check(self.lib.aog_set_wind(self._handle, C.c_void_p(v.data_ptr()), self._stream()))
+        _lib.check(self.lib.aog_set_rng_seed(self._handle, C.c_uint64(1234 if self.seed is None else int(self.seed))))
+        torch.cuda.current_stream(self.device).synchronize()
+
+    def _host_extrusion_noise(self):
+        """Host-RNG (parity) mode: draw the normals of the coming step's extrusions from each env's numpy stream in hcipy's
+        order (all x shifts, then all y shifts; ``normal(0, 1, N)`` per extrusion) and hand them to the library."""
+        torch = self._torch
+        N = self.num_pupil_pixels
+        t_prev, t_new = self.timestep * self.delta_t, (self.timestep + 1) * self.delta_t
+        shifts = integer_shifts(self.velocity_vectors, t_prev, t_new, self.params.pupil_pixel)  # [B, 2]
+        counts = np.abs(shifts).sum(axis=1)
+        max_ext = int(counts.max()) if counts.size else 0
+        if max_ext == 0:
+            return
+        noise = np.zeros((self.num_envs, max_ext, N))
+        for e in range(self.num_envs):
+            r = self._env_rng(e)
+            for k in range(int(counts[e])):
+                noise[e, k] = r.normal(0, 1, size=N)
+        self._noise_dev = torch.from_numpy(noise).to(self.device)  # kept alive until the step has run
+        _lib.check(self.lib.aog_set_extrusion_noise(self._handle, C.c_void_p(self._noise_dev.data_ptr()), max_ext, self._stream()))
+
+    def get_screens(self):
+        """Dynamic atmosphere: every env's current achromatic screen, [B, N, N] float64."""
+        torch = self._torch
+        N = self.num_pupil_pixels
+        out = torch.empty((self.num_envs, N, N), dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.aog_get_screens_f64(self._handle, C.c_void_p(out.data_ptr()), self._stream()))
+        return out
 
     def set_screens(self, screens, first=0):
         """Install achromatic screens (hcipy's ``layer._achromatic_screen``: phase * lambda) for envs
@@ -231,6 +289,8 @@ class BatchedAOEnv:
         if a.dtype != torch.float32:
             a = a.to(torch.float32)
         a = a.reshape(self.num_envs, self.num_modes).contiguous()
+        if self.atm_type == "dynamic" and self._host_rng:
+            self._host_extrusion_noise()
         n = self.obs_dim ** 2
         B = self.num_envs
         # three allocations per step: fp32 block (obs_raw | reward | power | strehl), fp16 obs, uint8 done

@@ -131,10 +131,56 @@ int launch_epilogue(aog_env* e, bool is_step, float* obs_raw, uint16_t* obs, flo
   p.ssim_peak = e->cfg.ssim_ref_peak;
   p.ssim_alpha = e->cfg.ssim_alpha;
   const int NS = 2 * (p.MRW + p.MRS);
-  const size_t lds = (size_t)(NS + p.n_obs) * aog::kEpiEnvs * sizeof(double);
-  hipLaunchKernelGGL(aog::k_epilogue, dim3((e->Bp + aog::kEpiEnvs - 1) / aog::kEpiEnvs), dim3(256), lds, s, p);
+  const size_t lds = (size_t)(aog::kEpiQuarters * NS + p.n_obs) * aog::kEpiEnvs * sizeof(double);
+  hipLaunchKernelGGL(aog::k_epilogue, dim3((e->Bp + aog::kEpiEnvs - 1) / aog::kEpiEnvs), dim3(1024), lds, s, p);
   HIP_TRY(hipGetLastError());
   return AOG_OK;
+}
+
+// float64 ring-buffer master screens of envs [first, first+count) -> the fused kernels' fp32 layouts
+int pack_from_master(aog_env* e, int first, int count, hipStream_t s) {
+  const double inv = 1.0 / (2.0 * M_PI * e->cfg.wavelength_wfs);
+  const int N2 = e->cfg.n_pupil * e->cfg.n_pupil;
+  // the MFMA kernel only reads psi_tile, the VALU kernel only psi_rev: write the one that is used
+  float* rev = e->kernel == AOG_KERNEL_VALU ? e->psi_rev : nullptr;
+  float* tile = e->kernel == AOG_KERNEL_MFMA ? e->psi_tile : nullptr;
+  hipLaunchKernelGGL((aog::k_pack_screens<double>), dim3(count), dim3(256), 0, s, e->psi_master + (size_t)first * N2, e->ap_index,
+                     rev, tile, e->psi64, first, N2, e->n_ap, e->n_ap_pad, e->Bp, inv, (const int32_t*)e->origin,
+                     e->cfg.n_pupil);
+  HIP_TRY(hipGetLastError());
+  return AOG_OK;
+}
+
+// layer.t = timestep * delta_t (AO_env.py:125): wind extrusion of every env, then refresh the fp32 layouts
+int evolve_layer(aog_env* e, hipStream_t s) {
+  if (!e->layer_ready) return fail(AOG_ERR_STATE, "dynamic atmosphere: aog_upload_layer / aog_set_wind not called");
+  aog::ExtrudeArgs p{};
+  p.master = e->psi_master;
+  p.origin = e->origin;
+  p.ext_counter = e->ext_counter;
+  p.velocity = e->velocity;
+  p.stencil_v = e->stencil_v;
+  p.stencil_h = e->stencil_h;
+  p.At_v = e->At_v;
+  p.Bt_v = e->Bt_v;
+  p.At_h = e->At_h;
+  p.Bt_h = e->Bt_h;
+  p.noise = e->next_noise;
+  p.max_ext = e->next_noise_max_ext;
+  p.N = e->cfg.n_pupil;
+  p.nz_v = e->nz_v;
+  p.nz_h = e->nz_h;
+  p.t_prev = (double)(e->timestep - 1) * e->delta_t;
+  p.t_new = (double)e->timestep * e->delta_t;
+  p.pitch = e->pitch;
+  p.sqrt_cn2 = e->sqrt_cn2;
+  p.seed = e->rng_seed;
+  const size_t lds = (size_t)(std::max(e->nz_v, e->nz_h) + e->cfg.n_pupil) * sizeof(double);
+  hipLaunchKernelGGL(aog::k_extrude, dim3(e->B), dim3(256), lds, s, p);
+  HIP_TRY(hipGetLastError());
+  e->next_noise = nullptr;
+  e->next_noise_max_ext = 0;
+  return pack_from_master(e, 0, e->B, s);
 }
 
 template <typename T>
@@ -146,9 +192,19 @@ int set_screens(aog_env* e, const T* psi, int first, int count, hipStream_t s) {
   if (count == 0) return AOG_OK;
   HIP_TRY(hipSetDevice(e->device));
   const double inv = 1.0 / (2.0 * M_PI * e->cfg.wavelength_wfs);
-  hipLaunchKernelGGL((aog::k_pack_screens<T>), dim3(count), dim3(256), 0, s, psi, e->ap_index, e->psi_rev, e->psi_tile,
-                     e->psi64, first, e->cfg.n_pupil * e->cfg.n_pupil, e->n_ap, e->n_ap_pad, e->Bp, inv);
-  HIP_TRY(hipGetLastError());
+  const int N2 = e->cfg.n_pupil * e->cfg.n_pupil;
+  if (e->cfg.atm_dynamic) {
+    const size_t n = (size_t)count * N2;
+    hipLaunchKernelGGL((aog::k_store_master<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, psi, e->psi_master, e->origin,
+                       e->ext_counter, first, count, N2);
+    HIP_TRY(hipGetLastError());
+    int rc = pack_from_master(e, first, count, s);
+    if (rc != AOG_OK) return rc;
+  } else {
+    hipLaunchKernelGGL((aog::k_pack_screens<T>), dim3(count), dim3(256), 0, s, psi, e->ap_index, e->psi_rev, e->psi_tile,
+                       e->psi64, first, N2, e->n_ap, e->n_ap_pad, e->Bp, inv, (const int32_t*)nullptr, e->cfg.n_pupil);
+    HIP_TRY(hipGetLastError());
+  }
   e->screens_ready = true;
   return AOG_OK;
 }
@@ -254,6 +310,13 @@ int aog_create(const aog_config* cfg, int device, aog_env** out) {
   TRY_ALLOC(dev_alloc(e, &e->act16, (size_t)e->n_etiles * e->A_pad * 32 * 2));
   TRY_ALLOC(dev_alloc(e, &e->t_render, e->B));
   TRY_ALLOC(dev_alloc(e, &e->partials, e->partial_elems));
+  if (cfg->atm_dynamic) {
+    const size_t N2 = (size_t)cfg->n_pupil * cfg->n_pupil;
+    TRY_ALLOC(dev_alloc(e, &e->psi_master, (size_t)e->B * N2));
+    TRY_ALLOC(dev_alloc(e, &e->origin, (size_t)e->B * 2));
+    TRY_ALLOC(dev_alloc(e, &e->ext_counter, (size_t)e->B));
+    TRY_ALLOC(dev_alloc(e, &e->velocity, (size_t)e->B * 2));
+  }
   if (cfg->precision == AOG_PRECISION_FAST) {
     const int TROW = round_up(e->MRW + e->MRS, 4);
     TRY_ALLOC(dev_alloc(e, &e->modes_f32, (size_t)e->n_ap_pad * e->A_pad));
@@ -370,6 +433,81 @@ int aog_set_screens_f32(aog_env* e, const float* psi, int first, int count, void
   return set_screens<float>(e, psi, first, count, static_cast<hipStream_t>(stream));
 }
 
+int aog_upload_layer(aog_env* e, const aog_layer_tables* t) {
+  if (!e || !t) return fail(AOG_ERR_INVALID, "aog_upload_layer: null argument");
+  if (!e->cfg.atm_dynamic) return fail(AOG_ERR_STATE, "aog_upload_layer: handle was not created with atm_dynamic = 1");
+  if (!t->stencil_vertical || !t->stencil_horizontal || !t->A_vertical || !t->B_vertical || !t->A_horizontal || !t->B_horizontal)
+    return fail(AOG_ERR_INVALID, "aog_upload_layer: null table pointer");
+  const int N = e->cfg.n_pupil;
+  if (t->nz_vertical < 1 || t->nz_horizontal < 1 || t->nz_vertical > 4 * N || t->nz_horizontal > 4 * N || !(t->pixel_pitch > 0) ||
+      !(t->delta_t > 0))
+    return fail(AOG_ERR_INVALID, "aog_upload_layer: bad sizes");
+  for (int k = 0; k < t->nz_vertical; ++k)
+    if (t->stencil_vertical[k] < 0 || t->stencil_vertical[k] >= N * N) return fail(AOG_ERR_INVALID, "aog_upload_layer: stencil index out of range");
+  for (int k = 0; k < t->nz_horizontal; ++k)
+    if (t->stencil_horizontal[k] < 0 || t->stencil_horizontal[k] >= N * N) return fail(AOG_ERR_INVALID, "aog_upload_layer: stencil index out of range");
+  HIP_TRY(hipSetDevice(e->device));
+  e->nz_v = t->nz_vertical;
+  e->nz_h = t->nz_horizontal;
+  e->sqrt_cn2 = t->sqrt_cn_squared;
+  e->pitch = t->pixel_pitch;
+  e->delta_t = t->delta_t;
+  int rc;
+  auto upload_t = [&](const double* src, int rows, int cols, double** dst) -> int {  // src [rows][cols] -> dst [cols][rows]
+    std::vector<double> tr((size_t)rows * cols);
+    for (int r = 0; r < rows; ++r)
+      for (int c = 0; c < cols; ++c) tr[(size_t)c * rows + r] = src[(size_t)r * cols + c];
+    if (!*dst && (rc = dev_alloc(e, dst, tr.size(), false)) != AOG_OK) return rc;
+    HIP_TRY(hipMemcpy(*dst, tr.data(), sizeof(double) * tr.size(), hipMemcpyHostToDevice));
+    return AOG_OK;
+  };
+  if (e->layer_ready) return fail(AOG_ERR_STATE, "aog_upload_layer: already uploaded");
+  if ((rc = upload_t(t->A_vertical, N, e->nz_v, &e->At_v)) != AOG_OK) return rc;
+  if ((rc = upload_t(t->B_vertical, N, N, &e->Bt_v)) != AOG_OK) return rc;
+  if ((rc = upload_t(t->A_horizontal, N, e->nz_h, &e->At_h)) != AOG_OK) return rc;
+  if ((rc = upload_t(t->B_horizontal, N, N, &e->Bt_h)) != AOG_OK) return rc;
+  if ((rc = dev_alloc(e, &e->stencil_v, e->nz_v, false)) != AOG_OK) return rc;
+  if ((rc = dev_alloc(e, &e->stencil_h, e->nz_h, false)) != AOG_OK) return rc;
+  HIP_TRY(hipMemcpy(e->stencil_v, t->stencil_vertical, sizeof(int32_t) * e->nz_v, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->stencil_h, t->stencil_horizontal, sizeof(int32_t) * e->nz_h, hipMemcpyHostToDevice));
+  e->layer_ready = true;
+  return AOG_OK;
+}
+
+int aog_set_wind(aog_env* e, const double* velocity_dev, void* stream) {
+  if (!e || !velocity_dev) return fail(AOG_ERR_INVALID, "aog_set_wind: null argument");
+  if (!e->cfg.atm_dynamic) return fail(AOG_ERR_STATE, "aog_set_wind: handle was not created with atm_dynamic = 1");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipMemcpyAsync(e->velocity, velocity_dev, sizeof(double) * 2 * e->B, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+  return AOG_OK;
+}
+
+int aog_set_extrusion_noise(aog_env* e, const double* noise_dev, int max_ext, void* stream) {
+  (void)stream;
+  if (!e || max_ext < 0) return fail(AOG_ERR_INVALID, "aog_set_extrusion_noise: bad argument");
+  if (!e->cfg.atm_dynamic) return fail(AOG_ERR_STATE, "aog_set_extrusion_noise: handle was not created with atm_dynamic = 1");
+  e->next_noise = noise_dev;
+  e->next_noise_max_ext = noise_dev ? max_ext : 0;
+  return AOG_OK;
+}
+
+int aog_set_rng_seed(aog_env* e, uint64_t seed) {
+  if (!e) return fail(AOG_ERR_INVALID, "aog_set_rng_seed: null handle");
+  e->rng_seed = seed;
+  return AOG_OK;
+}
+
+int aog_get_screens_f64(aog_env* e, double* psi_dev, void* stream) {
+  if (!e || !psi_dev) return fail(AOG_ERR_INVALID, "aog_get_screens_f64: null argument");
+  if (!e->cfg.atm_dynamic) return fail(AOG_ERR_STATE, "aog_get_screens_f64: only dynamic handles keep float64 master screens");
+  HIP_TRY(hipSetDevice(e->device));
+  const size_t n = (size_t)e->B * e->cfg.n_pupil * e->cfg.n_pupil;
+  hipLaunchKernelGGL(aog::k_unroll_master, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     e->psi_master, e->origin, psi_dev, e->B, e->cfg.n_pupil);
+  HIP_TRY(hipGetLastError());
+  return AOG_OK;
+}
+
 int aog_get_actuators(aog_env* e, double* act_dev, void* stream) {
   if (!e || !act_dev) return fail(AOG_ERR_INVALID, "aog_get_actuators: null argument");
   HIP_TRY(hipSetDevice(e->device));
@@ -417,6 +555,11 @@ int aog_step(aog_env* e, const float* action, float* obs_raw, uint16_t* obs, flo
     return fail(AOG_ERR_INVALID, "win_size exceeds image extent (smf_ssim needs obs_dim**2 >= 7; AO_env.py:495)");
   HIP_TRY(hipSetDevice(e->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
+  e->timestep += 1;  // AO_env.py:123
+  if (e->cfg.atm_dynamic) {
+    int rce = evolve_layer(e, s);
+    if (rce != AOG_OK) return rce;
+  }
   hipLaunchKernelGGL(aog::k_prologue, dim3(e->B), dim3(64), 0, s, action, e->gram, e->act_dm, e->act_rev, e->act16, e->A,
                      e->A_pad, e->Bp, e->cfg.sh_operation, e->cfg.surface_rms_target, 2.0 / e->cfg.wavelength_wfs);
   HIP_TRY(hipGetLastError());

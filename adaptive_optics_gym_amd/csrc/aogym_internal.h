@@ -44,6 +44,24 @@ struct aog_env {
   float* act_rev = nullptr;      // [A_pad][Bp]
   _Float16* act16 = nullptr;     // [Bp/32][A_pad/16][hi|lo][64][8]
   int32_t* t_render = nullptr;   // [B]
+  // dynamic atmosphere (cfg.atm_dynamic)
+  bool layer_ready = false;
+  long long timestep = 0;        // AOEnv.timestep: monotone over episodes (AO_env.py:123)
+  double* psi_master = nullptr;  // [B][N*N] float64 toroidal screens
+  int32_t* origin = nullptr;     // [B][2]
+  uint32_t* ext_counter = nullptr;  // [B]
+  double* velocity = nullptr;    // [B][2]
+  int32_t* stencil_v = nullptr;
+  int32_t* stencil_h = nullptr;
+  double* At_v = nullptr;        // [nz_v][N]
+  double* Bt_v = nullptr;        // [N][N]
+  double* At_h = nullptr;
+  double* Bt_h = nullptr;
+  int nz_v = 0, nz_h = 0;
+  double sqrt_cn2 = 0, pitch = 0, delta_t = 0;
+  const double* next_noise = nullptr;
+  int next_noise_max_ext = 0;
+  unsigned long long rng_seed = 1234;
   double* partials = nullptr;
   size_t partial_elems = 0;
   // profiling of the fused kernel

@@ -73,21 +73,37 @@ __device__ __host__ __forceinline__ size_t psi_tile_index(int env, int p, int n_
   return ((((size_t)et * n_ptiles + pt) * 4 + g) * 64 + (h * 32 + e)) * 4 + r;
 }
 
+// `origin` (nullable, [env][2] = (ox, oy)): the source screens are toroidal ring buffers (dynamic atmosphere) whose
+// logical pixel (iy, ix) lives at physical ((iy + oy) mod N, (ix + ox) mod N).
 template <typename T>
 __global__ __launch_bounds__(256) void k_pack_screens(const T* __restrict__ psi, const int32_t* __restrict__ ap_index,
                                                       float* __restrict__ psi_rev, float* __restrict__ psi_tile,
                                                       double* __restrict__ psi64, int first, int n_pix2, int n_ap,
-                                                      int n_ap_pad, int Bp, double inv_two_pi_lambda) {
+                                                      int n_ap_pad, int Bp, double inv_two_pi_lambda,
+                                                      const int32_t* __restrict__ origin, int N) {
   __shared__ double sm[8];
   const int e = blockIdx.x;
   const int env = first + e;
   const T* src = psi + (size_t)e * n_pix2;
+  int ox = 0, oy = 0;
+  if (origin) {
+    ox = origin[2 * env];
+    oy = origin[2 * env + 1];
+  }
+  auto phys = [&](int flat) {
+    if (!origin) return flat;
+    const int iy = flat / N, ix = flat - iy * N;
+    int py = iy + oy, px = ix + ox;
+    if (py >= N) py -= N;
+    if (px >= N) px -= N;
+    return py * N + px;
+  };
   double acc = 0;
-  for (int p = threadIdx.x; p < n_ap; p += blockDim.x) acc += (double)src[ap_index[p]];
+  for (int p = threadIdx.x; p < n_ap; p += blockDim.x) acc += (double)src[phys(ap_index[p])];
   const double mean = block_reduce_sum(acc, sm) / (double)n_ap;
   const int n_ptiles = n_ap_pad >> 5;
   for (int p = threadIdx.x; p < n_ap_pad; p += blockDim.x) {
-    const double v = (p < n_ap) ? ((double)src[ap_index[p]] - mean) : 0.0;
+    const double v = (p < n_ap) ? ((double)src[phys(ap_index[p])] - mean) : 0.0;
     const float vr = (float)(v * inv_two_pi_lambda);
     if (psi_rev) psi_rev[((size_t)(p >> 2) * Bp + env) * 4 + (p & 3)] = vr;
     if (psi_tile) psi_tile[psi_tile_index(env, p, n_ptiles)] = vr;
@@ -649,33 +665,48 @@ __device__ inline double ssim_1d_delta_ref(const double* x, int stride, int n, d
   return sum / cnt;
 }
 
-// block = 16 envs x 16 sum slots (256 threads, grid = ceil(Bp/16)): thread (e, q) reduces sums s = q, q+16, ... over the
-// chunk slabs (4 independent accumulators, 128-B coalesced rows), the sums meet in LDS, then the 16 threads with q == 0
-// finish one env each.  dynamic LDS: (NS + n_obs) * 16 doubles.
+// block = 16 envs x 16 sum slots x 4 chunk quarters (1024 threads, grid = ceil(Bp/16)): thread (e, q, cq) reduces sums
+// s = q, q+16, ... over chunks cq, cq+4, ... (8 independent loads in flight, 128-B coalesced rows); the quarters and the
+// sums meet in LDS, then the 16 threads with q == cq == 0 finish one env each.
+// dynamic LDS: (4 * NS + n_obs) * 16 doubles.
 constexpr int kEpiEnvs = 16;
+constexpr int kEpiQuarters = 4;
 #ifdef AOG_MAIN_TU
-__global__ __launch_bounds__(256) void k_epilogue(EpilogueArgs p) {
+__global__ __launch_bounds__(1024) void k_epilogue(EpilogueArgs p) {
   extern __shared__ double sm[];
-  const int lane = threadIdx.x & (kEpiEnvs - 1), wave = threadIdx.x / kEpiEnvs, nw = blockDim.x / kEpiEnvs;
+  const int lane = threadIdx.x & (kEpiEnvs - 1);
+  const int wave = (threadIdx.x / kEpiEnvs) & 15;       // sum slot q
+  const int cq = threadIdx.x / (kEpiEnvs * 16);         // chunk quarter
+  const int nw = 16;
   const int env = blockIdx.x * kEpiEnvs + lane;  // < Bp: padded envs read defined (ignored) slabs
   const int MR = p.MRW + p.MRS;
   const int NS = 2 * MR;
   const size_t cstride = (size_t)NS * p.Bp;
+  double* part = sm + (size_t)(NS + p.n_obs) * kEpiEnvs;  // [quarter 1..3][NS][16]
   for (int s = wave; s < NS; s += nw) {
     const double* src = p.partials + (size_t)s * p.Bp + env;
-    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    int c = 0;
-    for (; c + 4 <= p.n_chunks; c += 4) {
-      a0 += src[(size_t)c * cstride];
-      a1 += src[(size_t)(c + 1) * cstride];
-      a2 += src[(size_t)(c + 2) * cstride];
-      a3 += src[(size_t)(c + 3) * cstride];
+    double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int c = cq;
+    for (; c + 28 < p.n_chunks; c += 32) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += src[(size_t)(c + 4 * u) * cstride];
     }
-    for (; c < p.n_chunks; ++c) a0 += src[(size_t)c * cstride];
-    sm[s * kEpiEnvs + lane] = (a0 + a1) + (a2 + a3);
+    for (; c < p.n_chunks; c += 4) a[0] += src[(size_t)c * cstride];
+    const double v = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    if (cq == 0) sm[s * kEpiEnvs + lane] = v;
+    else part[((size_t)(cq - 1) * NS + s) * kEpiEnvs + lane] = v;
   }
   __syncthreads();
-  if (wave != 0 || env >= p.B) return;
+  if (cq == 0) {
+    for (int s = wave; s < NS; s += nw) {
+      double v = sm[s * kEpiEnvs + lane];
+#pragma unroll
+      for (int k = 0; k < kEpiQuarters - 1; ++k) v += part[((size_t)k * NS + s) * kEpiEnvs + lane];
+      sm[s * kEpiEnvs + lane] = v;
+    }
+  }
+  __syncthreads();
+  if (wave != 0 || cq != 0 || env >= p.B) return;
   const double* U = sm + lane;             // U_m = U[(2m) * kEpiEnvs], V_m = U[(2m + 1) * kEpiEnvs]
   double* obsv = sm + (size_t)NS * kEpiEnvs + lane;  // obsv[j * kEpiEnvs]
   double power = 0;
@@ -722,6 +753,155 @@ __global__ __launch_bounds__(256) void k_epilogue(EpilogueArgs p) {
   if (p.done) p.done[env] = (tr == p.max_steps) ? 1 : 0;
   if (p.power) p.power[env] = (float)power;
   if (p.strehl) p.strehl[env] = (float)strehl;
+}
+#endif  // AOG_MAIN_TU
+
+// ------------------------------------------------------------------------------------------------
+// K7  dynamic atmosphere: hcipy InfiniteAtmosphericLayer.evolve_until / _extrude (AO_env.py:125).
+// One workgroup per env.  The float64 master screen is a toroidal ring buffer, so an extrusion writes N values
+// instead of moving N^2:  'left'/'bottom' decrement the origin and fill logical column/row 0; 'right'/'top' (hcipy
+// works on the 180-degree rotated screen) increment it and fill logical column/row N-1 in reversed order.
+//   new = A z + sqrt(Cn^2) B n,   z = screen[stencil] (flat-index order, on the rotated screen when flipped),
+//   n = N standard normals: caller-supplied (parity mode: numpy's stream) or Philox4x32-10 + Box-Muller.
+// Matrices are stored transposed (At [nz][N], Bt [N][N]) so the N threads of a row read contiguous memory.
+// ------------------------------------------------------------------------------------------------
+struct ExtrudeArgs {
+  double* master;            // [B][N*N]
+  int32_t* origin;           // [B][2] (ox, oy)
+  uint32_t* ext_counter;     // [B] extrusions done so far (RNG stream position)
+  const double* velocity;    // [B][2] m/s
+  const int32_t* stencil_v;  // [nz_v] flat logical indices
+  const int32_t* stencil_h;  // [nz_h]
+  const double* At_v;        // [nz_v][N]
+  const double* Bt_v;        // [N][N]
+  const double* At_h;
+  const double* Bt_h;
+  const double* noise;       // nullable: [B][max_ext][N]
+  int N, nz_v, nz_h, max_ext;
+  double t_prev, t_new, pitch, sqrt_cn2;
+  unsigned long long seed;
+};
+
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0];
+  const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+  const uint32_t n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+  const uint32_t n3 = (uint32_t)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+// standard normal number `idx` of stream (seed, env, extrusion)
+__device__ inline double philox_normal(unsigned long long seed, uint32_t env, uint32_t ext, uint32_t idx) {
+  uint32_t c[4] = {idx >> 1, ext, env, 0u};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  // two 52-bit-ish uniforms in (0,1] / [0,1) from the four words, Box-Muller, pick by parity of idx
+  const double u1 = ((double)c[0] * 4294967296.0 + (double)c[1] + 1.0) * (1.0 / 18446744073709551616.0);
+  const double u2 = ((double)c[2] * 4294967296.0 + (double)c[3]) * (1.0 / 18446744073709551616.0);
+  const double r = sqrt(-2.0 * log(u1));
+  double sn, cs;
+  sincospi(2.0 * u2, &sn, &cs);
+  return (idx & 1) ? r * sn : r * cs;
+}
+
+#ifdef AOG_MAIN_TU
+__global__ __launch_bounds__(256) void k_extrude(ExtrudeArgs p) {
+  extern __shared__ double lds[];  // z [max(nz_v, nz_h)] | noise [N]
+  const int env = blockIdx.x;
+  const int N = p.N;
+  double* z = lds;
+  double* nz_buf = lds + max(p.nz_v, p.nz_h);
+  double* master = p.master + (size_t)env * N * N;
+  int ox = p.origin[2 * env], oy = p.origin[2 * env + 1];
+  const double vx = p.velocity[2 * env], vy = p.velocity[2 * env + 1];
+  // np.round(center / delta).astype(int) before and after (round-half-even = rint)
+  const int dx = (int)rint(vx * p.t_new / p.pitch) - (int)rint(vx * p.t_prev / p.pitch);
+  const int dy = (int)rint(vy * p.t_new / p.pitch) - (int)rint(vy * p.t_prev / p.pitch);
+  const int n_ext = abs(dx) + abs(dy);
+  const uint32_t ext0 = p.ext_counter[env];
+  for (int e = 0; e < n_ext; ++e) {
+    const bool horizontal = e < abs(dx);
+    const bool flipped = horizontal ? dx > 0 : dy > 0;
+    const int nz = horizontal ? p.nz_h : p.nz_v;
+    const int32_t* st = horizontal ? p.stencil_h : p.stencil_v;
+    const double* At = horizontal ? p.At_h : p.At_v;
+    const double* Bt = horizontal ? p.Bt_h : p.Bt_v;
+    for (int k = threadIdx.x; k < nz; k += blockDim.x) {
+      int sy = st[k] / N, sx = st[k] - sy * N;
+      if (flipped) { sy = N - 1 - sy; sx = N - 1 - sx; }
+      int py = sy + oy, px = sx + ox;
+      if (py >= N) py -= N;
+      if (px >= N) px -= N;
+      z[k] = master[(size_t)py * N + px];
+    }
+    for (int j = threadIdx.x; j < N; j += blockDim.x) {
+      nz_buf[j] = (p.noise && e < p.max_ext) ? p.noise[((size_t)env * p.max_ext + e) * N + j]
+                                             : philox_normal(p.seed, (uint32_t)env, ext0 + (uint32_t)e, (uint32_t)j);
+    }
+    __syncthreads();
+    // origin after this extrusion
+    int nox = ox, noy = oy;
+    if (horizontal) nox = flipped ? (ox + 1 == N ? 0 : ox + 1) : (ox == 0 ? N - 1 : ox - 1);
+    else noy = flipped ? (oy + 1 == N ? 0 : oy + 1) : (oy == 0 ? N - 1 : oy - 1);
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+      double a = 0, b = 0;
+      for (int k = 0; k < nz; ++k) a = fma(At[(size_t)k * N + i], z[k], a);
+      for (int j = 0; j < N; ++j) b = fma(Bt[(size_t)j * N + i], nz_buf[j], b);
+      const double v = a + b * p.sqrt_cn2;
+      // logical position of new_slice[i]
+      int ly, lx;
+      if (horizontal) { ly = flipped ? N - 1 - i : i; lx = flipped ? N - 1 : 0; }
+      else { ly = flipped ? N - 1 : 0; lx = flipped ? N - 1 - i : i; }
+      int py = ly + noy, px = lx + nox;
+      if (py >= N) py -= N;
+      if (px >= N) px -= N;
+      master[(size_t)py * N + px] = v;
+    }
+    ox = nox;
+    oy = noy;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    p.origin[2 * env] = ox;
+    p.origin[2 * env + 1] = oy;
+    p.ext_counter[env] = ext0 + (uint32_t)n_ext;
+  }
+}
+
+// caller screens -> float64 master (origin 0)
+template <typename T>
+__global__ void k_store_master(const T* __restrict__ psi, double* __restrict__ master, int32_t* __restrict__ origin,
+                               uint32_t* __restrict__ ext_counter, int first, int count, int n_pix2) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)count * n_pix2) return;
+  const int e = (int)(idx / n_pix2);
+  master[(size_t)(first + e) * n_pix2 + (idx - (size_t)e * n_pix2)] = (double)psi[idx];
+  if (idx - (size_t)e * n_pix2 == 0) {
+    origin[2 * (first + e)] = 0;
+    origin[2 * (first + e) + 1] = 0;
+    ext_counter[first + e] = 0;
+  }
+}
+
+// ring buffer -> plain [B][N][N] (tests, checkpointing)
+__global__ void k_unroll_master(const double* __restrict__ master, const int32_t* __restrict__ origin, double* __restrict__ out,
+                                int B, int N) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)B * N * N) return;
+  const int env = (int)(idx / ((size_t)N * N));
+  const int flat = (int)(idx - (size_t)env * N * N);
+  const int iy = flat / N, ix = flat - iy * N;
+  int py = iy + origin[2 * env + 1], px = ix + origin[2 * env];
+  if (py >= N) py -= N;
+  if (px >= N) px -= N;
+  out[idx] = master[(size_t)env * N * N + (size_t)py * N + px];
 }
 #endif  // AOG_MAIN_TU
 

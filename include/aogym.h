@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define AOG_ABI_VERSION 3
+#define AOG_ABI_VERSION 4
 
 typedef struct aog_env aog_env;
 
@@ -60,7 +60,7 @@ typedef struct {
   int32_t precision;            /* AOG_PRECISION_*                                               */
   int32_t kernel;               /* AOG_KERNEL_* (fast precision only)                            */
   int32_t pixel_chunks;         /* 0 = auto; number of pixel chunks the fused kernel splits into */
-  int32_t reserved0;
+  int32_t atm_dynamic;          /* 1: atm_type == 'dynamic' (float64 master screens + wind extrusion each step) */
   double wavelength_wfs;        /* 1.5e-6 (AO_env.py:219)                                        */
   double wavelength_sci;        /* 2.2e-6 (AO_env.py:220)                                        */
   double surface_rms_target;    /* 0.1*wavelength_sci (AO_env.py:120)                            */
@@ -113,6 +113,33 @@ int aog_upload_tables(aog_env* env, const aog_tables* tables);
  * removed (all outputs are invariant to a global phase) before conversion to the internal fp32 layout. */
 int aog_set_screens_f64(aog_env* env, const double* psi_dev, int first, int count, void* stream);
 int aog_set_screens_f32(aog_env* env, const float* psi_dev, int first, int count, void* stream);
+
+/* hcipy InfiniteAtmosphericLayer construction products (AO_env.py:370; hcipy _make_stencils / _make_AB_matrices):
+ * stencil positions and the auto-regressive extrusion matrices, shared by every env of the handle.  HOST pointers. */
+typedef struct {
+  int32_t nz_vertical, nz_horizontal;   /* stencil sizes (3N unless samples coincide)                        */
+  const int32_t* stencil_vertical;      /* [nz_v] flat logical index iy*N+ix, increasing ('bottom' stencil)  */
+  const int32_t* stencil_horizontal;    /* [nz_h] ('left' stencil)                                           */
+  const double* A_vertical;             /* [N][nz_v]  new row    = A z + sqrt(Cn^2) B n                      */
+  const double* B_vertical;             /* [N][N]                                                            */
+  const double* A_horizontal;           /* [N][nz_h]  new column                                             */
+  const double* B_horizontal;           /* [N][N]                                                            */
+  double sqrt_cn_squared;               /* sqrt of AO_env.py:367                                             */
+  double pixel_pitch;                   /* pupil_grid.delta (m)                                              */
+  double delta_t;                       /* 1e-3 s (AO_env.py:226)                                            */
+} aog_layer_tables;
+int aog_upload_layer(aog_env* env, const aog_layer_tables* layer);
+
+/* layer.velocity of every env: [B][2] float64 (vx, vy) in m/s (hcipy draws the direction at construction). */
+int aog_set_wind(aog_env* env, const double* velocity_dev, void* stream);
+
+/* Standard normals for the extrusions of the NEXT aog_step: [B][max_ext][N] float64, consumed in hcipy's order (x shifts
+ * first, then y).  NULL (default) = on-device Philox4x32-10 stream seeded by aog_set_rng_seed. */
+int aog_set_extrusion_noise(aog_env* env, const double* noise_dev, int max_ext, void* stream);
+int aog_set_rng_seed(aog_env* env, uint64_t seed);
+
+/* layer._achromatic_screen of every env as plain [B][N][N] float64 (dynamic atmosphere only). */
+int aog_get_screens_f64(aog_env* env, double* psi_dev, void* stream);
 
 /* deformable_mirror.actuators for all envs (metres; AO_env.py:116).  [B][A] float64 device pointers. */
 int aog_get_actuators(aog_env* env, double* act_dev, void* stream);

@@ -147,3 +147,21 @@ def test_shard_range_partitions_exactly():
     assert sharding.shard_range(8192, 3, 8) == (3072, 4096)
     with pytest.raises(ValueError):
         sharding.shard_range(8, 8, 8)
+
+
+def test_layer_tables_match_oracle_layer():
+    """Stencils and AR matrices of the product's host builder == the oracle's InfiniteAtmosphericLayer (same seed)."""
+    n, D, L0 = 14, 0.5, 10.0
+    lay = atmosphere_host.build_layer_tables(n, D / n, L0, np.random.RandomState(21))
+    rng = np.random.RandomState(21)
+    ref = H.InfiniteAtmosphericLayer(H.make_pupil_grid(n, D), 1e-12, L0, np.array([1.0, 0.0]), rng=rng, initial_screen=np.zeros(n * n))
+    assert np.array_equal(lay["stencil_vertical"], np.flatnonzero(ref.stencil_bottom))
+    assert np.array_equal(lay["stencil_horizontal"], np.flatnonzero(ref.stencil_left))
+    np.testing.assert_allclose(lay["A_vertical"], ref.A_vertical, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(lay["A_horizontal"], ref.A_horizontal, rtol=1e-7, atol=1e-9)
+    # B is defined up to the sign of each singular vector: compare B B^T
+    np.testing.assert_allclose(lay["B_vertical"] @ lay["B_vertical"].T, ref.B_vertical @ ref.B_vertical.T, rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(lay["B_vertical"], ref.B_vertical, rtol=1e-6, atol=1e-9)
+    v = np.array([[3.0, -4.0], [0.2, 0.0]])
+    s = atmosphere_host.integer_shifts(v, 0.004, 0.005, D / n)
+    assert s.tolist() == [[(round(3 * 0.005 / (D / n)) - round(3 * 0.004 / (D / n))), (round(-4 * 0.005 / (D / n)) - round(-4 * 0.004 / (D / n)))], [0, 0]]
