@@ -138,15 +138,24 @@ int launch_epilogue(aog_env* e, bool is_step, float* obs_raw, uint16_t* obs, flo
 }
 
 // float64 ring-buffer master screens of envs [first, first+count) -> the fused kernels' fp32 layouts
-int pack_from_master(aog_env* e, int first, int count, hipStream_t s) {
+int pack_from_master(aog_env* e, int first, int count, hipStream_t s, bool per_step = false) {
   const double inv = 1.0 / (2.0 * M_PI * e->cfg.wavelength_wfs);
   const int N2 = e->cfg.n_pupil * e->cfg.n_pupil;
+  if (per_step && e->kernel == AOG_KERNEL_MFMA && e->cfg.precision == AOG_PRECISION_FAST && first == 0 && count == e->B) {
+    // fast path: offsets = means measured by the previous repack, whole-row writes
+    hipLaunchKernelGGL(aog::k_refresh_offsets, dim3((e->B + 255) / 256), dim3(256), 0, s, e->psi_offset, e->psi_sum, e->B, e->n_ap);
+    dim3 grid((e->n_ptiles + 1) / 2, e->n_etiles);
+    hipLaunchKernelGGL(aog::k_repack_master, grid, dim3(256), 0, s, e->psi_master, e->origin, e->ap_index, e->psi_offset, e->psi_sum,
+                       e->psi_tile, e->B, e->cfg.n_pupil, e->n_ap, e->n_ptiles, inv);
+    HIP_TRY(hipGetLastError());
+    return AOG_OK;
+  }
   // the MFMA kernel only reads psi_tile, the VALU kernel only psi_rev: write the one that is used
   float* rev = e->kernel == AOG_KERNEL_VALU ? e->psi_rev : nullptr;
   float* tile = e->kernel == AOG_KERNEL_MFMA ? e->psi_tile : nullptr;
   hipLaunchKernelGGL((aog::k_pack_screens<double>), dim3(count), dim3(256), 0, s, e->psi_master + (size_t)first * N2, e->ap_index,
                      rev, tile, e->psi64, first, N2, e->n_ap, e->n_ap_pad, e->Bp, inv, (const int32_t*)e->origin,
-                     e->cfg.n_pupil);
+                     e->cfg.n_pupil, e->psi_offset, e->psi_sum);
   HIP_TRY(hipGetLastError());
   return AOG_OK;
 }
@@ -175,12 +184,16 @@ int evolve_layer(aog_env* e, hipStream_t s) {
   p.pitch = e->pitch;
   p.sqrt_cn2 = e->sqrt_cn2;
   p.seed = e->rng_seed;
-  const size_t lds = (size_t)(std::max(e->nz_v, e->nz_h) + e->cfg.n_pupil) * sizeof(double);
-  hipLaunchKernelGGL(aog::k_extrude, dim3(e->B), dim3(256), lds, s, p);
+  const size_t lds = (size_t)aog::kExtG * (std::max(e->nz_v, e->nz_h) + 2 * e->cfg.n_pupil) * sizeof(double);
+  if (lds > 64 * 1024 && !e->extrude_attr_set) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(aog::k_extrude), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    e->extrude_attr_set = true;
+  }
+  hipLaunchKernelGGL(aog::k_extrude, dim3((e->B + aog::kExtG - 1) / aog::kExtG), dim3(aog::kExtThreads), lds, s, p, e->B);
   HIP_TRY(hipGetLastError());
   e->next_noise = nullptr;
   e->next_noise_max_ext = 0;
-  return pack_from_master(e, 0, e->B, s);
+  return pack_from_master(e, 0, e->B, s, true);
 }
 
 template <typename T>
@@ -316,6 +329,8 @@ int aog_create(const aog_config* cfg, int device, aog_env** out) {
     TRY_ALLOC(dev_alloc(e, &e->origin, (size_t)e->B * 2));
     TRY_ALLOC(dev_alloc(e, &e->ext_counter, (size_t)e->B));
     TRY_ALLOC(dev_alloc(e, &e->velocity, (size_t)e->B * 2));
+    TRY_ALLOC(dev_alloc(e, &e->psi_offset, (size_t)e->B));
+    TRY_ALLOC(dev_alloc(e, &e->psi_sum, (size_t)e->B));
   }
   if (cfg->precision == AOG_PRECISION_FAST) {
     const int TROW = round_up(e->MRW + e->MRS, 4);

@@ -46,11 +46,14 @@ struct aog_env {
   int32_t* t_render = nullptr;   // [B]
   // dynamic atmosphere (cfg.atm_dynamic)
   bool layer_ready = false;
+  bool extrude_attr_set = false;
   long long timestep = 0;        // AOEnv.timestep: monotone over episodes (AO_env.py:123)
   double* psi_master = nullptr;  // [B][N*N] float64 toroidal screens
   int32_t* origin = nullptr;     // [B][2]
   uint32_t* ext_counter = nullptr;  // [B]
   double* velocity = nullptr;    // [B][2]
+  double* psi_offset = nullptr;  // [B] piston offset used by the per-step repack
+  double* psi_sum = nullptr;     // [B] aperture sums accumulated by the last repack
   int32_t* stencil_v = nullptr;
   int32_t* stencil_h = nullptr;
   double* At_v = nullptr;        // [nz_v][N]

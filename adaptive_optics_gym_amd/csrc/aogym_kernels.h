@@ -80,7 +80,9 @@ __global__ __launch_bounds__(256) void k_pack_screens(const T* __restrict__ psi,
                                                       float* __restrict__ psi_rev, float* __restrict__ psi_tile,
                                                       double* __restrict__ psi64, int first, int n_pix2, int n_ap,
                                                       int n_ap_pad, int Bp, double inv_two_pi_lambda,
-                                                      const int32_t* __restrict__ origin, int N) {
+                                                      const int32_t* __restrict__ origin, int N,
+                                                      double* __restrict__ offset_out = nullptr,
+                                                      double* __restrict__ sum_out = nullptr) {
   __shared__ double sm[8];
   const int e = blockIdx.x;
   const int env = first + e;
@@ -100,7 +102,12 @@ __global__ __launch_bounds__(256) void k_pack_screens(const T* __restrict__ psi,
   };
   double acc = 0;
   for (int p = threadIdx.x; p < n_ap; p += blockDim.x) acc += (double)src[phys(ap_index[p])];
-  const double mean = block_reduce_sum(acc, sm) / (double)n_ap;
+  const double total = block_reduce_sum(acc, sm);
+  const double mean = total / (double)n_ap;
+  if (threadIdx.x == 0) {
+    if (offset_out) offset_out[env] = mean;
+    if (sum_out) sum_out[env] = total;  // as if a repack had just measured this screen
+  }
   const int n_ptiles = n_ap_pad >> 5;
   for (int p = threadIdx.x; p < n_ap_pad; p += blockDim.x) {
     const double v = (p < n_ap) ? ((double)src[phys(ap_index[p])] - mean) : 0.0;
@@ -812,66 +819,144 @@ __device__ inline double philox_normal(unsigned long long seed, uint32_t env, ui
 }
 
 #ifdef AOG_MAIN_TU
-__global__ __launch_bounds__(256) void k_extrude(ExtrudeArgs p) {
-  extern __shared__ double lds[];  // z [max(nz_v, nz_h)] | noise [N]
-  const int env = blockIdx.x;
+// One workgroup advances kExtG consecutive envs together.  The envs are independent, but they share the AR matrices, and
+// those (2 MB per direction at N = 256) are what the kernel streams: in every round each matrix row is loaded ONCE per
+// workgroup and used for all envs of the group that extrude in that direction (x shifts come first for every env, so the
+// rounds of a group line up as horizontal ... horizontal, vertical ... vertical).
+constexpr int kExtG = 4;
+constexpr int kExtThreads = 512;  // N rows x 2 halves of the contraction index (more loads in flight per row)
+__global__ __launch_bounds__(512) void k_extrude(ExtrudeArgs p, int B) {
+  extern __shared__ double lds[];  // z [G][nzmax] | noise [G][N] | partial [G][N]
   const int N = p.N;
-  double* z = lds;
-  double* nz_buf = lds + max(p.nz_v, p.nz_h);
-  double* master = p.master + (size_t)env * N * N;
-  int ox = p.origin[2 * env], oy = p.origin[2 * env + 1];
-  const double vx = p.velocity[2 * env], vy = p.velocity[2 * env + 1];
-  // np.round(center / delta).astype(int) before and after (round-half-even = rint)
-  const int dx = (int)rint(vx * p.t_new / p.pitch) - (int)rint(vx * p.t_prev / p.pitch);
-  const int dy = (int)rint(vy * p.t_new / p.pitch) - (int)rint(vy * p.t_prev / p.pitch);
-  const int n_ext = abs(dx) + abs(dy);
-  const uint32_t ext0 = p.ext_counter[env];
-  for (int e = 0; e < n_ext; ++e) {
-    const bool horizontal = e < abs(dx);
-    const bool flipped = horizontal ? dx > 0 : dy > 0;
-    const int nz = horizontal ? p.nz_h : p.nz_v;
-    const int32_t* st = horizontal ? p.stencil_h : p.stencil_v;
-    const double* At = horizontal ? p.At_h : p.At_v;
-    const double* Bt = horizontal ? p.Bt_h : p.Bt_v;
-    for (int k = threadIdx.x; k < nz; k += blockDim.x) {
-      int sy = st[k] / N, sx = st[k] - sy * N;
-      if (flipped) { sy = N - 1 - sy; sx = N - 1 - sx; }
-      int py = sy + oy, px = sx + ox;
-      if (py >= N) py -= N;
-      if (px >= N) px -= N;
-      z[k] = master[(size_t)py * N + px];
+  const int nzmax = max(p.nz_v, p.nz_h);
+  double* zb = lds;
+  double* nb = lds + (size_t)kExtG * nzmax;
+  double* pb = nb + (size_t)kExtG * N;
+  __shared__ int s_ox[kExtG], s_oy[kExtG], s_dx[kExtG], s_dy[kExtG];
+  const int env0 = blockIdx.x * kExtG;
+  if (threadIdx.x < kExtG) {
+    const int env = env0 + threadIdx.x;
+    int dx = 0, dy = 0, ox = 0, oy = 0;
+    if (env < B) {
+      const double vx = p.velocity[2 * env], vy = p.velocity[2 * env + 1];
+      // np.round(center / delta).astype(int) before and after (round-half-even = rint)
+      dx = (int)rint(vx * p.t_new / p.pitch) - (int)rint(vx * p.t_prev / p.pitch);
+      dy = (int)rint(vy * p.t_new / p.pitch) - (int)rint(vy * p.t_prev / p.pitch);
+      ox = p.origin[2 * env];
+      oy = p.origin[2 * env + 1];
     }
-    for (int j = threadIdx.x; j < N; j += blockDim.x) {
-      nz_buf[j] = (p.noise && e < p.max_ext) ? p.noise[((size_t)env * p.max_ext + e) * N + j]
-                                             : philox_normal(p.seed, (uint32_t)env, ext0 + (uint32_t)e, (uint32_t)j);
+    s_dx[threadIdx.x] = dx; s_dy[threadIdx.x] = dy; s_ox[threadIdx.x] = ox; s_oy[threadIdx.x] = oy;
+  }
+  __syncthreads();
+  int rounds = 0;
+  for (int g = 0; g < kExtG; ++g) rounds = max(rounds, abs(s_dx[g]) + abs(s_dy[g]));
+  for (int r = 0; r < rounds; ++r) {
+    // class of env g this round: 1 horizontal, 2 vertical, 0 idle
+    auto cls = [&](int g) { return r < abs(s_dx[g]) ? 1 : (r < abs(s_dx[g]) + abs(s_dy[g]) ? 2 : 0); };
+    for (int g = 0; g < kExtG; ++g) {
+      const int c = cls(g);
+      if (!c) continue;
+      const int env = env0 + g;
+      const bool horizontal = c == 1;
+      const bool flipped = horizontal ? s_dx[g] > 0 : s_dy[g] > 0;
+      const int nz = horizontal ? p.nz_h : p.nz_v;
+      const int32_t* st = horizontal ? p.stencil_h : p.stencil_v;
+      const double* master = p.master + (size_t)env * N * N;
+      const int ox = s_ox[g], oy = s_oy[g];
+      for (int k = threadIdx.x; k < nz; k += blockDim.x) {
+        int sy = st[k] / N, sx = st[k] - sy * N;
+        if (flipped) { sy = N - 1 - sy; sx = N - 1 - sx; }
+        int py = sy + oy, px = sx + ox;
+        if (py >= N) py -= N;
+        if (px >= N) px -= N;
+        zb[(size_t)g * nzmax + k] = master[(size_t)py * N + px];
+      }
+      const uint32_t ext = p.ext_counter[env] + (uint32_t)r;
+      for (int j = threadIdx.x; j < N; j += blockDim.x)
+        nb[(size_t)g * N + j] = (p.noise && r < p.max_ext) ? p.noise[((size_t)env * p.max_ext + r) * N + j]
+                                                           : philox_normal(p.seed, (uint32_t)env, ext, (uint32_t)j);
     }
     __syncthreads();
-    // origin after this extrusion
-    int nox = ox, noy = oy;
-    if (horizontal) nox = flipped ? (ox + 1 == N ? 0 : ox + 1) : (ox == 0 ? N - 1 : ox - 1);
-    else noy = flipped ? (oy + 1 == N ? 0 : oy + 1) : (oy == 0 ? N - 1 : oy - 1);
-    for (int i = threadIdx.x; i < N; i += blockDim.x) {
-      double a = 0, b = 0;
-      for (int k = 0; k < nz; ++k) a = fma(At[(size_t)k * N + i], z[k], a);
-      for (int j = 0; j < N; ++j) b = fma(Bt[(size_t)j * N + i], nz_buf[j], b);
-      const double v = a + b * p.sqrt_cn2;
-      // logical position of new_slice[i]
-      int ly, lx;
-      if (horizontal) { ly = flipped ? N - 1 - i : i; lx = flipped ? N - 1 : 0; }
-      else { ly = flipped ? N - 1 : 0; lx = flipped ? N - 1 - i : i; }
-      int py = ly + noy, px = lx + nox;
-      if (py >= N) py -= N;
-      if (px >= N) px -= N;
-      master[(size_t)py * N + px] = v;
+    // thread (row i, half kh): rows i = tid % N (+ strides), kh = tid / N in {0, 1} sums one half of the stencil / noise
+    // index; the halves meet in LDS.  (N <= 256 rows per pass; larger N loops.)
+    const int half = blockDim.x >> 1;
+    const int kh = threadIdx.x >= half ? 1 : 0;
+    for (int i0 = 0; i0 < N; i0 += half) {
+      const int i = i0 + (threadIdx.x - kh * half);
+      double out[kExtG];
+#pragma unroll
+      for (int g = 0; g < kExtG; ++g) out[g] = 0.0;
+      if (i < N) {
+        for (int c = 1; c <= 2; ++c) {
+          bool any = false;
+          for (int g = 0; g < kExtG; ++g) any |= cls(g) == c;
+          if (!any) continue;
+          const int nz = c == 1 ? p.nz_h : p.nz_v;
+          const double* At = c == 1 ? p.At_h : p.At_v;
+          const double* Bt = c == 1 ? p.Bt_h : p.Bt_v;
+          double a[kExtG], b[kExtG];
+#pragma unroll
+          for (int g = 0; g < kExtG; ++g) { a[g] = 0.0; b[g] = 0.0; }
+          const int k0 = kh ? (nz + 1) / 2 : 0, k1 = kh ? nz : (nz + 1) / 2;
+#pragma unroll 8
+          for (int k = k0; k < k1; ++k) {
+            const double w = At[(size_t)k * N + i];
+#pragma unroll
+            for (int g = 0; g < kExtG; ++g) a[g] = fma(w, zb[(size_t)g * nzmax + k], a[g]);
+          }
+          const int j0 = kh ? (N + 1) / 2 : 0, j1 = kh ? N : (N + 1) / 2;
+#pragma unroll 8
+          for (int j = j0; j < j1; ++j) {
+            const double w = Bt[(size_t)j * N + i];
+#pragma unroll
+            for (int g = 0; g < kExtG; ++g) b[g] = fma(w, nb[(size_t)g * N + j], b[g]);
+          }
+#pragma unroll
+          for (int g = 0; g < kExtG; ++g)
+            if (cls(g) == c) out[g] = a[g] + b[g] * p.sqrt_cn2;
+        }
+        if (kh) {
+#pragma unroll
+          for (int g = 0; g < kExtG; ++g) pb[(size_t)g * N + i] = out[g];
+        }
+      }
+      __syncthreads();
+      if (i < N && !kh) {
+#pragma unroll
+        for (int g = 0; g < kExtG; ++g) {
+          const int c = cls(g);
+          if (!c) continue;
+          const double v = out[g] + pb[(size_t)g * N + i];
+          const bool horizontal = c == 1;
+          const bool flipped = horizontal ? s_dx[g] > 0 : s_dy[g] > 0;
+          int nox = s_ox[g], noy = s_oy[g];
+          if (horizontal) nox = flipped ? (nox + 1 == N ? 0 : nox + 1) : (nox == 0 ? N - 1 : nox - 1);
+          else noy = flipped ? (noy + 1 == N ? 0 : noy + 1) : (noy == 0 ? N - 1 : noy - 1);
+          int ly, lx;
+          if (horizontal) { ly = flipped ? N - 1 - i : i; lx = flipped ? N - 1 : 0; }
+          else { ly = flipped ? N - 1 : 0; lx = flipped ? N - 1 - i : i; }
+          int py = ly + noy, px = lx + nox;
+          if (py >= N) py -= N;
+          if (px >= N) px -= N;
+          p.master[(size_t)(env0 + g) * N * N + (size_t)py * N + px] = v;
+        }
+      }
+      __syncthreads();
     }
-    ox = nox;
-    oy = noy;
+    __syncthreads();
+    if (threadIdx.x < kExtG) {
+      const int g = threadIdx.x;
+      const int c = cls(g);
+      if (c == 1) s_ox[g] = s_dx[g] > 0 ? (s_ox[g] + 1 == N ? 0 : s_ox[g] + 1) : (s_ox[g] == 0 ? N - 1 : s_ox[g] - 1);
+      else if (c == 2) s_oy[g] = s_dy[g] > 0 ? (s_oy[g] + 1 == N ? 0 : s_oy[g] + 1) : (s_oy[g] == 0 ? N - 1 : s_oy[g] - 1);
+    }
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
-    p.origin[2 * env] = ox;
-    p.origin[2 * env + 1] = oy;
-    p.ext_counter[env] = ext0 + (uint32_t)n_ext;
+  if (threadIdx.x < kExtG && env0 + threadIdx.x < B) {
+    const int g = threadIdx.x, env = env0 + g;
+    p.origin[2 * env] = s_ox[g];
+    p.origin[2 * env + 1] = s_oy[g];
+    p.ext_counter[env] += (uint32_t)(abs(s_dx[g]) + abs(s_dy[g]));
   }
 }
 
@@ -888,6 +973,76 @@ __global__ void k_store_master(const T* __restrict__ psi, double* __restrict__ m
     origin[2 * (first + e) + 1] = 0;
     ext_counter[first + e] = 0;
   }
+}
+
+// Per-step repack of the float64 ring-buffer screens into the MFMA kernel's tiled fp32 layout (dynamic atmosphere).
+// One workgroup = one 32-env tile x 2 pixel tiles: each wave reads 64 consecutive packed pixels of one env at a time
+// (coalesced along x), the block transposes through LDS and every wave then writes whole 1-KiB rows of psi_tile.
+// The piston offset subtracted is the aperture mean measured by the PREVIOUS repack (outputs are invariant to a global
+// phase; the offset only keeps the fp32 magnitudes small), and this pass accumulates the sums for the next one.
+__global__ __launch_bounds__(256) void k_repack_master(const double* __restrict__ master, const int32_t* __restrict__ origin,
+                                                        const int32_t* __restrict__ ap_index, const double* __restrict__ offset,
+                                                        double* __restrict__ sum_next, float* __restrict__ psi_tile, int B, int N,
+                                                        int n_ap, int n_ptiles, double inv_two_pi_lambda) {
+  constexpr int LD = 68;  // padded row (floats) of the [32 envs][64 pixels] staging tile
+  __shared__ float stage[32 * LD];
+  const int et = blockIdx.y;
+  const int pt0 = blockIdx.x * 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int p = pt0 * 32 + lane;
+  // logical pupil coordinates of this lane's packed pixel (same for every env)
+  int iy = 0, ix = 0;
+  const bool valid_p = p < n_ap;
+  if (valid_p) {
+    const int flat = ap_index[p];
+    iy = flat / N;
+    ix = flat - iy * N;
+  }
+  // all 8 env loads of this wave are issued before any is consumed (memory-level parallelism)
+  double v[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int env = et * 32 + wave * 8 + q;
+    v[q] = 0.0;
+    if (env < B && valid_p) {
+      int py = iy + origin[2 * env + 1], px = ix + origin[2 * env];
+      if (py >= N) py -= N;
+      if (px >= N) px -= N;
+      v[q] = master[(size_t)env * N * N + (size_t)py * N + px];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int e = wave * 8 + q;
+    const int env = et * 32 + e;
+    float out = 0.f;
+    if (env < B) {
+      if (valid_p) out = (float)((v[q] - offset[env]) * inv_two_pi_lambda);
+      double sum = v[q];
+      for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+      if (lane == 0) atomicAdd(&sum_next[env], sum);
+    }
+    stage[e * LD + lane] = out;
+  }
+  __syncthreads();
+  // rows of psi_tile: [et][pt][g][lane = 32 h + e][4]; this block owns pt0, pt0 + 1 (8 rows); wave w writes rows 2w, 2w+1
+  for (int rr = 0; rr < 2; ++rr) {
+    const int row = wave * 2 + rr, tl = row >> 2, g = row & 3;
+    const int pt = pt0 + tl;
+    if (pt >= n_ptiles) continue;
+    const int h = lane >> 5, e = lane & 31;
+    const float* src = stage + e * LD + tl * 32 + 8 * g + 4 * h;
+    float4 v = make_float4(src[0], src[1], src[2], src[3]);
+    reinterpret_cast<float4*>(psi_tile)[(((size_t)et * n_ptiles + pt) * 4 + g) * 64 + lane] = v;
+  }
+}
+
+// offsets for the next repack: mean of the sums the last one accumulated
+__global__ void k_refresh_offsets(double* __restrict__ offset, double* __restrict__ sum_next, int B, int n_ap) {
+  const int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= B) return;
+  offset[env] = sum_next[env] / (double)n_ap;
+  sum_next[env] = 0.0;
 }
 
 // ring buffer -> plain [B][N][N] (tests, checkpointing)

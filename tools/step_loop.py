@@ -8,14 +8,14 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--B", type=int, default=1024); ap.add_argument("--N", type=int, default=256)
 ap.add_argument("--A", type=int, default=64); ap.add_argument("--o", type=int, default=2)
 ap.add_argument("--steps", type=int, default=20); ap.add_argument("--kernel", default="auto")
-ap.add_argument("--chunks", type=int, default=0); ap.add_argument("--act_type", default="num_actuators")
+ap.add_argument("--chunks", type=int, default=0); ap.add_argument("--atm", default="quasi_static"); ap.add_argument("--vel", type=float, default=0.0); ap.add_argument("--act_type", default="num_actuators")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 g = torch.Generator(dev).manual_seed(1)
 # cheap synthetic screens (smooth random, a few rad rms): the fused kernel's cost does not depend on their spectrum
 scr = torch.nn.functional.interpolate(torch.randn(args.B, 1, 16, 16, device=dev, generator=g), size=(args.N, args.N),
                                       mode="bicubic").squeeze(1) * 2e-6
-env = BatchedAOEnv(args.B, dev, num_pupil_pixels=args.N, act_dim=args.A, obs_dim=args.o, act_type=args.act_type,
+env = BatchedAOEnv(args.B, dev, atm_type=args.atm, atm_vel=args.vel, num_pupil_pixels=args.N, act_dim=args.A, obs_dim=args.o, act_type=args.act_type,
                    timesteps_per_episode=1000000, kernel=args.kernel, pixel_chunks=args.chunks, screens=scr, verbose=False)
 a = torch.randn(args.B, args.A, device=dev, generator=g) * 0.7071
 env.reset()
