@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libaogym.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 AOG_REWARD = {"strehl_ratio": 0, "smf_ssim": 1}
 AOG_PRECISION = {"fast": 0, "fp64": 1}
@@ -27,7 +27,7 @@ class AogConfig(C.Structure):
 
 class AogTables(C.Structure):
     _fields_ = [("ap_index", C.POINTER(C.c_int32))] + [(n, C.POINTER(C.c_double)) for n in (
-        "modes", "gram", "wfs_tables", "sci_tables", "wfs_coef", "sci_coef")]
+        "modes", "gram", "wfs_tables", "sci_tables", "wfs_coef", "sci_coef", "focal_m1", "focal_m2")] + [("n_focal", C.c_int32)]
 
 
 class AogLayerTables(C.Structure):
@@ -63,6 +63,7 @@ SYMBOLS = {
     "aog_set_actuators": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "aog_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "aog_step": (C.c_int, [C.c_void_p] * 9),
+    "aog_focal_image": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "aog_selftest_sincos": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "aog_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "aog_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),

@@ -129,10 +129,13 @@ class BatchedAOEnv:
             st=np.ascontiguousarray(t.sci_tables, dtype=np.float64),
             wc=np.ascontiguousarray(np.stack([t.wfs_coef.real, t.wfs_coef.imag], axis=-1), dtype=np.float64),
             sc=np.ascontiguousarray(np.stack([t.sci_coef.real, t.sci_coef.imag], axis=-1), dtype=np.float64),
+            m1=np.ascontiguousarray(np.stack([t.focal_m1.real, t.focal_m1.imag], axis=-1), dtype=np.float64),
+            m2=np.ascontiguousarray(np.stack([t.focal_m2.real, t.focal_m2.imag], axis=-1), dtype=np.float64),
         )
         tabs = _lib.AogTables(_dptr(keep["ap"], C.c_int32), _dptr(keep["modes"], C.c_double), _dptr(keep["gram"], C.c_double),
                               _dptr(keep["wt"], C.c_double), _dptr(keep["st"], C.c_double), _dptr(keep["wc"], C.c_double),
-                              _dptr(keep["sc"], C.c_double))
+                              _dptr(keep["sc"], C.c_double), _dptr(keep["m1"], C.c_double), _dptr(keep["m2"], C.c_double),
+                              int(t.focal_m1.shape[0]))
         _lib.check(self.lib.aog_upload_tables(self._handle, C.byref(tabs)))
         self.info = _lib.AogInfo()
         _lib.check(self.lib.aog_get_info(self._handle, C.byref(self.info)))
@@ -324,6 +327,15 @@ class BatchedAOEnv:
         a = torch.as_tensor(act, device=self.device).to(torch.float64).reshape(self.num_envs, self.num_modes).contiguous()
         _lib.check(self.lib.aog_set_actuators(self._handle, C.c_void_p(a.data_ptr()), self._stream()))
         torch.cuda.current_stream(self.device).synchronize()
+
+    def focal_image(self, env_index=0):
+        """``wf_wfs_after_foc.electric_field`` of one env (AO_env.py:138): complex64 [n_focal, n_focal] (y, x), up to a global
+        phase.  ``abs()**2 * tables.focal_pixel_area`` is the ``.power`` image the reference's render() shows."""
+        torch = self._torch
+        nf = int(self.tables.focal_m1.shape[0])
+        out = torch.empty((nf, nf, 2), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.aog_focal_image(self._handle, int(env_index), C.c_void_p(out.data_ptr()), self._stream()))
+        return torch.view_as_complex(out)
 
     def profile(self, enable=True):
         _lib.check(self.lib.aog_profile_enable(self._handle, int(bool(enable))))

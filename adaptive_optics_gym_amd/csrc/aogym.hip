@@ -436,6 +436,17 @@ int aog_upload_tables(aog_env* e, const aog_tables* t) {
     HIP_TRY(hipMemcpy(e->tabs_f32, tf.data(), sizeof(float) * tf.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->tabs_tile, tt.data(), sizeof(float) * tt.size(), hipMemcpyHostToDevice));
   }
+  if (t->focal_m1 && t->focal_m2 && t->n_focal > 0 && !e->focal_m1) {
+    const int N = e->cfg.n_pupil, nf = t->n_focal;
+    int rc;
+    if ((rc = dev_alloc(e, &e->focal_m1, (size_t)nf * N * 2, false)) != AOG_OK) return rc;
+    if ((rc = dev_alloc(e, &e->focal_m2, (size_t)nf * N * 2, false)) != AOG_OK) return rc;
+    if ((rc = dev_alloc(e, &e->focal_E, (size_t)N * N * 2)) != AOG_OK) return rc;
+    if ((rc = dev_alloc(e, &e->focal_T, (size_t)nf * N * 2)) != AOG_OK) return rc;
+    HIP_TRY(hipMemcpy(e->focal_m1, t->focal_m1, sizeof(double) * nf * N * 2, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->focal_m2, t->focal_m2, sizeof(double) * nf * N * 2, hipMemcpyHostToDevice));
+    e->n_focal = nf;
+  }
   e->tables_ready = true;
   return AOG_OK;
 }
@@ -581,6 +592,30 @@ int aog_step(aog_env* e, const float* action, float* obs_raw, uint16_t* obs, flo
   int rc = launch_fused(e, s);
   if (rc != AOG_OK) return rc;
   return launch_epilogue(e, true, obs_raw, obs, reward, done, power, strehl, s);
+}
+
+int aog_focal_image(aog_env* e, int env_index, float* field_dev, void* stream) {
+  if (!e || !field_dev) return fail(AOG_ERR_INVALID, "aog_focal_image: null argument");
+  if (!e->tables_ready || !e->screens_ready) return fail(AOG_ERR_STATE, "aog_focal_image before aog_upload_tables/aog_set_screens");
+  if (!e->n_focal) return fail(AOG_ERR_STATE, "aog_focal_image: focal_m1/focal_m2 were not uploaded");
+  if (env_index < 0 || env_index >= e->B) return fail(AOG_ERR_INVALID, "aog_focal_image: env %d outside [0,%d)", env_index, e->B);
+  const bool fast = e->cfg.precision == AOG_PRECISION_FAST;
+  if (fast && e->kernel != AOG_KERNEL_MFMA && !e->cfg.atm_dynamic) {
+    // psi_tile is always written by aog_set_screens in non-dynamic handles, whatever kernel steps them
+  }
+  HIP_TRY(hipSetDevice(e->device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int N = e->cfg.n_pupil, nf = e->n_focal;
+  HIP_TRY(hipMemsetAsync(e->focal_E, 0, sizeof(double) * 2 * N * N, s));
+  hipLaunchKernelGGL(aog::k_focal_field, dim3((e->n_ap + 255) / 256), dim3(256), 0, s, fast ? e->psi_tile : nullptr,
+                     fast ? nullptr : e->psi64, e->modes_f32, e->modes64, e->act_rev, e->act_dm, e->ap_index,
+                     reinterpret_cast<double2*>(e->focal_E), env_index, e->n_ap, e->n_ptiles, e->A, e->A_pad, e->Bp, e->cfg.wavelength_wfs);
+  hipLaunchKernelGGL(aog::k_cgemm_small, dim3((nf * N + 255) / 256), dim3(256), 0, s, reinterpret_cast<const double2*>(e->focal_m1),
+                     reinterpret_cast<const double2*>(e->focal_E), reinterpret_cast<double2*>(e->focal_T), (float2*)nullptr, nf, N, N);
+  hipLaunchKernelGGL(aog::k_cgemm_small, dim3((nf * nf + 255) / 256), dim3(256), 0, s, reinterpret_cast<const double2*>(e->focal_T),
+                     reinterpret_cast<const double2*>(e->focal_m2), (double2*)nullptr, reinterpret_cast<float2*>(field_dev), nf, N, nf);
+  HIP_TRY(hipGetLastError());
+  return AOG_OK;
 }
 
 int aog_selftest_sincos(const float* u_dev, float* sin_dev, float* cos_dev, int n, int flavour, void* stream) {

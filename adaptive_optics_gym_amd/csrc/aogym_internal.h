@@ -36,6 +36,12 @@ struct aog_env {
   double* sci_coef = nullptr;    // [MRS_used][2]
   double* modes64 = nullptr;     // validation: [n_ap][A]
   double* tabs64 = nullptr;      // validation: [n_ap][MRW_used+MRS_used]
+  // focal-image export (optional)
+  int n_focal = 0;
+  double* focal_m1 = nullptr;    // [n_focal][N] complex
+  double* focal_m2 = nullptr;    // [N][n_focal] complex
+  double* focal_E = nullptr;     // [N][N] complex scratch
+  double* focal_T = nullptr;     // [n_focal][N] complex scratch
   // state
   float* psi_rev = nullptr;      // [n_quads][Bp][4]
   float* psi_tile = nullptr;     // [Bp/32][n_ptiles][4][64][4]

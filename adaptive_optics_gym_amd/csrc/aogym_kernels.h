@@ -1060,6 +1060,50 @@ __global__ void k_unroll_master(const double* __restrict__ master, const int32_t
 }
 #endif  // AOG_MAIN_TU
 
+// ------------------------------------------------------------------------------------------------
+// K4  focal-plane field of one env (propagator_fiber, AO_env.py:138), off the step() path.
+//   E[y][x]  = exp(2 pi i (psi + M a))  on the aperture (amplitude folded into focal_m1), 0 outside
+//   T[v][x]  = sum_y m1[v][y] E[y][x];     F[v][u] = sum_x T[v][x] m2[x][u]        (float64 accumulation)
+// ------------------------------------------------------------------------------------------------
+#ifdef AOG_MAIN_TU
+__global__ void k_focal_field(const float* __restrict__ psi_tile, const double* __restrict__ psi64, const float* __restrict__ modes_f32,
+                              const double* __restrict__ modes64, const float* __restrict__ act_rev, const double* __restrict__ act_dm,
+                              const int32_t* __restrict__ ap_index, double2* __restrict__ E, int env, int n_ap, int n_ptiles, int A,
+                              int A_pad, int Bp, double lambda_wfs) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_ap) return;
+  double rev;
+  if (psi64) {  // float64 validation handle
+    double surf = 0;
+    for (int k = 0; k < A; ++k) surf = fma(modes64[(size_t)p * A + k], act_dm[(size_t)env * A + k], surf);
+    rev = (psi64[(size_t)env * n_ap + p] + 4.0 * M_PI * surf) / (2.0 * M_PI * lambda_wfs);
+  } else {
+    double acc = (double)psi_tile[psi_tile_index(env, p, n_ptiles)];
+    for (int k = 0; k < A; ++k) acc = fma((double)modes_f32[(size_t)p * A_pad + k], (double)act_rev[(size_t)k * Bp + env], acc);
+    rev = acc;
+  }
+  double sn, cs;
+  sincospi(2.0 * (rev - rint(rev)), &sn, &cs);
+  E[ap_index[p]] = make_double2(cs, sn);
+}
+
+// out[r][c] = sum_k a[r][k] * b[k][c]  (complex, row-major), one thread per output
+__global__ void k_cgemm_small(const double2* __restrict__ a, const double2* __restrict__ b, double2* __restrict__ out, float2* __restrict__ out32,
+                              int R, int K, int Cn) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= R * Cn) return;
+  const int r = idx / Cn, c = idx - r * Cn;
+  double re = 0, im = 0;
+  for (int k = 0; k < K; ++k) {
+    const double2 x = a[(size_t)r * K + k], y = b[(size_t)k * Cn + c];
+    re = fma(x.x, y.x, fma(-x.y, y.y, re));
+    im = fma(x.x, y.y, fma(x.y, y.x, im));
+  }
+  if (out) out[idx] = make_double2(re, im);
+  if (out32) out32[idx] = make_float2((float)re, (float)im);
+}
+#endif  // AOG_MAIN_TU
+
 // self-test hook: the three sin/cos flavours of the fused kernels on caller-supplied revolutions
 #ifdef AOG_MAIN_TU
 __global__ void k_selftest_sincos(const float* __restrict__ u, float* __restrict__ s, float* __restrict__ c, int n, int flavour) {

@@ -193,6 +193,10 @@ class HostTables:
     sci_coef: np.ndarray            # [1, MRS] complex
     n_fiber_modes: int
     lp_u: list = field(default_factory=list)
+    focal_m1: np.ndarray = None      # [n_focal, N] complex (scale factors folded in)
+    focal_m2: np.ndarray = None      # [N, n_focal] complex
+    lp_modes: np.ndarray = None      # [n_fiber, n_focal, n_focal]
+    focal_pixel_area: float = 0.0
     strehl_focal_index: int = 0
 
 
@@ -283,4 +287,6 @@ def build_tables(params: OpticalParams, act_type: str, act_dim: int, obs_dim: in
     return HostTables(params=params, act_type=act_type, act_dim=act_dim, obs_dim=obs_dim, n_ap=n_ap, ap_index=ap_index,
                       x_ap=x_ap, y_ap=y_ap, modes=modes, mode_specs=specs, gram=gram, wfs_tables=wfs_tables,
                       wfs_coef=wfs_coef, sci_tables=sci_tables, sci_coef=sci_coef, n_fiber_modes=int(lps.shape[0]),
-                      lp_u=[lp_roots(0, V), lp_roots(1, V)], strehl_focal_index=kstar)
+                      lp_u=[lp_roots(0, V), lp_roots(1, V)], strehl_focal_index=kstar,
+                      focal_m1=amp * pix_area / (1j * lam * f) * np.exp(-1j * kappa * np.outer(Xf, ax)),
+                      focal_m2=np.exp(-1j * kappa * np.outer(ax, Xf)), lp_modes=lps, focal_pixel_area=dAf)

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define AOG_ABI_VERSION 4
+#define AOG_ABI_VERSION 5
 
 typedef struct aog_env aog_env;
 
@@ -87,6 +87,12 @@ typedef struct {
   const double* sci_tables;  /* [n_sci_tables][n_ap]                                                 */
   const double* wfs_coef;    /* [o^2 + n_fiber_modes][n_wfs_tables][2]  (re, im)                     */
   const double* sci_coef;    /* [1][n_sci_tables][2]                                                 */
+  /* optional (NULL = aog_focal_image unsupported): the two matrices of the Fraunhofer matrix Fourier transform onto
+   * the n_focal x n_focal fiber focal grid (propagator_fiber, AO_env.py:390), scale factors folded into focal_m1:
+   *   F = focal_m1 [n_focal][N] . E [N][N] . focal_m2 [N][n_focal]                                           */
+  const double* focal_m1;    /* [n_focal][N][2]                                                        */
+  const double* focal_m2;    /* [N][n_focal][2]                                                        */
+  int32_t n_focal;           /* 128 (AO_env.py:235)                                                    */
 } aog_tables;
 
 typedef struct {
@@ -158,6 +164,11 @@ int aog_reset(aog_env* env, const uint8_t* mask_dev, float* obs_raw_dev, uint16_
  *   strehl_dev  [B] float32 (Strehl ratio in [0,1]; nullable) */
 int aog_step(aog_env* env, const float* action_dev, float* obs_raw_dev, uint16_t* obs_dev, float* reward_dev,
              uint8_t* done_dev, float* power_dev, float* strehl_dev, void* stream);
+
+/* self.wf_wfs_after_foc.electric_field of one env (AO_env.py:138): the n_focal x n_focal focal-plane field of the sensing
+ * arm with the current screen and mirror, as interleaved (re, im) float32, row-major (y, x), up to a global phase (the
+ * library stores screens with their aperture mean removed).  Off the step() path; used for render()/fiber cross-checks. */
+int aog_focal_image(aog_env* env, int env_index, float* field_dev /* [n_focal][n_focal][2] */, void* stream);
 
 /* Self-test hook: sin(2 pi u), cos(2 pi u) for n float32 revolutions u_dev with the fused kernels' device code.
  * flavour 0 = polynomial, 1 = v_sin_f32/v_cos_f32 after the exact reduction, 2 = v_sin_f32/v_cos_f32 on raw input. */

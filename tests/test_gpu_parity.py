@@ -403,3 +403,47 @@ def test_dynamic_atmosphere_device_rng_statistics_and_shift():
     var1 = float(env.get_screens().var())
     assert 0.3 * var0 < var1 < 3.0 * var0
     env.close()
+
+
+def test_batched_rollout_on_device():
+    torch = _torch()
+    from adaptive_optics_gym_amd import BatchedAOEnv
+    from adaptive_optics_gym_amd.rollout import make_actor, rollout
+
+    B, T = 8, 5
+    env = BatchedAOEnv(B, "cuda:0", act_dim=16, obs_dim=2, num_pupil_pixels=32, timesteps_per_episode=T,
+                       screens=smooth_screens(B, 32, 1), verbose=False)
+    out = rollout(env, make_actor(4, 16, 32, device="cuda:0"), episodes=2)
+    assert out["obs"].shape == (2 * T, B, 4) and out["obs"].dtype == torch.float16
+    assert out["rew"].shape == (2 * T, B) and bool(torch.isfinite(out["rew"]).all())
+    assert bool(out["done"][T - 1].all()) and not bool(out["done"][T - 2].any())
+    assert -100.0 <= out["avg_ep_rew"] <= 0.0     # Strehl reward = 100 (S - 1)
+    env.close()
+
+
+@pytest.mark.parametrize("precision", ["fast", "fp64"])
+def test_focal_image_matches_literal_propagation(precision):
+    """K4: the materialised 128x128 focal field == the oracle's propagator_fiber output (AO_env.py:138), and projecting it
+    on the LP modes (the reference's literal fiber path, AO_env.py:471-474) == the power the fused kernel reports."""
+    torch = _torch()
+    from adaptive_optics_gym_amd import BatchedAOEnv
+    from oracle.ao_env_oracle import AOEnvOracle
+
+    N, B, A = 64, 2, 16
+    scr = smooth_screens(B, N, 8)
+    a = actions_for(B, A, 2)
+    kw = dict(act_dim=A, obs_dim=2, timesteps_per_episode=5)
+    env = BatchedAOEnv(B, "cuda:0", num_pupil_pixels=N, screens=scr, precision=precision, verbose=False, **kw)
+    env.reset()
+    _, _, _, _, info = env.step(torch.from_numpy(a).cuda())
+    for b in range(B):
+        ref = AOEnvOracle(num_pupil_pixels=N, screen=scr[b].ravel(), verbose=False, **kw)
+        ref.reset()
+        ref.step(a[b])
+        F = env.focal_image(b).cpu().numpy().astype(np.complex128)
+        power = np.abs(F) ** 2 * env.tables.focal_pixel_area
+        ref_power = ref.wf_wfs_after_foc.power.reshape(128, 128)
+        np.testing.assert_allclose(power, ref_power, rtol=1e-4, atol=1e-6 * ref_power.max())
+        coef = (env.tables.lp_modes * F[None]).sum(axis=(1, 2)) * env.tables.focal_pixel_area
+        np.testing.assert_allclose(np.sum(np.abs(coef) ** 2), float(info["power"][b]), rtol=2e-5)
+    env.close()

@@ -1,0 +1,59 @@
+"""Host logic of the batched rollout harness (no GPU): a stand-in env with the BatchedAOEnv interface on CPU tensors."""
+import math
+
+import torch
+from torch.distributions import MultivariateNormal
+
+from adaptive_optics_gym_amd.rollout import make_actor, rollout, sample_action
+
+
+class FakeEnv:
+    def __init__(self, B, obs_n, A, T):
+        self.num_envs, self.max_steps, self.device = B, T, torch.device("cpu")
+        self.obs_n, self.A, self.t = obs_n, A, 0
+
+    def reset(self):
+        self.t = 0
+        return torch.zeros(self.num_envs, self.obs_n, dtype=torch.float16), {}
+
+    def step(self, a):
+        self.t += 1
+        rew = -a.abs().mean(dim=1) - self.t
+        done = torch.full((self.num_envs,), self.t == self.max_steps)
+        obs = torch.full((self.num_envs, self.obs_n), float(self.t), dtype=torch.float16)
+        return obs, rew, done, torch.zeros(self.num_envs, dtype=torch.bool), {}
+
+
+def test_actor_shape_init_and_active_dropout():
+    torch.manual_seed(0)
+    actor = make_actor(4, 64, 150)
+    assert [tuple(l.weight.shape) for l in actor.hidden] == [(150, 4), (150, 150), (150, 150)]
+    assert tuple(actor.out.weight.shape) == (64, 150)
+    assert actor.hidden[0].weight.abs().max() <= 0.5 and actor.hidden[1].weight.abs().max() <= 1 / math.sqrt(150)
+    assert actor.out.weight.abs().max() <= 3e-3
+    x = torch.ones(3, 4)
+    assert not torch.equal(actor(x), actor(x))      # dropout is live while acting (network.py:48-55)
+
+
+def test_sample_action_matches_multivariate_normal_logprob():
+    torch.manual_seed(1)
+    mean = torch.randn(5, 6)
+    a, lp = sample_action(mean, 0.5)
+    ref = MultivariateNormal(mean, torch.diag(torch.full((6,), 0.5))).log_prob(a)
+    torch.testing.assert_close(lp, ref, rtol=1e-5, atol=1e-5)
+    big = sample_action(torch.zeros(20000, 4), 0.5)[0]
+    assert abs(float(big.var()) - 0.5) < 0.02
+
+
+def test_rollout_layout_and_logged_scalar():
+    torch.manual_seed(2)
+    B, T, E = 3, 4, 2
+    env = FakeEnv(B, 4, 6, T)
+    out = rollout(env, make_actor(4, 6, 16), episodes=E)
+    assert out["obs"].shape == (T * E, B, 4) and out["act"].shape == (T * E, B, 6)
+    assert out["rew"].shape == (T * E, B) and out["done"].shape == (T * E, B) and out["log_prob"].shape == (T * E, B)
+    assert out["done"][T - 1].all() and not out["done"][:T - 1].any()
+    assert torch.equal(out["next_obs"][0], out["obs"][1])
+    ep = out["rew"].reshape(E, T, B).sum(1)
+    torch.testing.assert_close(out["ep_returns"], ep)
+    assert abs(out["avg_ep_rew"] - float(ep.mean()) / T) < 1e-6   # algorithm.py:509-510
