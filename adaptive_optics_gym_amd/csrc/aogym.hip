@@ -131,7 +131,8 @@ int launch_epilogue(aog_env* e, bool is_step, float* obs_raw, uint16_t* obs, flo
   p.ssim_peak = e->cfg.ssim_ref_peak;
   p.ssim_alpha = e->cfg.ssim_alpha;
   const int NS = 2 * (p.MRW + p.MRS);
-  const size_t lds = (size_t)(aog::kEpiQuarters * NS + p.n_obs) * aog::kEpiEnvs * sizeof(double);
+  const size_t lds = ((size_t)(aog::kEpiQuarters * NS + p.n_obs) * aog::kEpiEnvs + (size_t)(p.n_obs + p.n_fiber) * p.MRW_used * 2 +
+                      (size_t)p.MRS_used * 2) * sizeof(double);
   hipLaunchKernelGGL(aog::k_epilogue, dim3((e->Bp + aog::kEpiEnvs - 1) / aog::kEpiEnvs), dim3(1024), lds, s, p);
   HIP_TRY(hipGetLastError());
   return AOG_OK;

@@ -690,6 +690,12 @@ __global__ __launch_bounds__(1024) void k_epilogue(EpilogueArgs p) {
   const int NS = 2 * MR;
   const size_t cstride = (size_t)NS * p.Bp;
   double* part = sm + (size_t)(NS + p.n_obs) * kEpiEnvs;  // [quarter 1..3][NS][16]
+  // the small coefficient matrices go to LDS once (the finishing threads would otherwise chase them through L2 serially)
+  const int n_out_all = p.n_obs + p.n_fiber;
+  double* cfs = part + (size_t)(kEpiQuarters - 1) * NS * kEpiEnvs;  // [n_out][MRW_used][2] then [MRS_used][2]
+  for (int i = threadIdx.x; i < n_out_all * p.MRW_used * 2; i += blockDim.x) cfs[i] = p.wfs_coef[i];
+  double* cfsci = cfs + (size_t)n_out_all * p.MRW_used * 2;
+  for (int i = threadIdx.x; i < p.MRS_used * 2; i += blockDim.x) cfsci[i] = p.sci_coef[i];
   for (int s = wave; s < NS; s += nw) {
     const double* src = p.partials + (size_t)s * p.Bp + env;
     double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -720,7 +726,7 @@ __global__ __launch_bounds__(1024) void k_epilogue(EpilogueArgs p) {
   const int n_out = p.n_obs + p.n_fiber;
   for (int j = 0; j < n_out; ++j) {
     double zr = 0, zi = 0;
-    const double* cf = p.wfs_coef + (size_t)j * p.MRW_used * 2;
+    const double* cf = cfs + (size_t)j * p.MRW_used * 2;
     for (int m = 0; m < p.MRW_used; ++m) {
       const double u = U[(2 * m) * kEpiEnvs], v = U[(2 * m + 1) * kEpiEnvs];
       zr += cf[2 * m] * u - cf[2 * m + 1] * v;
@@ -742,8 +748,8 @@ __global__ __launch_bounds__(1024) void k_epilogue(EpilogueArgs p) {
   double zr = 0, zi = 0;
   for (int m = 0; m < p.MRS_used; ++m) {
     const double u = U[(2 * (p.MRW + m)) * kEpiEnvs], v = U[(2 * (p.MRW + m) + 1) * kEpiEnvs];
-    zr += p.sci_coef[2 * m] * u - p.sci_coef[2 * m + 1] * v;
-    zi += p.sci_coef[2 * m] * v + p.sci_coef[2 * m + 1] * u;
+    zr += cfsci[2 * m] * u - cfsci[2 * m + 1] * v;
+    zi += cfsci[2 * m] * v + cfsci[2 * m + 1] * u;
   }
   const double strehl = zr * zr + zi * zi;
   double reward;
