@@ -218,7 +218,7 @@ class BatchedAOEnv:
             float(np.sqrt(self.Cn_squared)), float(self.params.pupil_pixel), float(self.params.delta_t))
         _lib.check(self.lib.aog_upload_layer(self._handle, C.byref(lt)))
         v = torch.from_numpy(np.ascontiguousarray(self.velocity_vectors)).to(self.device)
-        _lib.check(self.lib.aog_set_wind(self._handle, C.c_void_p(v.data_ptr()), self._stream()))
+        _lib.check(self.lib.aog_set_wind(self._handle, C.c_void_p(v.data_ptr()), float(np.abs(self.velocity_vectors).max()), self._stream()))
         _lib.check(self.lib.aog_set_rng_seed(self._handle, C.c_uint64(1234 if self.seed is None else int(self.seed))))
         torch.cuda.current_stream(self.device).synchronize()
 

@@ -185,13 +185,35 @@ int evolve_layer(aog_env* e, hipStream_t s) {
   p.pitch = e->pitch;
   p.sqrt_cn2 = e->sqrt_cn2;
   p.seed = e->rng_seed;
-  const size_t lds = (size_t)aog::kExtG * (std::max(e->nz_v, e->nz_h) + 2 * e->cfg.n_pupil) * sizeof(double);
-  if (lds > 64 * 1024 && !e->extrude_attr_set) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(aog::k_extrude), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    e->extrude_attr_set = true;
+  const bool use_rounds = e->rounds_ok && e->B >= 64 && !getenv("AOG_EXTRUDE_SIMPLE");
+  if (use_rounds) {
+    // per axis at most ceil(|v| dt / pitch) + 1 whole-pixel shifts in one step
+    const int R = (int)std::ceil(e->max_wind * e->delta_t / e->pitch) + 1;
+    aog::ExtrudeRoundArgs q{};
+    q.a = p;
+    q.B = e->B;
+    dim3 grid((e->cfg.n_pupil + 31) / 32, (e->B + 31) / 32);
+    for (int phase = 0; phase < 2; ++phase)
+      for (int r = 0; r < R; ++r) {
+        q.origin_in = e->origin;
+        q.origin_out = e->origin_alt;
+        q.phase = phase;
+        q.round = r;
+        hipLaunchKernelGGL(aog::k_extrude_round, grid, dim3(256), 0, s, q);
+        std::swap(e->origin, e->origin_alt);
+      }
+    hipLaunchKernelGGL(aog::k_extrude_finish, dim3((e->B + 255) / 256), dim3(256), 0, s, p, e->B);
+    HIP_TRY(hipGetLastError());
+  } else {
+    const size_t lds = (size_t)aog::kExtG * (std::max(e->nz_v, e->nz_h) + 2 * e->cfg.n_pupil) * sizeof(double);
+    if (lds > 64 * 1024 && !e->extrude_attr_set) {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(aog::k_extrude), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      e->extrude_attr_set = true;
+    }
+    p.origin = e->origin;
+    hipLaunchKernelGGL(aog::k_extrude, dim3((e->B + aog::kExtG - 1) / aog::kExtG), dim3(aog::kExtThreads), lds, s, p, e->B);
+    HIP_TRY(hipGetLastError());
   }
-  hipLaunchKernelGGL(aog::k_extrude, dim3((e->B + aog::kExtG - 1) / aog::kExtG), dim3(aog::kExtThreads), lds, s, p, e->B);
-  HIP_TRY(hipGetLastError());
   e->next_noise = nullptr;
   e->next_noise_max_ext = 0;
   return pack_from_master(e, 0, e->B, s, true);
@@ -328,6 +350,7 @@ int aog_create(const aog_config* cfg, int device, aog_env** out) {
     const size_t N2 = (size_t)cfg->n_pupil * cfg->n_pupil;
     TRY_ALLOC(dev_alloc(e, &e->psi_master, (size_t)e->B * N2));
     TRY_ALLOC(dev_alloc(e, &e->origin, (size_t)e->B * 2));
+    TRY_ALLOC(dev_alloc(e, &e->origin_alt, (size_t)e->B * 2));
     TRY_ALLOC(dev_alloc(e, &e->ext_counter, (size_t)e->B));
     TRY_ALLOC(dev_alloc(e, &e->velocity, (size_t)e->B * 2));
     TRY_ALLOC(dev_alloc(e, &e->psi_offset, (size_t)e->B));
@@ -473,6 +496,12 @@ int aog_upload_layer(aog_env* e, const aog_layer_tables* t) {
     if (t->stencil_vertical[k] < 0 || t->stencil_vertical[k] >= N * N) return fail(AOG_ERR_INVALID, "aog_upload_layer: stencil index out of range");
   for (int k = 0; k < t->nz_horizontal; ++k)
     if (t->stencil_horizontal[k] < 0 || t->stencil_horizontal[k] >= N * N) return fail(AOG_ERR_INVALID, "aog_upload_layer: stencil index out of range");
+  // the lock-step round kernel overwrites the row / column that drops out while other workgroups still gather stencil
+  // samples: only legal if no stencil sample lies in the last logical row (vertical) / column (horizontal)
+  bool safe = true;
+  for (int k = 0; k < t->nz_vertical; ++k) safe &= t->stencil_vertical[k] / N != N - 1;
+  for (int k = 0; k < t->nz_horizontal; ++k) safe &= t->stencil_horizontal[k] % N != N - 1;
+  e->rounds_ok = safe;
   HIP_TRY(hipSetDevice(e->device));
   e->nz_v = t->nz_vertical;
   e->nz_h = t->nz_horizontal;
@@ -501,8 +530,9 @@ int aog_upload_layer(aog_env* e, const aog_layer_tables* t) {
   return AOG_OK;
 }
 
-int aog_set_wind(aog_env* e, const double* velocity_dev, void* stream) {
-  if (!e || !velocity_dev) return fail(AOG_ERR_INVALID, "aog_set_wind: null argument");
+int aog_set_wind(aog_env* e, const double* velocity_dev, double max_abs_component, void* stream) {
+  if (!e || !velocity_dev || !(max_abs_component >= 0)) return fail(AOG_ERR_INVALID, "aog_set_wind: bad argument");
+  e->max_wind = max_abs_component;
   if (!e->cfg.atm_dynamic) return fail(AOG_ERR_STATE, "aog_set_wind: handle was not created with atm_dynamic = 1");
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipMemcpyAsync(e->velocity, velocity_dev, sizeof(double) * 2 * e->B, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));

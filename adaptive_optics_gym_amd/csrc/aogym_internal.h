@@ -53,6 +53,9 @@ struct aog_env {
   // dynamic atmosphere (cfg.atm_dynamic)
   bool layer_ready = false;
   bool extrude_attr_set = false;
+  bool rounds_ok = false;        // stencils never sample the dropped row/column -> lock-step round kernel is race-free
+  int32_t* origin_alt = nullptr; // second origin buffer (rounds ping-pong)
+  double max_wind = 0;           // max |component| of any env's velocity (bounds the rounds per step)
   long long timestep = 0;        // AOEnv.timestep: monotone over episodes (AO_env.py:123)
   double* psi_master = nullptr;  // [B][N*N] float64 toroidal screens
   int32_t* origin = nullptr;     // [B][2]

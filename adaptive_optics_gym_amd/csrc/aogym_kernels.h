@@ -966,6 +966,157 @@ __global__ __launch_bounds__(512) void k_extrude(ExtrudeArgs p, int B) {
   }
 }
 
+// ---- lock-step rounds: one launch = the r-th x (phase 0) or y (phase 1) extrusion of EVERY env --------------------------
+// out[row][env] = sum_k At[k][row] z_env[k] + sqrt(Cn^2) sum_j Bt[j][row] n_env[j]  is a [N x (nz+N)] x [(nz+N) x B] float64 matrix
+// product per round, so the AR matrices are streamed once per 32-env tile instead of once per env.  A workgroup owns a
+// 32-row x 32-env tile (256 threads, 2 x 2 outputs each), gathers its z / noise chunks straight from the ring buffers and
+// writes its part of the new slice in place.  That is race-free across workgroups because the slot being overwritten (the
+// row / column that drops out) is never a stencil sample; the host checks that property of the stencil and otherwise uses
+// k_extrude above.  Origins are double-buffered (read origin_in, write origin_out).
+struct ExtrudeRoundArgs {
+  ExtrudeArgs a;
+  const int32_t* origin_in;
+  int32_t* origin_out;
+  int B, phase, round;
+};
+
+#ifdef AOG_MAIN_TU
+__global__ __launch_bounds__(256) void k_extrude_round(ExtrudeRoundArgs q) {
+  constexpr int KC = 32;
+  __shared__ double Ws[KC][32];
+  __shared__ double Zs[KC][34];
+  __shared__ int s_act[32], s_flip[32], s_ox[32], s_oy[32], s_ext[32];
+  const ExtrudeArgs& p = q.a;
+  const int N = p.N;
+  const int row0 = blockIdx.x * 32, env0 = blockIdx.y * 32;
+  const bool horizontal = q.phase == 0;
+  if (threadIdx.x < 32) {
+    const int env = env0 + threadIdx.x;
+    int act = 0, flip = 0, ox = 0, oy = 0, ext = 0;
+    if (env < q.B) {
+      const double vx = p.velocity[2 * env], vy = p.velocity[2 * env + 1];
+      const int dx = (int)rint(vx * p.t_new / p.pitch) - (int)rint(vx * p.t_prev / p.pitch);
+      const int dy = (int)rint(vy * p.t_new / p.pitch) - (int)rint(vy * p.t_prev / p.pitch);
+      const int d = horizontal ? dx : dy;
+      act = q.round < abs(d);
+      flip = d > 0;
+      ox = q.origin_in[2 * env];
+      oy = q.origin_in[2 * env + 1];
+      ext = (horizontal ? 0 : abs(dx)) + q.round;
+    }
+    s_act[threadIdx.x] = act; s_flip[threadIdx.x] = flip; s_ox[threadIdx.x] = ox; s_oy[threadIdx.x] = oy; s_ext[threadIdx.x] = ext;
+  }
+  __syncthreads();
+  // new origins (every workgroup needs them for the write-back; row block 0 publishes them)
+  auto new_origin = [&](int e, int& nox, int& noy) {
+    nox = s_ox[e]; noy = s_oy[e];
+    if (!s_act[e]) return;
+    if (horizontal) nox = s_flip[e] ? (nox + 1 == N ? 0 : nox + 1) : (nox == 0 ? N - 1 : nox - 1);
+    else noy = s_flip[e] ? (noy + 1 == N ? 0 : noy + 1) : (noy == 0 ? N - 1 : noy - 1);
+  };
+  if (blockIdx.x == 0 && threadIdx.x < 32 && env0 + threadIdx.x < q.B) {
+    int nox, noy;
+    new_origin(threadIdx.x, nox, noy);
+    q.origin_out[2 * (env0 + threadIdx.x)] = nox;
+    q.origin_out[2 * (env0 + threadIdx.x) + 1] = noy;
+  }
+  bool any = false;
+  for (int e = 0; e < 32; ++e) any |= s_act[e] != 0;
+  if (!any) return;
+
+  const int nz = horizontal ? p.nz_h : p.nz_v;
+  const int32_t* st = horizontal ? p.stencil_h : p.stencil_v;
+  const double* At = horizontal ? p.At_h : p.At_v;
+  const double* Bt = horizontal ? p.Bt_h : p.Bt_v;
+  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;   // rows 2ty, 2ty+1; envs 2tx, 2tx+1
+  const int ge = threadIdx.x >> 3, gk = (threadIdx.x & 7) * 4;  // gather role: env ge, 4 consecutive k
+  double a00 = 0, a01 = 0, a10 = 0, a11 = 0, b00 = 0, b01 = 0, b10 = 0, b11 = 0;
+  for (int part = 0; part < 2; ++part) {
+    const int K = part == 0 ? nz : N;
+    const double* Wt = part == 0 ? At : Bt;
+    for (int k0 = 0; k0 < K; k0 += KC) {
+      // W chunk: KC x 32 rows (4 elements per thread, 256-B coalesced segments)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = threadIdx.x + 256 * u, kk = idx >> 5, i = idx & 31;
+        Ws[kk][i] = (k0 + kk < K && row0 + i < N) ? Wt[(size_t)(k0 + kk) * N + row0 + i] : 0.0;
+      }
+      // z / noise chunk of the 32 envs
+      {
+        const int env = env0 + ge;
+        const bool on = s_act[ge] != 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int k = k0 + gk + u;
+          double v = 0.0;
+          if (on && k < K) {
+            if (part == 0) {
+              int sy = st[k] / N, sx = st[k] - sy * N;
+              if (s_flip[ge]) { sy = N - 1 - sy; sx = N - 1 - sx; }
+              int py = sy + s_oy[ge], px = sx + s_ox[ge];
+              if (py >= N) py -= N;
+              if (px >= N) px -= N;
+              v = p.master[(size_t)env * N * N + (size_t)py * N + px];
+            } else {
+              const int e = s_ext[ge];
+              v = (p.noise && e < p.max_ext) ? p.noise[((size_t)env * p.max_ext + e) * N + k]
+                                             : philox_normal(p.seed, (uint32_t)env, p.ext_counter[env] + (uint32_t)e, (uint32_t)k);
+            }
+          }
+          Zs[gk + u][ge] = v;
+        }
+      }
+      __syncthreads();
+      if (part == 0) {
+#pragma unroll 8
+        for (int kk = 0; kk < KC; ++kk) {
+          const double w0 = Ws[kk][2 * ty], w1 = Ws[kk][2 * ty + 1], z0 = Zs[kk][2 * tx], z1 = Zs[kk][2 * tx + 1];
+          a00 = fma(w0, z0, a00); a01 = fma(w0, z1, a01); a10 = fma(w1, z0, a10); a11 = fma(w1, z1, a11);
+        }
+      } else {
+#pragma unroll 8
+        for (int kk = 0; kk < KC; ++kk) {
+          const double w0 = Ws[kk][2 * ty], w1 = Ws[kk][2 * ty + 1], z0 = Zs[kk][2 * tx], z1 = Zs[kk][2 * tx + 1];
+          b00 = fma(w0, z0, b00); b01 = fma(w0, z1, b01); b10 = fma(w1, z0, b10); b11 = fma(w1, z1, b11);
+        }
+      }
+      __syncthreads();
+    }
+  }
+  const double outv[2][2] = {{a00 + b00 * p.sqrt_cn2, a01 + b01 * p.sqrt_cn2}, {a10 + b10 * p.sqrt_cn2, a11 + b11 * p.sqrt_cn2}};
+#pragma unroll
+  for (int ee = 0; ee < 2; ++ee) {
+    const int e = 2 * tx + ee;
+    if (!s_act[e]) continue;
+    int nox, noy;
+    new_origin(e, nox, noy);
+    const bool flipped = s_flip[e] != 0;
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int i = row0 + 2 * ty + rr;
+      if (i >= N) continue;
+      int ly, lx;
+      if (horizontal) { ly = flipped ? N - 1 - i : i; lx = flipped ? N - 1 : 0; }
+      else { ly = flipped ? N - 1 : 0; lx = flipped ? N - 1 - i : i; }
+      int py = ly + noy, px = lx + nox;
+      if (py >= N) py -= N;
+      if (px >= N) px -= N;
+      p.master[(size_t)(env0 + e) * N * N + (size_t)py * N + px] = outv[rr][ee];
+    }
+  }
+}
+
+// after the rounds of a step: advance every env's RNG stream position by its extrusion count
+__global__ void k_extrude_finish(ExtrudeArgs p, int B) {
+  const int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= B) return;
+  const double vx = p.velocity[2 * env], vy = p.velocity[2 * env + 1];
+  const int dx = (int)rint(vx * p.t_new / p.pitch) - (int)rint(vx * p.t_prev / p.pitch);
+  const int dy = (int)rint(vy * p.t_new / p.pitch) - (int)rint(vy * p.t_prev / p.pitch);
+  p.ext_counter[env] += (uint32_t)(abs(dx) + abs(dy));
+}
+#endif  // AOG_MAIN_TU
+
 // caller screens -> float64 master (origin 0)
 template <typename T>
 __global__ void k_store_master(const T* __restrict__ psi, double* __restrict__ master, int32_t* __restrict__ origin,

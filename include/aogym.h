@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define AOG_ABI_VERSION 5
+#define AOG_ABI_VERSION 6
 
 typedef struct aog_env aog_env;
 
@@ -136,8 +136,9 @@ typedef struct {
 } aog_layer_tables;
 int aog_upload_layer(aog_env* env, const aog_layer_tables* layer);
 
-/* layer.velocity of every env: [B][2] float64 (vx, vy) in m/s (hcipy draws the direction at construction). */
-int aog_set_wind(aog_env* env, const double* velocity_dev, void* stream);
+/* layer.velocity of every env: [B][2] float64 (vx, vy) in m/s (hcipy draws the direction at construction).
+ * max_abs_component >= max over envs of max(|vx|, |vy|): bounds the whole-pixel shifts per step. */
+int aog_set_wind(aog_env* env, const double* velocity_dev, double max_abs_component, void* stream);
 
 /* Standard normals for the extrusions of the NEXT aog_step: [B][max_ext][N] float64, consumed in hcipy's order (x shifts
  * first, then y).  NULL (default) = on-device Philox4x32-10 stream seeded by aog_set_rng_seed. */

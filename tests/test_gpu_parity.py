@@ -447,3 +447,31 @@ def test_focal_image_matches_literal_propagation(precision):
         coef = (env.tables.lp_modes * F[None]).sum(axis=(1, 2)) * env.tables.focal_pixel_area
         np.testing.assert_allclose(np.sum(np.abs(coef) ** 2), float(info["power"][b]), rtol=2e-5)
     env.close()
+
+
+def test_dynamic_round_kernel_equals_per_env_kernel(monkeypatch):
+    """The lock-step round extrusion (32 envs share every AR-matrix row, one launch per round) gives the same screens as
+    the per-env-group kernel on the same Philox stream (only the float64 summation order differs)."""
+    torch = _torch()
+    from adaptive_optics_gym_amd import BatchedAOEnv
+
+    def run(simple):
+        if simple:
+            monkeypatch.setenv("AOG_EXTRUDE_SIMPLE", "1")
+        else:
+            monkeypatch.delenv("AOG_EXTRUDE_SIMPLE", raising=False)
+        env = BatchedAOEnv(70, "cuda:0", atm_type="dynamic", atm_vel=35, atm_fried=0.15, act_dim=6, act_type="zernike", obs_dim=2,
+                           num_pupil_pixels=32, timesteps_per_episode=100, seed=11, screen_oversampling=4, verbose=False)
+        env.reset()
+        a = torch.ones(70, 6, device="cuda")
+        obs = None
+        for _ in range(7):
+            obs = env.step(a)[4]["obs_raw"]
+        out = env.get_screens().cpu().numpy(), obs.cpu().numpy()
+        env.close()
+        return out
+
+    s_simple, o_simple = run(True)
+    s_round, o_round = run(False)
+    np.testing.assert_allclose(s_round, s_simple, rtol=1e-9, atol=1e-12 * np.abs(s_simple).max())
+    _assert_obs_close(o_round, o_simple)

@@ -165,3 +165,4 @@ def test_layer_tables_match_oracle_layer():
     v = np.array([[3.0, -4.0], [0.2, 0.0]])
     s = atmosphere_host.integer_shifts(v, 0.004, 0.005, D / n)
     assert s.tolist() == [[(round(3 * 0.005 / (D / n)) - round(3 * 0.004 / (D / n))), (round(-4 * 0.005 / (D / n)) - round(-4 * 0.004 / (D / n)))], [0, 0]]
+
