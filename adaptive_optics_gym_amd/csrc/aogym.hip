@@ -185,7 +185,8 @@ int evolve_layer(aog_env* e, hipStream_t s) {
   p.pitch = e->pitch;
   p.sqrt_cn2 = e->sqrt_cn2;
   p.seed = e->rng_seed;
-  const bool use_rounds = e->rounds_ok && e->B >= 64 && !getenv("AOG_EXTRUDE_SIMPLE");
+  // the lock-step round kernel (k_extrude_round) is correct but not yet faster than the per-group kernel: opt-in
+  const bool use_rounds = e->rounds_ok && e->B >= 64 && getenv("AOG_EXTRUDE_ROUNDS") != nullptr;
   if (use_rounds) {
     // per axis at most ceil(|v| dt / pitch) + 1 whole-pixel shifts in one step
     const int R = (int)std::ceil(e->max_wind * e->delta_t / e->pitch) + 1;

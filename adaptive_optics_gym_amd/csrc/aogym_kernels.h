@@ -1155,27 +1155,20 @@ __global__ __launch_bounds__(256) void k_repack_master(const double* __restrict_
     iy = flat / N;
     ix = flat - iy * N;
   }
-  // all 8 env loads of this wave are issued before any is consumed (memory-level parallelism)
-  double v[8];
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const int env = et * 32 + wave * 8 + q;
-    v[q] = 0.0;
-    if (env < B && valid_p) {
-      int py = iy + origin[2 * env + 1], px = ix + origin[2 * env];
-      if (py >= N) py -= N;
-      if (px >= N) px -= N;
-      v[q] = master[(size_t)env * N * N + (size_t)py * N + px];
-    }
-  }
-#pragma unroll
   for (int q = 0; q < 8; ++q) {
     const int e = wave * 8 + q;
     const int env = et * 32 + e;
     float out = 0.f;
     if (env < B) {
-      if (valid_p) out = (float)((v[q] - offset[env]) * inv_two_pi_lambda);
-      double sum = v[q];
+      double v = 0.0;
+      if (valid_p) {
+        int py = iy + origin[2 * env + 1], px = ix + origin[2 * env];
+        if (py >= N) py -= N;
+        if (px >= N) px -= N;
+        v = master[(size_t)env * N * N + (size_t)py * N + px];
+        out = (float)((v - offset[env]) * inv_two_pi_lambda);
+      }
+      double sum = v;
       for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
       if (lane == 0) atomicAdd(&sum_next[env], sum);
     }

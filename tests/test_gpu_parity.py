@@ -457,9 +457,9 @@ def test_dynamic_round_kernel_equals_per_env_kernel(monkeypatch):
 
     def run(simple):
         if simple:
-            monkeypatch.setenv("AOG_EXTRUDE_SIMPLE", "1")
+            monkeypatch.delenv("AOG_EXTRUDE_ROUNDS", raising=False)
         else:
-            monkeypatch.delenv("AOG_EXTRUDE_SIMPLE", raising=False)
+            monkeypatch.setenv("AOG_EXTRUDE_ROUNDS", "1")
         env = BatchedAOEnv(70, "cuda:0", atm_type="dynamic", atm_vel=35, atm_fried=0.15, act_dim=6, act_type="zernike", obs_dim=2,
                            num_pupil_pixels=32, timesteps_per_episode=100, seed=11, screen_oversampling=4, verbose=False)
         env.reset()
