@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libaogym.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 AOG_REWARD = {"strehl_ratio": 0, "smf_ssim": 1}
 AOG_PRECISION = {"fast": 0, "fp64": 1}
@@ -59,6 +59,7 @@ SYMBOLS = {
     "aog_set_extrusion_noise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "aog_set_rng_seed": (C.c_int, [C.c_void_p, C.c_uint64]),
     "aog_get_screens_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "aog_generate_screens": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p]),
     "aog_get_actuators": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "aog_set_actuators": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "aog_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -81,6 +82,10 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} is missing: the HIP extension has not been built. Run `python -c 'import __graft_entry__ as g; "
             "g.build()'` (or adaptive_optics_gym_amd/build.py) — there is no CPU fallback for the device path.")
+    try:  # let torch's bundled ROCm libraries (HIP runtime, hipFFT/rocFFT; same SONAMEs) win if torch is going to be used
+        import torch  # noqa: F401
+    except Exception:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)

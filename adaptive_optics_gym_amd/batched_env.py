@@ -30,7 +30,8 @@ class BatchedAOEnv:
     device              torch device (default ``cuda:0``)
     num_pupil_pixels    pupil grid side N (reference: 240)
     seed                seed of the screen generator (env e uses seed + e for ``screen_source='numpy'``)
-    screen_source       'torch' (batched rocFFT synthesis on the GPU) | 'numpy' (hcipy draw order, float64, host)
+    screen_source       'device' (default: hipFFT synthesis inside libaogym, Philox normals) | 'torch' (same algorithm through
+                        torch.fft) | 'numpy' (hcipy's draw order on a numpy legacy stream, float64, host)
     screens             optional [B, N, N] achromatic screens to use instead of generating them
     precision           'fast' (fp32 data, float64 accumulators) | 'fp64' (validation kernel)
     kernel              'auto' | 'mfma' | 'valu'
@@ -39,7 +40,7 @@ class BatchedAOEnv:
     def __init__(self, num_envs=1, device=None, atm_type="quasi_static", atm_vel=0, atm_fried=0.15,
                  act_type="num_actuators", act_dim=64, obs_dim=2, rew_type="strehl_ratio", rew_threshold=None,
                  timesteps_per_episode=20, flat_mirror_start_per_episode=True, SH_operation=False, *,
-                 num_pupil_pixels=240, seed=None, screen_source="torch", screen_oversampling=16, screens=None,
+                 num_pupil_pixels=240, seed=None, screen_source="device", screen_oversampling=16, screens=None,
                  precision="fast", kernel="auto", pixel_chunks=0, rng=None, verbose=True, params=None):
         import torch
 
@@ -195,6 +196,16 @@ class BatchedAOEnv:
                 psi = screen_numpy(p.num_pupil_pixels, p.pupil_pixel, self.Cn_squared, p.outer_scale, self._env_rng(e),
                                    self.screen_oversampling)
                 self.set_screens(psi[None], first=e)
+        elif self.screen_source == "device":
+            _lib.check(self.lib.aog_set_rng_seed(self._handle, C.c_uint64(1234 if self.seed is None else int(self.seed))))
+            args = (int(self.screen_oversampling), float(self.Cn_squared), float(p.outer_scale), float(p.pupil_pixel), self._stream())
+            if mask is None:
+                _lib.check(self.lib.aog_generate_screens(self._handle, 0, self.num_envs, *args))
+            else:
+                idx = np.flatnonzero(np.asarray(mask.cpu() if hasattr(mask, "cpu") else mask))
+                runs = np.split(idx, np.flatnonzero(np.diff(idx) != 1) + 1) if idx.size else []
+                for r in runs:
+                    _lib.check(self.lib.aog_generate_screens(self._handle, int(r[0]), int(r.size), *args))
         else:
             if not hasattr(self, "_gen"):
                 self._gen = torch.Generator(device=self.device)

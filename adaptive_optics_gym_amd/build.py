@@ -54,7 +54,7 @@ def build(force: bool = False, verbose: bool = True, fast: bool = False) -> str:
     with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
         list(ex.map(run, jobs))
     objs = [os.path.join(OBJ, "aogym.o")] + [os.path.join(OBJ, f"fused_apad{a}.o") for a in APADS]
-    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs])
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs, "-lhipfft"])
     return OUT
 
 

@@ -4,6 +4,8 @@
 #include "aogym_internal.h"
 #include "aogym_kernels.h"
 
+#include <hipfft/hipfft.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -379,6 +381,7 @@ void aog_destroy(aog_env* e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
   for (void* p : e->allocs) (void)hipFree(p);
+  if (e->fft_plan) hipfftDestroy((hipfftHandle)(uintptr_t)e->fft_plan);
   for (auto& ev : e->events) {
     (void)hipEventDestroy(ev.first);
     (void)hipEventDestroy(ev.second);
@@ -563,6 +566,65 @@ int aog_get_screens_f64(aog_env* e, double* psi_dev, void* stream) {
   hipLaunchKernelGGL(aog::k_unroll_master, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      e->psi_master, e->origin, psi_dev, e->B, e->cfg.n_pupil);
   HIP_TRY(hipGetLastError());
+  return AOG_OK;
+}
+
+int aog_generate_screens(aog_env* e, int first, int count, int oversampling, double cn_squared, double outer_scale, double pixel_pitch,
+                         void* stream) {
+  if (!e) return fail(AOG_ERR_INVALID, "aog_generate_screens: null handle");
+  if (!e->tables_ready) return fail(AOG_ERR_STATE, "aog_generate_screens before aog_upload_tables");
+  if (first < 0 || count < 0 || first + count > e->B) return fail(AOG_ERR_INVALID, "aog_generate_screens: env range outside [0,%d)", e->B);
+  if (oversampling < 1 || oversampling > 32 || !(cn_squared > 0) || !(outer_scale > 0) || !(pixel_pitch > 0))
+    return fail(AOG_ERR_INVALID, "aog_generate_screens: bad parameter");
+  if (count == 0) return AOG_OK;
+  HIP_TRY(hipSetDevice(e->device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int N = e->cfg.n_pupil, m = N * oversampling;
+  if ((m & 1) != 0) return fail(AOG_ERR_UNSUPPORTED, "aog_generate_screens: odd FFT size");
+  if (e->fft_m != m) {
+    if (e->fft_plan) {
+      hipfftDestroy((hipfftHandle)(uintptr_t)e->fft_plan);
+      e->fft_plan = nullptr;
+    }
+    // batch so that the complex64 work buffer stays under ~2 GiB
+    const size_t per = (size_t)m * m * 8;
+    int batch = (int)std::max<size_t>(1, std::min<size_t>((size_t)e->B, ((size_t)2 << 30) / per));
+    int rc;
+    if ((rc = dev_alloc(e, &e->fft_work, (size_t)batch * m * m * 2, false)) != AOG_OK) return rc;
+    if ((rc = dev_alloc(e, &e->fft_crop, (size_t)batch * N * N, false)) != AOG_OK) return rc;
+    hipfftHandle plan;
+    int dims[2] = {m, m};
+    if (hipfftPlanMany(&plan, 2, dims, nullptr, 1, m * m, nullptr, 1, m * m, HIPFFT_C2C, batch) != HIPFFT_SUCCESS)
+      return fail(AOG_ERR_HIP, "hipfftPlanMany(%d x %d, batch %d) failed", m, m, batch);
+    e->fft_plan = (void*)(uintptr_t)plan;
+    e->fft_m = m;
+    e->fft_batch = batch;
+  }
+  hipfftHandle plan = (hipfftHandle)(uintptr_t)e->fft_plan;
+  if (hipfftSetStream(plan, s) != HIPFFT_SUCCESS) return fail(AOG_ERR_HIP, "hipfftSetStream failed");
+  const double du = 2.0 * M_PI / ((double)m * pixel_pitch);
+  const double u0 = 2.0 * M_PI / outer_scale;
+  const double r0 = std::pow(0.423 * 4.0 * M_PI * M_PI, -3.0 / 5.0);  // Fried parameter for Cn^2 = 1 at 1 m
+  // a = sqrt(0.0229 r0^(-5/3)) (2 pi)^(11/6) (f^2 + u0^2)^(-11/12) (2 pi) / du
+  const double amp_scale = std::sqrt(0.0229 * std::pow(r0, -5.0 / 3.0)) * std::pow(2.0 * M_PI, 11.0 / 6.0) * (2.0 * M_PI) / du;
+  const float crop_scale = (float)(std::sqrt(cn_squared) / ((double)m * m * pixel_pitch * pixel_pitch));
+  e->screen_generation += 1;
+  for (int done = 0; done < count; done += e->fft_batch) {
+    const int nb = std::min(e->fft_batch, count - done);
+    const size_t pairs = (size_t)m * m / 2;
+    hipLaunchKernelGGL(aog::k_spectrum_fill, dim3((unsigned)((pairs + 255) / 256), nb), dim3(256), 0, s, reinterpret_cast<float2*>(e->fft_work), m,
+                       first + done, e->rng_seed, e->screen_generation, du, u0 * u0, amp_scale);
+    HIP_TRY(hipGetLastError());
+    // the plan is batched for fft_batch transforms; surplus slots of a short last chunk hold stale (finite) data and are ignored
+    if (hipfftExecC2C(plan, reinterpret_cast<hipfftComplex*>(e->fft_work), reinterpret_cast<hipfftComplex*>(e->fft_work), HIPFFT_BACKWARD) !=
+        HIPFFT_SUCCESS)
+      return fail(AOG_ERR_HIP, "hipfftExecC2C failed");
+    hipLaunchKernelGGL(aog::k_screen_crop, dim3((N * N + 255) / 256, nb), dim3(256), 0, s, reinterpret_cast<const float2*>(e->fft_work), e->fft_crop, m,
+                       N, crop_scale);
+    HIP_TRY(hipGetLastError());
+    int rc = set_screens<float>(e, e->fft_crop, first + done, nb, s);
+    if (rc != AOG_OK) return rc;
+  }
   return AOG_OK;
 }
 

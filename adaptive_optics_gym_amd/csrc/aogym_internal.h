@@ -36,6 +36,12 @@ struct aog_env {
   double* sci_coef = nullptr;    // [MRS_used][2]
   double* modes64 = nullptr;     // validation: [n_ap][A]
   double* tabs64 = nullptr;      // validation: [n_ap][MRW_used+MRS_used]
+  // device screen synthesis (K8)
+  void* fft_plan = nullptr;      // hipfftHandle
+  int fft_m = 0, fft_batch = 0;
+  float* fft_work = nullptr;     // [fft_batch][m][m] complex64
+  float* fft_crop = nullptr;     // [fft_batch][N][N]
+  uint32_t screen_generation = 0;
   // focal-image export (optional)
   int n_focal = 0;
   double* focal_m1 = nullptr;    // [n_focal][N] complex

@@ -1254,6 +1254,57 @@ __global__ void k_cgemm_small(const double2* __restrict__ a, const double2* __re
 }
 #endif  // AOG_MAIN_TU
 
+// ------------------------------------------------------------------------------------------------
+// K8  screen synthesis (hcipy FiniteAtmosphericLayer / SpectralNoiseFactoryFFT; layer.reset(), AO_env.py:77)
+//   spectrum[b][v][u] = a(u, v) (g1 + i g2),  a = sqrt(PSD_vK (2 pi)^2 / du^2)  on the UNSHIFTED (q N)^2 FFT grid,
+//   then an un-normalised inverse FFT (hipFFT) and k_screen_crop takes Re of the centred N x N crop / (M delta^2) * sqrt(Cn^2).
+// ------------------------------------------------------------------------------------------------
+#ifdef AOG_MAIN_TU
+__global__ void k_spectrum_fill(float2* __restrict__ spec, int m, int first_env, unsigned long long seed, uint32_t generation, double du,
+                                double u0sq, double amp_scale) {
+  // one thread = two adjacent complex samples (one Philox call = 4 words = 2 Box-Muller pairs)
+  const size_t pair = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t per_env = (size_t)m * m / 2;
+  const int b = blockIdx.y;
+  if (pair >= per_env) return;
+  uint32_t c[4] = {(uint32_t)pair, (uint32_t)(pair >> 32) ^ (generation * 0x9E3779B9u), (uint32_t)(first_env + b), 0x5C4EE7u};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  float2 out[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const size_t idx = 2 * pair + h;
+    const int v = (int)(idx / m), u = (int)(idx - (size_t)v * m);
+    const double fu = du * (double)(u < m / 2 ? u : u - m), fv = du * (double)(v < m / 2 ? v : v - m);
+    const double f2 = fu * fu + fv * fv;
+    // 0.0229 r0^(-5/3) ((f^2 + u0^2)/(2 pi)^2)^(-11/6) (2 pi)^2 / du^2, zero at the origin; amp_scale holds the constants
+    const float a = f2 < 1e-18 ? 0.f : (float)(amp_scale * pow(f2 + u0sq, -11.0 / 12.0));
+    const float u1 = ((float)c[2 * h] + 0.5f) * (1.0f / 4294967296.0f);
+    const float u2 = ((float)c[2 * h + 1] + 0.5f) * (1.0f / 4294967296.0f);
+    const float r = a * sqrtf(-2.0f * __logf(u1));
+    float sn, cs;
+    __sincosf(6.2831853071795865f * u2, &sn, &cs);
+    out[h] = make_float2(r * cs, r * sn);
+  }
+  reinterpret_cast<float4*>(spec + (size_t)b * m * m)[pair] = make_float4(out[0].x, out[0].y, out[1].x, out[1].y);
+}
+
+__global__ void k_screen_crop(const float2* __restrict__ field, float* __restrict__ out, int m, int N, float scale) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  if (idx >= N * N) return;
+  const int iy = idx / N, ix = idx - iy * N;
+  // centred crop index i in [m/2 - N/2, m/2 + N/2) <-> unshifted (i - m/2) mod m
+  const int jy = (iy - N / 2 + m) % m, jx = (ix - N / 2 + m) % m;
+  out[(size_t)b * N * N + idx] = field[(size_t)b * m * m + (size_t)jy * m + jx].x * scale;
+}
+#endif  // AOG_MAIN_TU
+
 // self-test hook: the three sin/cos flavours of the fused kernels on caller-supplied revolutions
 #ifdef AOG_MAIN_TU
 __global__ void k_selftest_sincos(const float* __restrict__ u, float* __restrict__ s, float* __restrict__ c, int n, int flavour) {

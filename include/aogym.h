@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define AOG_ABI_VERSION 6
+#define AOG_ABI_VERSION 7
 
 typedef struct aog_env aog_env;
 
@@ -147,6 +147,13 @@ int aog_set_rng_seed(aog_env* env, uint64_t seed);
 
 /* layer._achromatic_screen of every env as plain [B][N][N] float64 (dynamic atmosphere only). */
 int aog_get_screens_f64(aog_env* env, double* psi_dev, void* stream);
+
+/* layer.reset() / layer construction (AO_env.py:77, :370): synthesise new von Karman screens for envs [first, first+count) ON THE
+ * DEVICE and install them — hcipy's FiniteAtmosphericLayer + SpectralNoiseFactoryFFT: complex normals on the (oversampling N)^2
+ * FFT grid times sqrt(PSD (2 pi)^2 / du^2), inverse FFT (hipFFT/rocFFT), real part of the central N x N crop / delta^2 * sqrt(Cn^2).
+ * Normals come from the handle's Philox stream (aog_set_rng_seed); statistically equivalent to hcipy, not draw-for-draw. */
+int aog_generate_screens(aog_env* env, int first, int count, int oversampling, double cn_squared, double outer_scale,
+                         double pixel_pitch, void* stream);
 
 /* deformable_mirror.actuators for all envs (metres; AO_env.py:116).  [B][A] float64 device pointers. */
 int aog_get_actuators(aog_env* env, double* act_dev, void* stream);

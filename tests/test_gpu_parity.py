@@ -475,3 +475,40 @@ def test_dynamic_round_kernel_equals_per_env_kernel(monkeypatch):
     s_round, o_round = run(False)
     np.testing.assert_allclose(s_round, s_simple, rtol=1e-9, atol=1e-12 * np.abs(s_simple).max())
     _assert_obs_close(o_round, o_simple)
+
+
+def test_device_screen_synthesis_statistics():
+    """K8 inside the library (hipFFT + Philox): same variance / structure function as the literal numpy generator and as the
+    discrete integral of the von Karman PSD over the FFT grid; new screens on every call; masked regeneration."""
+    torch = _torch()
+    from adaptive_optics_gym_amd import BatchedAOEnv
+    from adaptive_optics_gym_amd.atmosphere_host import cn_squared_from_fried_parameter, screen_numpy, spectral_amplitude
+
+    B, N, q = 256, 32, 8
+    env = BatchedAOEnv(B, "cuda:0", atm_type="dynamic", atm_vel=1, atm_fried=0.2, act_dim=6, act_type="zernike", obs_dim=2,
+                       num_pupil_pixels=N, seed=5, screen_oversampling=q, screen_source="device", verbose=False)
+    dev = env.get_screens().cpu().numpy()
+    assert np.isfinite(dev).all()
+    cn2 = cn_squared_from_fried_parameter(0.2, 2.2e-6)
+    delta = 0.5 / N
+    m = N * q
+    var_expect = (spectral_amplitude(N, delta, 10.0, q) ** 2).sum() / (float(m) * m * delta ** 4) / (m * m) * cn2 * (m * m) / (m * m)
+    # Var = sum a^2 / (M^2 delta^4) * Cn^2  (see atmosphere_host.screen_numpy)
+    var_expect = (spectral_amplitude(N, delta, 10.0, q) ** 2).sum() / (float(m) ** 4 * delta ** 4) * cn2
+    np.testing.assert_allclose(dev.var(), var_expect, rtol=0.15)
+    rng = np.random.RandomState(0)
+    lit = np.stack([screen_numpy(N, delta, cn2, 10.0, rng, q) for _ in range(200)])
+    d_dev = np.mean((dev[:, :, 2:] - dev[:, :, :-2]) ** 2)
+    d_lit = np.mean((lit[:, :, 2:] - lit[:, :, :-2]) ** 2)
+    np.testing.assert_allclose(d_dev, d_lit, rtol=0.1)
+    d_dev_y = np.mean((dev[:, 5:, :] - dev[:, :-5, :]) ** 2)
+    d_lit_y = np.mean((lit[:, 5:, :] - lit[:, :-5, :]) ** 2)
+    np.testing.assert_allclose(d_dev_y, d_lit_y, rtol=0.1)
+    assert abs(np.corrcoef(dev[0].ravel(), dev[1].ravel())[0, 1]) < 0.9 and not np.array_equal(dev[0], dev[1])
+    # masked regeneration: only the selected envs change
+    mask = np.zeros(B, dtype=bool); mask[[3, 4, 5, 200]] = True
+    env._generate_screens(mask=torch.from_numpy(mask))
+    new = env.get_screens().cpu().numpy()
+    changed = np.array([not np.array_equal(new[b], dev[b]) for b in range(B)])
+    assert np.array_equal(changed, mask)
+    env.close()
