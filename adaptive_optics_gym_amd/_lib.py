@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libaogym.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 AOG_REWARD = {"strehl_ratio": 0, "smf_ssim": 1}
 AOG_PRECISION = {"fast": 0, "fp64": 1}
@@ -38,6 +38,12 @@ class AogLayerTables(C.Structure):
                 ("sqrt_cn_squared", C.c_double), ("pixel_pitch", C.c_double), ("delta_t", C.c_double)]
 
 
+class AogShTables(C.Structure):
+    _fields_ = [("n_sub", C.c_int32), ("sub_slot", C.POINTER(C.c_int32))] + [(n, C.POINTER(C.c_double)) for n in (
+        "centres", "slopes_ref", "reconstruction", "mla_phase", "transfer", "x_det")] + [(n, C.c_double) for n in (
+        "field_amplitude", "image_scale", "gain", "leakage")]
+
+
 class AogInfo(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "abi_version", "num_envs", "num_envs_padded", "n_ap", "n_ap_padded", "n_modes_padded", "pixel_chunks",
@@ -60,6 +66,9 @@ SYMBOLS = {
     "aog_set_rng_seed": (C.c_int, [C.c_void_p, C.c_uint64]),
     "aog_get_screens_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "aog_generate_screens": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p]),
+    "aog_upload_sh": (C.c_int, [C.c_void_p, C.POINTER(AogShTables)]),
+    "aog_sh_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "aog_sh_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "aog_get_actuators": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "aog_set_actuators": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "aog_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -84,8 +84,6 @@ class BatchedAOEnv:
         self._episode_returns = None
         self._trunc = None
 
-        if self.SH_operation:
-            raise NotImplementedError("Shack-Hartmann operation (AO_env.py:254-290, 396-465) is not built yet")
 
         self.observation_space = make_box(-1, 1, (self.obs_dim ** 2,), np.float16)  # AO_env.py:45
         self.action_space = make_box(-1, 1, (self.num_modes,), np.float16)          # AO_env.py:46
@@ -170,6 +168,8 @@ class BatchedAOEnv:
             self.set_screens(screens)
         else:
             self._generate_screens(first_call=True)
+        if self.SH_operation:
+            self._upload_shack_hartmann()
 
     # ------------------------------------------------------------------------------------------------
     def _stream(self):
@@ -232,6 +232,51 @@ class BatchedAOEnv:
         _lib.check(self.lib.aog_set_wind(self._handle, C.c_void_p(v.data_ptr()), float(np.abs(self.velocity_vectors).max()), self._stream()))
         _lib.check(self.lib.aog_set_rng_seed(self._handle, C.c_uint64(1234 if self.seed is None else int(self.seed))))
         torch.cuda.current_stream(self.device).synchronize()
+
+    def _upload_shack_hartmann(self):
+        """shack_hartmann_init (AO_env.py:396-465): host calibration, then the tables of the device chain."""
+        from .sh_host import ShackHartmannHost
+
+        sh = ShackHartmannHost(self.params, self.tables)
+        self.sh = sh
+        c = np.ascontiguousarray
+        keep = dict(slot=c(sh.sub_slot, dtype=np.int32), cen=c(sh.centres, dtype=np.float64), ref=c(sh.slopes_ref, dtype=np.float64),
+                    rec=c(sh.reconstruction, dtype=np.float64),
+                    mla=c(np.stack([sh.mla_phase.real, sh.mla_phase.imag], axis=-1), dtype=np.float64),
+                    tf=c(np.stack([sh.transfer.real, sh.transfer.imag], axis=-1), dtype=np.float64), xd=c(sh.x_det, dtype=np.float64))
+        t = _lib.AogShTables(int(sh.n_sub), _dptr(keep["slot"], C.c_int32), _dptr(keep["cen"], C.c_double), _dptr(keep["ref"], C.c_double),
+                             _dptr(keep["rec"], C.c_double), _dptr(keep["mla"], C.c_double), _dptr(keep["tf"], C.c_double),
+                             _dptr(keep["xd"], C.c_double), float(sh.amp_wfs / sh.mag), float(sh.pitch ** 2 * self.params.delta_t), 0.3, 0.01)
+        _lib.check(self.lib.aog_upload_sh(self._handle, C.byref(t)))
+
+    def SH_step(self):
+        """AOEnv.SH_step (AO_env.py:254-290) for every env: returns (actions [B, A] float64 = deformable_mirror_shack.actuators,
+        torch.tensor([1])).  Photon noise comes from the handle's Philox stream, or — in host-RNG (parity) mode — from each env's
+        numpy stream through hcipy's large_poisson draw order."""
+        torch = self._torch
+        if not self.SH_operation:
+            raise RuntimeError("SH_step needs SH_operation=True (AO_env.py:67-68 only initialises the sensor then)")
+        B, N = self.num_envs, self.num_pupil_pixels
+        action = torch.empty((B, self.num_modes), dtype=torch.float64, device=self.device)
+        if self._host_rng:
+            img = torch.empty((B, N * N), dtype=torch.float64, device=self.device)
+            _lib.check(self.lib.aog_sh_image(self._handle, C.c_void_p(img.data_ptr()), self._stream()))
+            lam = img.cpu().numpy()
+            noisy = np.empty_like(lam)
+            for e in range(B):
+                r = self._env_rng(e)
+                large = lam[e] > 1e6
+                out = np.zeros(N * N)
+                out[large] = np.round(lam[e][large] + r.normal(size=int(large.sum())) * np.sqrt(lam[e][large]))
+                out[~large] = r.poisson(lam[e][~large], size=int((~large).sum()))
+                noisy[e] = out
+            nd = torch.from_numpy(noisy).to(self.device)
+            _lib.check(self.lib.aog_sh_update(self._handle, C.c_void_p(nd.data_ptr()), C.c_void_p(action.data_ptr()), self._stream()))
+            torch.cuda.current_stream(self.device).synchronize()
+        else:
+            _lib.check(self.lib.aog_sh_image(self._handle, None, self._stream()))
+            _lib.check(self.lib.aog_sh_update(self._handle, None, C.c_void_p(action.data_ptr()), self._stream()))
+        return action, torch.tensor([1])
 
     def _host_extrusion_noise(self):
         """Host-RNG (parity) mode: draw the normals of the coming step's extrusions from each env's numpy stream in hcipy's

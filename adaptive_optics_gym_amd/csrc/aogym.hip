@@ -155,7 +155,7 @@ int pack_from_master(aog_env* e, int first, int count, hipStream_t s, bool per_s
   }
   // the MFMA kernel only reads psi_tile, the VALU kernel only psi_rev: write the one that is used
   float* rev = e->kernel == AOG_KERNEL_VALU ? e->psi_rev : nullptr;
-  float* tile = e->kernel == AOG_KERNEL_MFMA ? e->psi_tile : nullptr;
+  float* tile = (e->kernel == AOG_KERNEL_MFMA || e->sh_ready) ? e->psi_tile : nullptr;
   hipLaunchKernelGGL((aog::k_pack_screens<double>), dim3(count), dim3(256), 0, s, e->psi_master + (size_t)first * N2, e->ap_index,
                      rev, tile, e->psi64, first, N2, e->n_ap, e->n_ap_pad, e->Bp, inv, (const int32_t*)e->origin,
                      e->cfg.n_pupil, e->psi_offset, e->psi_sum);
@@ -382,6 +382,7 @@ void aog_destroy(aog_env* e) {
   (void)hipSetDevice(e->device);
   for (void* p : e->allocs) (void)hipFree(p);
   if (e->fft_plan) hipfftDestroy((hipfftHandle)(uintptr_t)e->fft_plan);
+  if (e->sh_plan) hipfftDestroy((hipfftHandle)(uintptr_t)e->sh_plan);
   for (auto& ev : e->events) {
     (void)hipEventDestroy(ev.first);
     (void)hipEventDestroy(ev.second);
@@ -625,6 +626,108 @@ int aog_generate_screens(aog_env* e, int first, int count, int oversampling, dou
     int rc = set_screens<float>(e, e->fft_crop, first + done, nb, s);
     if (rc != AOG_OK) return rc;
   }
+  return AOG_OK;
+}
+
+int aog_upload_sh(aog_env* e, const aog_sh_tables* t) {
+  if (!e || !t) return fail(AOG_ERR_INVALID, "aog_upload_sh: null argument");
+  if (!e->tables_ready) return fail(AOG_ERR_STATE, "aog_upload_sh before aog_upload_tables");
+  if (e->cfg.precision != AOG_PRECISION_FAST) return fail(AOG_ERR_UNSUPPORTED, "aog_upload_sh: the Shack-Hartmann chain is built for the fast precision only");
+  if (e->sh_ready) return fail(AOG_ERR_STATE, "aog_upload_sh: already uploaded");
+  if (t->n_sub < 1 || !t->sub_slot || !t->centres || !t->slopes_ref || !t->reconstruction || !t->mla_phase || !t->transfer || !t->x_det)
+    return fail(AOG_ERR_INVALID, "aog_upload_sh: bad table");
+  const int N = e->cfg.n_pupil;
+  const size_t N2 = (size_t)N * N;
+  for (size_t i = 0; i < N2; ++i)
+    if (t->sub_slot[i] < -1 || t->sub_slot[i] >= t->n_sub) return fail(AOG_ERR_INVALID, "aog_upload_sh: sub_slot out of range");
+  HIP_TRY(hipSetDevice(e->device));
+  int rc;
+  auto up = [&](auto** dst, const auto* src, size_t count) -> int {
+    if ((rc = dev_alloc(e, dst, count, false)) != AOG_OK) return rc;
+    HIP_TRY(hipMemcpy(*dst, src, sizeof(**dst) * count, hipMemcpyHostToDevice));
+    return AOG_OK;
+  };
+  e->sh_n_sub = t->n_sub;
+  if ((rc = up(&e->sh_slot, t->sub_slot, N2)) != AOG_OK) return rc;
+  if ((rc = up(&e->sh_centres, t->centres, (size_t)t->n_sub * 2)) != AOG_OK) return rc;
+  if ((rc = up(&e->sh_ref, t->slopes_ref, (size_t)t->n_sub * 2)) != AOG_OK) return rc;
+  if ((rc = up(&e->sh_recon, t->reconstruction, (size_t)e->A * t->n_sub * 2)) != AOG_OK) return rc;
+  if ((rc = up(&e->sh_mla, t->mla_phase, N2 * 2)) != AOG_OK) return rc;
+  if ((rc = up(&e->sh_tf, t->transfer, N2 * 4 * 2)) != AOG_OK) return rc;
+  if ((rc = up(&e->sh_xdet, t->x_det, (size_t)N)) != AOG_OK) return rc;
+  if ((rc = dev_alloc(e, &e->sh_act, (size_t)e->B * e->A)) != AOG_OK) return rc;
+  if ((rc = dev_alloc(e, &e->sh_pad, (size_t)e->B * N2 * 4 * 2, false)) != AOG_OK) return rc;
+  if ((rc = dev_alloc(e, &e->sh_image, (size_t)e->B * N2, false)) != AOG_OK) return rc;
+  if ((rc = dev_alloc(e, &e->sh_noisy, (size_t)e->B * N2, false)) != AOG_OK) return rc;
+  hipfftHandle plan;
+  int dims[2] = {2 * N, 2 * N};
+  if (hipfftPlanMany(&plan, 2, dims, nullptr, 1, 4 * N * N, nullptr, 1, 4 * N * N, HIPFFT_Z2Z, e->B) != HIPFFT_SUCCESS)
+    return fail(AOG_ERR_HIP, "hipfftPlanMany(Z2Z %d x %d, batch %d) failed", 2 * N, 2 * N, e->B);
+  e->sh_plan = (void*)(uintptr_t)plan;
+  e->sh_amp = t->field_amplitude;
+  e->sh_scale = t->image_scale;
+  e->sh_gain = t->gain;
+  e->sh_leak = t->leakage;
+  e->sh_ready = true;
+  return AOG_OK;
+}
+
+int aog_sh_image(aog_env* e, double* image_dev, void* stream) {
+  if (!e) return fail(AOG_ERR_INVALID, "aog_sh_image: null handle");
+  if (!e->sh_ready || !e->screens_ready) return fail(AOG_ERR_STATE, "aog_sh_image before aog_upload_sh / aog_set_screens");
+  HIP_TRY(hipSetDevice(e->device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int N = e->cfg.n_pupil;
+  const size_t per = (size_t)4 * N * N;
+  hipfftHandle plan = (hipfftHandle)(uintptr_t)e->sh_plan;
+  if (hipfftSetStream(plan, s) != HIPFFT_SUCCESS) return fail(AOG_ERR_HIP, "hipfftSetStream failed");
+  HIP_TRY(hipMemsetAsync(e->sh_pad, 0, sizeof(double) * 2 * per * e->B, s));
+  hipLaunchKernelGGL(aog::k_sh_field, dim3((e->n_ap + 255) / 256, e->B), dim3(256), 0, s, e->psi_tile, e->modes_f32, e->sh_act, e->ap_index,
+                     reinterpret_cast<const double2*>(e->sh_mla), reinterpret_cast<double2*>(e->sh_pad), e->n_ap, e->n_ptiles, e->A, e->A_pad, N,
+                     2.0 / e->cfg.wavelength_wfs, e->sh_amp);
+  HIP_TRY(hipGetLastError());
+  hipfftDoubleComplex* buf = reinterpret_cast<hipfftDoubleComplex*>(e->sh_pad);
+  if (hipfftExecZ2Z(plan, buf, buf, HIPFFT_FORWARD) != HIPFFT_SUCCESS) return fail(AOG_ERR_HIP, "hipfftExecZ2Z forward failed");
+  hipLaunchKernelGGL(aog::k_sh_transfer, dim3((unsigned)((per + 255) / 256), e->B), dim3(256), 0, s, reinterpret_cast<double2*>(e->sh_pad),
+                     reinterpret_cast<const double2*>(e->sh_tf), per);
+  if (hipfftExecZ2Z(plan, buf, buf, HIPFFT_BACKWARD) != HIPFFT_SUCCESS) return fail(AOG_ERR_HIP, "hipfftExecZ2Z backward failed");
+  const double norm = 1.0 / (double)per;  // hipFFT's inverse is un-normalised
+  hipLaunchKernelGGL(aog::k_sh_intensity, dim3((N * N + 255) / 256, e->B), dim3(256), 0, s, reinterpret_cast<const double2*>(e->sh_pad), e->sh_image,
+                     N, e->sh_scale * norm * norm);
+  HIP_TRY(hipGetLastError());
+  if (image_dev) HIP_TRY(hipMemcpyAsync(image_dev, e->sh_image, sizeof(double) * (size_t)e->B * N * N, hipMemcpyDeviceToDevice, s));
+  return AOG_OK;
+}
+
+int aog_sh_update(aog_env* e, const double* noisy_image_dev, double* action_dev, void* stream) {
+  if (!e || !action_dev) return fail(AOG_ERR_INVALID, "aog_sh_update: null argument");
+  if (!e->sh_ready) return fail(AOG_ERR_STATE, "aog_sh_update before aog_upload_sh");
+  HIP_TRY(hipSetDevice(e->device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int N = e->cfg.n_pupil;
+  const size_t n = (size_t)e->B * N * N;
+  const double* img = noisy_image_dev;
+  if (!img) {
+    e->sh_calls += 1;
+    hipLaunchKernelGGL(aog::k_sh_noise, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, e->sh_image, e->sh_noisy, n, e->rng_seed, e->sh_calls);
+    img = e->sh_noisy;
+  }
+  aog::ShEstimateArgs p{};
+  p.image = img;
+  p.sub_slot = e->sh_slot;
+  p.x_det = e->sh_xdet;
+  p.centres = e->sh_centres;
+  p.slopes_ref = e->sh_ref;
+  p.recon = e->sh_recon;
+  p.sh_act = e->sh_act;
+  p.action_out = action_dev;
+  p.N = N;
+  p.n_sub = e->sh_n_sub;
+  p.A = e->A;
+  p.gain = e->sh_gain;
+  p.leakage = e->sh_leak;
+  hipLaunchKernelGGL(aog::k_sh_estimate, dim3(e->B), dim3(256), sizeof(double) * 5 * e->sh_n_sub, s, p);
+  HIP_TRY(hipGetLastError());
   return AOG_OK;
 }
 

@@ -36,6 +36,23 @@ struct aog_env {
   double* sci_coef = nullptr;    // [MRS_used][2]
   double* modes64 = nullptr;     // validation: [n_ap][A]
   double* tabs64 = nullptr;      // validation: [n_ap][MRW_used+MRS_used]
+  // Shack-Hartmann chain (K10)
+  bool sh_ready = false;
+  int sh_n_sub = 0;
+  int32_t* sh_slot = nullptr;
+  double* sh_centres = nullptr;
+  double* sh_ref = nullptr;
+  double* sh_recon = nullptr;
+  double* sh_mla = nullptr;       // [N*N] complex
+  double* sh_tf = nullptr;        // [2N][2N] complex
+  double* sh_xdet = nullptr;
+  double* sh_act = nullptr;       // [B][A] deformable_mirror_shack.actuators
+  double* sh_pad = nullptr;       // [B][2N][2N] complex work buffer
+  double* sh_image = nullptr;     // [B][N*N]
+  double* sh_noisy = nullptr;     // [B][N*N]
+  void* sh_plan = nullptr;        // hipfftHandle (Z2Z, batch B)
+  double sh_amp = 0, sh_scale = 0, sh_gain = 0, sh_leak = 0;
+  uint32_t sh_calls = 0;
   // device screen synthesis (K8)
   void* fft_plan = nullptr;      // hipfftHandle
   int fft_m = 0, fft_batch = 0;

@@ -1305,6 +1305,118 @@ __global__ void k_screen_crop(const float2* __restrict__ field, float* __restric
 }
 #endif  // AOG_MAIN_TU
 
+// ------------------------------------------------------------------------------------------------
+// K10  Shack-Hartmann chain (AO_env.py:254-290): field on the magnified pupil x micro-lens phase -> angular-spectrum
+// Fresnel propagation over one lenslet focal length (2x zero-padded hipFFT, float64) -> detector image -> photon noise ->
+// centre of gravity per selected lenslet -> reconstructor GEMV + leaky integrator.
+// ------------------------------------------------------------------------------------------------
+#ifdef AOG_MAIN_TU
+__global__ void k_sh_field(const float* __restrict__ psi_tile, const float* __restrict__ modes_f32, const double* __restrict__ sh_act,
+                           const int32_t* __restrict__ ap_index, const double2* __restrict__ mla_phase, double2* __restrict__ pad, int n_ap,
+                           int n_ptiles, int A, int A_pad, int N, double two_over_lambda, double amplitude) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int env = blockIdx.y;
+  if (p >= n_ap) return;
+  double rev = (double)psi_tile[psi_tile_index(env, p, n_ptiles)];
+  for (int k = 0; k < A; ++k) rev = fma((double)modes_f32[(size_t)p * A_pad + k], sh_act[(size_t)env * A + k] * two_over_lambda, rev);
+  double sn, cs;
+  sincospi(2.0 * (rev - rint(rev)), &sn, &cs);
+  const int flat = ap_index[p];
+  const int iy = flat / N, ix = flat - iy * N;
+  const double2 m = mla_phase[flat];
+  // E * mla: (cs + i sn) * (m.x + i m.y)
+  pad[(size_t)env * 4 * N * N + (size_t)iy * 2 * N + ix] = make_double2(amplitude * (cs * m.x - sn * m.y), amplitude * (cs * m.y + sn * m.x));
+}
+
+__global__ void k_sh_transfer(double2* __restrict__ f, const double2* __restrict__ tf, size_t per_env) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= per_env) return;
+  double2* v = f + (size_t)blockIdx.y * per_env + idx;
+  const double2 a = *v, b = tf[idx];
+  *v = make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+__global__ void k_sh_intensity(const double2* __restrict__ f, double* __restrict__ image, int N, double scale) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int env = blockIdx.y;
+  if (idx >= N * N) return;
+  const int iy = idx / N, ix = idx - iy * N;
+  const double2 v = f[(size_t)env * 4 * N * N + (size_t)iy * 2 * N + ix];
+  image[(size_t)env * N * N + idx] = (v.x * v.x + v.y * v.y) * scale;
+}
+
+// hcipy.util.large_poisson with the handle's Philox stream: normal approximation above 1e6 (like hcipy), and below it exact
+// inversion for lambda < 30, rounded normal approximation otherwise (indistinguishable at those counts)
+__global__ void k_sh_noise(const double* __restrict__ image, double* __restrict__ noisy, size_t n, unsigned long long seed, uint32_t call) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const double lam = image[idx];
+  double out;
+  if (lam < 30.0) {
+    uint32_t c[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), call, 0x50155u};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    for (int r = 0; r < 10; ++r) { philox_round(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+    const double u = ((double)c[0] * 4294967296.0 + (double)c[1] + 0.5) * (1.0 / 18446744073709551616.0);
+    double pk = exp(-lam), cdf = pk;
+    int k = 0;
+    while (u > cdf && k < 200) { ++k; pk *= lam / k; cdf += pk; }
+    out = (double)k;
+  } else {
+    const double g = philox_normal(seed ^ 0xA5A5A5A5ull, (uint32_t)(idx >> 32) ^ call, (uint32_t)idx, 0u);
+    out = fmax(0.0, rint(lam + g * sqrt(lam)));
+  }
+  noisy[idx] = out;
+}
+
+struct ShEstimateArgs {
+  const double* image;          // [B][N*N] (already noisy)
+  const int32_t* sub_slot;      // [N*N]
+  const double* x_det;          // [N]
+  const double* centres;        // [n_sub][2]
+  const double* slopes_ref;     // [2 n_sub]
+  const double* recon;          // [A][2 n_sub]
+  double* sh_act;               // [B][A]
+  double* action_out;           // [B][A]
+  int N, n_sub, A;
+  double gain, leakage;
+};
+
+// one workgroup per env; dynamic LDS: sums [3 n_sub] + slopes [2 n_sub] doubles
+__global__ __launch_bounds__(256) void k_sh_estimate(ShEstimateArgs p) {
+  extern __shared__ double sh[];
+  double* sums = sh;                       // [n_sub][3]: flux, sum x, sum y
+  double* slopes = sh + 3 * (size_t)p.n_sub;
+  const int env = blockIdx.x;
+  for (int i = threadIdx.x; i < 3 * p.n_sub; i += blockDim.x) sums[i] = 0.0;
+  __syncthreads();
+  const double* img = p.image + (size_t)env * p.N * p.N;
+  for (int idx = threadIdx.x; idx < p.N * p.N; idx += blockDim.x) {
+    const int slot = p.sub_slot[idx];
+    if (slot < 0) continue;
+    const int iy = idx / p.N, ix = idx - iy * p.N;
+    const double w = img[idx] + 1e-10;      // estimate([wfs_image + 1e-10]) (AO_env.py:277)
+    atomicAdd(&sums[3 * slot], w);
+    atomicAdd(&sums[3 * slot + 1], w * p.x_det[ix]);
+    atomicAdd(&sums[3 * slot + 2], w * p.x_det[iy]);
+  }
+  __syncthreads();
+  for (int s = threadIdx.x; s < p.n_sub; s += blockDim.x) {
+    const double fl = sums[3 * s];
+    slopes[s] = sums[3 * s + 1] / fl - p.centres[2 * s] - p.slopes_ref[s];
+    slopes[p.n_sub + s] = sums[3 * s + 2] / fl - p.centres[2 * s + 1] - p.slopes_ref[p.n_sub + s];
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < p.A; k += blockDim.x) {
+    const double* r = p.recon + (size_t)k * 2 * p.n_sub;
+    double acc = 0;
+    for (int j = 0; j < 2 * p.n_sub; ++j) acc = fma(r[j], slopes[j], acc);
+    const double a = (1.0 - p.leakage) * p.sh_act[(size_t)env * p.A + k] - p.gain * acc;
+    p.sh_act[(size_t)env * p.A + k] = a;
+    p.action_out[(size_t)env * p.A + k] = a;
+  }
+}
+#endif  // AOG_MAIN_TU
+
 // self-test hook: the three sin/cos flavours of the fused kernels on caller-supplied revolutions
 #ifdef AOG_MAIN_TU
 __global__ void k_selftest_sincos(const float* __restrict__ u, float* __restrict__ s, float* __restrict__ c, int n, int flavour) {

@@ -62,7 +62,9 @@ class AOEnv(env_base()):
         raise NotImplementedError("render() (matplotlib UI, AO_env.py:156-194) is outside the device hot path")
 
     def SH_step(self):
-        raise NotImplementedError("Shack-Hartmann baseline (AO_env.py:254-290) is not built yet")
+        """AO_env.py:254-290: (actuators [A] float64, torch.tensor([1]))."""
+        action, log_action = self._env.SH_step()
+        return action[0].cpu().numpy(), log_action
 
     def close(self):
         self._env.close()

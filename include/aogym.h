@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define AOG_ABI_VERSION 7
+#define AOG_ABI_VERSION 8
 
 typedef struct aog_env aog_env;
 
@@ -154,6 +154,32 @@ int aog_get_screens_f64(aog_env* env, double* psi_dev, void* stream);
  * Normals come from the handle's Philox stream (aog_set_rng_seed); statistically equivalent to hcipy, not draw-for-draw. */
 int aog_generate_screens(aog_env* env, int first, int count, int oversampling, double cn_squared, double outer_scale,
                          double pixel_pitch, void* stream);
+
+/* Shack-Hartmann baseline controller (AO_env.py:254-290, 396-465).  Tables built on the host by the counterpart of
+ * shack_hartmann_init (adaptive_optics_gym_amd/sh_host.py).  HOST pointers, float64. */
+typedef struct {
+  int32_t n_sub;                /* flux-selected sub-apertures (AO_env.py:418-425)                                 */
+  const int32_t* sub_slot;      /* [N*N] slot 0..n_sub-1 of the pixel's lenslet, or -1                             */
+  const double* centres;        /* [n_sub][2] lenslet positions (x, y) the estimator subtracts                      */
+  const double* slopes_ref;     /* [2 n_sub] reference slopes, all x then all y (AO_env.py:428)                     */
+  const double* reconstruction; /* [A][2 n_sub] inverse_tikhonov(response, 1e-3) (AO_env.py:464-465)                */
+  const double* mla_phase;      /* [N*N][2] exp(i k opd) of the micro-lens array                                    */
+  const double* transfer;       /* [2N][2N][2] Fresnel transfer function on the unshifted 2x-padded FFT grid        */
+  const double* x_det;          /* [N] detector coordinate of a column / row (NoiselessDetector(focal_grid))        */
+  double field_amplitude;       /* amplitude of wf_wfs on the aperture / magnification                              */
+  double image_scale;           /* magnified pixel area x delta_t: image = |E|^2 * image_scale                      */
+  double gain, leakage;         /* 0.3, 0.01 (AO_env.py:282-283)                                                    */
+} aog_sh_tables;
+int aog_upload_sh(aog_env* env, const aog_sh_tables* sh);
+
+/* camera.integrate(shwfs(magnifier(deformable_mirror_shack(layer(wf_wfs)))), delta_t); camera.read_out() (AO_env.py:263-274):
+ * the noise-free Shack-Hartmann image of every env, [B][N*N] float64 (may be NULL: kept internally). */
+int aog_sh_image(aog_env* env, double* image_dev, void* stream);
+
+/* large_poisson + estimate + slopes_ref + leaky integrator (AO_env.py:275-287) -> deformable_mirror_shack.actuators, which
+ * are also returned in action_dev [B][A] float64 (the action SH_step hands to step()).  noisy_image_dev: the image after the
+ * caller's own large_poisson (parity with a host RNG stream), or NULL = photon noise from the handle's Philox stream. */
+int aog_sh_update(aog_env* env, const double* noisy_image_dev, double* action_dev, void* stream);
 
 /* deformable_mirror.actuators for all envs (metres; AO_env.py:116).  [B][A] float64 device pointers. */
 int aog_get_actuators(aog_env* env, double* act_dev, void* stream);

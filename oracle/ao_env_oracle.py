@@ -79,7 +79,7 @@ class AOEnvOracle:
         self.single_mode_fiber = H.StepIndexFiber(self.singlemode_fiber_core_radius, self.fiber_NA, self.fiber_length)
 
         if self.SH_operation:
-            raise NotImplementedError("Shack-Hartmann chain (AO_env.py:396-465) is not restated yet")
+            self.shack_hartmann_init()
 
         self.timestep = 0
         self.episode_no = 0
@@ -119,6 +119,73 @@ class AOEnvOracle:
         self.num_lenslets = 12
         self.sh_diameter = 5e-3
         self.stellar_magnitude = -5
+
+    # AO_env.py:396-465
+    def shack_hartmann_init(self):
+        magnification = self.sh_diameter / self.telescope_diameter
+        self.magnifier = H.Magnifier(magnification)
+        sh_grid = self.pupil_grid.scaled(magnification)
+        self.shwfs = H.SquareShackHartmannWavefrontSensorOptics(sh_grid, self.f_number, self.num_lenslets, self.sh_diameter)
+        # NoiselessDetector(focal_grid): the reference hands it the 240^2 science focal grid (it only works because that has as
+        # many samples as the 240^2 pupil); for other pupil sizes use a centred grid of N samples with the same pitch
+        if self.num_pupil_pixels == int(self.focal_grid.dims[0]):
+            det_grid = self.focal_grid
+        else:
+            n = self.num_pupil_pixels
+            d = self.focal_grid.delta
+            det_grid = H.Grid(d, [n, n], d * (-n / 2 + (n % 2) * 0.5))
+        self.detector_grid = det_grid
+        self.camera = H.NoiselessDetector(det_grid)
+        mla = self.shwfs.micro_lens_array
+        self.shwfse = H.ShackHartmannWavefrontSensorEstimator(self.shwfs.mla_points, mla.mla_index, det_grid)
+        wf_camera = H.Wavefront(self.aperture, self.wavelength_wfs, self.pupil_grid)
+        self.camera.integrate(self.shwfs(self.magnifier(wf_camera)), 1)
+        image_ref = self.camera.read_out()
+        import scipy.ndimage as ndimage
+
+        fluxes = ndimage.sum(image_ref, mla.mla_index, self.shwfse.estimation_subapertures)
+        flux_limit = fluxes.max() * 0.5
+        sel = np.zeros(len(self.shwfs.mla_points), dtype=bool)
+        sel[self.shwfse.estimation_subapertures[fluxes > flux_limit]] = True
+        self.shwfse = H.ShackHartmannWavefrontSensorEstimator(self.shwfs.mla_points, mla.mla_index, det_grid, sel)
+        self.slopes_ref = self.shwfse.estimate([image_ref])
+        self.deformable_mirror_shack = H.DeformableMirror(self.dm_modes)
+        probe_amp = 0.01 * self.wavelength_wfs
+        response = []
+        wf_cal = H.Wavefront(self.aperture, self.wavelength_wfs, self.pupil_grid)
+        wf_cal.total_power = 1
+        for i in range(self.num_modes):
+            slope = 0
+            amps = [-probe_amp, probe_amp]
+            for amp in amps:
+                self.deformable_mirror_shack.flatten()
+                act = self.deformable_mirror_shack.actuators
+                act[i] = amp
+                self.deformable_mirror_shack.actuators = act
+                self.camera.integrate(self.shwfs(self.magnifier(self.deformable_mirror_shack.forward(wf_cal))), 1)
+                slopes = self.shwfse.estimate([self.camera.read_out()])
+                slope = slope + amp * slopes / np.var(amps)
+            response.append(np.asarray(slope).ravel())
+        self.response_matrix = np.stack(response, axis=-1)          # ModeBasis(...).transformation_matrix: [2 n_sub, A]
+        self.reconstruction_matrix = H.inverse_tikhonov(self.response_matrix, rcond=1e-3)
+        self.deformable_mirror_shack.flatten()
+
+    # AO_env.py:254-290
+    def SH_step(self):
+        wf = self.deformable_mirror_shack(self.layer(self.wf_wfs))
+        wf_on_sh = self.shwfs(self.magnifier(wf))
+        self.camera.integrate(wf_on_sh, self.delta_t)
+        wfs_image = self.camera.read_out()
+        self.last_sh_image_noiseless = wfs_image.copy()
+        wfs_image = H.large_poisson(wfs_image, rng=self.rng).astype("float")
+        slopes = self.shwfse.estimate([wfs_image + 1e-10])
+        slopes = slopes - self.slopes_ref
+        slopes = slopes.ravel()
+        self.last_sh_slopes = slopes
+        gain, leakage = 0.3, 0.01
+        self.deformable_mirror_shack.actuators = ((1 - leakage) * self.deformable_mirror_shack.actuators
+                                                  - gain * self.reconstruction_matrix.dot(slopes))
+        return self.deformable_mirror_shack.actuators, np.array([1])
 
     # AO_env.py:74-103
     def reset(self, seed=None, options=None):

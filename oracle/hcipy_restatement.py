@@ -641,3 +641,151 @@ def structural_similarity_1d(im1, im2, data_range, win_size=7, K1=0.01, K2=0.03)
         vxy = cov_norm * (uxy - ux * uy)
         S.append(((2 * ux * uy + C1) * (2 * vxy + C2)) / ((ux ** 2 + uy ** 2 + C1) * (vx + vy + C2)))
     return float(np.mean(S))
+
+
+# --------------------------------------------------------------------------------------
+# Shack-Hartmann chain (hcipy.optics.Magnifier, hcipy.wavefront_sensing.shack_hartmann, hcipy.propagation.FresnelPropagator,
+# hcipy.optics.NoiselessDetector, hcipy.util.large_poisson, hcipy.math_util.inverse_tikhonov) — AO_env.py:254-290, 396-465.
+# Confidence in these restatements is lower than for the Fraunhofer path (tags L-M).
+# --------------------------------------------------------------------------------------
+class Magnifier:
+    """Rescales the grid by ``magnification`` and the field by 1/magnification, conserving total power (AO_env.py:404)."""
+
+    def __init__(self, magnification):
+        self.magnification = float(magnification)
+
+    def forward(self, wf):
+        out = Wavefront(wf.electric_field / self.magnification, wf.wavelength, wf.grid.scaled(self.magnification))
+        return out
+
+    __call__ = forward
+
+
+class MicroLensArray:
+    """hcipy MicroLensArray with lenslet_shape=None: each pixel belongs to the closest lenslet centre; sag
+    -(d^2)/(2 f) applied as a SurfaceApodizer of refractive index 2 (opd = sag)."""
+
+    def __init__(self, input_grid, lenslet_centres, focal_length):
+        xs, ys = input_grid.x, input_grid.y
+        cx, cy = lenslet_centres
+        # separable nearest centre (the lenslet grid is a regular separable grid)
+        ix = np.argmin(np.abs(xs[:, None] - cx[None, :]), axis=1)
+        iy = np.argmin(np.abs(ys[:, None] - cy[None, :]), axis=1)
+        self.mla_index = iy * len(cx) + ix
+        d2 = (xs - cx[ix]) ** 2 + (ys - cy[iy]) ** 2
+        self.mla_opd = (-1.0 / (2 * focal_length)) * d2
+
+    def forward(self, wf):
+        out = wf.copy()
+        out.electric_field *= np.exp(1j * self.mla_opd * wf.wavenumber)
+        return out
+
+
+class FresnelPropagator:
+    """hcipy FresnelPropagator(grid, distance, num_oversampling=2): FFT with 2x zero padding, multiply by the paraxial
+    transfer function exp(-i z |k|^2 / (2 k)) exp(i k z), inverse FFT, crop.  (The sampling test of hcipy selects this
+    transfer-function branch for the reference's geometry: delta = 20.8 um >= lambda z / L = 6.25 um.)"""
+
+    def __init__(self, input_grid, distance, num_oversampling=2):
+        self.grid = input_grid
+        self.distance = float(distance)
+        self.q = int(num_oversampling)
+        self._tf = {}
+
+    def forward(self, wf):
+        g = wf.grid
+        ny, nx = g.shape
+        my, mx = ny * self.q, nx * self.q
+        lam = wf.wavelength
+        if np.any(g.delta < lam * self.distance / np.max(g.dims * g.delta)):
+            raise NotImplementedError("impulse-response branch of hcipy's FresnelPropagator is not restated")
+        if lam not in self._tf:
+            k = 2 * np.pi / lam
+            kx = 2 * np.pi * np.fft.fftfreq(mx, g.delta[0])
+            ky = 2 * np.pi * np.fft.fftfreq(my, g.delta[1])
+            k2 = kx[None, :] ** 2 + ky[:, None] ** 2
+            self._tf[lam] = np.exp(-0.5j * self.distance * k2 / k) * np.exp(1j * k * self.distance)
+        pad = np.zeros((my, mx), dtype=complex)
+        y0, x0 = my // 2 - ny // 2, mx // 2 - nx // 2
+        pad[y0:y0 + ny, x0:x0 + nx] = wf.electric_field.reshape(ny, nx)
+        out = np.fft.ifft2(np.fft.fft2(pad) * self._tf[lam])[y0:y0 + ny, x0:x0 + nx]
+        return Wavefront(out.ravel(), lam, g)
+
+    __call__ = forward
+
+
+class SquareShackHartmannWavefrontSensorOptics:
+    """hcipy SquareShackHartmannWavefrontSensorOptics(input_grid, f_number, num_lenslets, pupil_diameter) (AO_env.py:407)."""
+
+    def __init__(self, input_grid, f_number, num_lenslets, pupil_diameter):
+        lenslet_diameter = float(pupil_diameter) / num_lenslets
+        x = np.arange(-pupil_diameter, pupil_diameter, lenslet_diameter)
+        self.mla_centres = (x, x)
+        self.num_lenslet_axis = len(x)
+        gx, gy = np.meshgrid(x, x)
+        self.mla_points = np.stack([gx.ravel(), gy.ravel()], axis=1)  # [n_lenslets, 2] (x, y), x fastest
+        focal_length = f_number * lenslet_diameter
+        self.micro_lens_array = MicroLensArray(input_grid, self.mla_centres, focal_length)
+        self.propagator = FresnelPropagator(input_grid, focal_length)
+
+    def forward(self, wf):
+        return self.propagator(self.micro_lens_array.forward(wf))
+
+    __call__ = forward
+
+
+class NoiselessDetector:
+    def __init__(self, detector_grid):
+        self.detector_grid = detector_grid
+        self.accumulated = 0.0
+
+    def integrate(self, wf, dt, weight=1):
+        self.accumulated = self.accumulated + wf.power * dt * weight
+
+    def read_out(self):
+        out = np.array(self.accumulated, dtype=float)
+        self.accumulated = 0.0
+        return out
+
+
+def large_poisson(lam, thresh=1e6, rng=np.random):
+    """hcipy.util.large_poisson: normal approximation above ``thresh`` (draws normal(size=n_large) first), exact Poisson below."""
+    lam = np.asarray(lam, dtype=float)
+    large = lam > thresh
+    small = ~large
+    n = np.zeros(lam.shape)
+    n[large] = np.round(lam[large] + rng.normal(size=np.sum(large)) * np.sqrt(lam[large]))
+    n[small] = rng.poisson(lam[small], size=np.sum(small))
+    return n
+
+
+class ShackHartmannWavefrontSensorEstimator:
+    """Centre of gravity per lenslet (scipy.ndimage sums over the lenslet labels) minus the lenslet position
+    (hcipy ShackHartmannWavefrontSensorEstimator.estimate).  Coordinates are those of the IMAGE's grid."""
+
+    def __init__(self, mla_points, mla_index, image_grid, estimation_subapertures=None):
+        self.mla_points = mla_points
+        self.mla_index = mla_index
+        self.image_grid = image_grid
+        if estimation_subapertures is None:
+            self.estimation_subapertures = np.unique(mla_index)
+        else:
+            self.estimation_subapertures = np.flatnonzero(np.asarray(estimation_subapertures))
+
+    def estimate(self, images):
+        import scipy.ndimage as ndimage
+
+        image = np.asarray(images[0], dtype=float)
+        sub = self.estimation_subapertures
+        fluxes = ndimage.sum(image, self.mla_index, sub)
+        sum_x = ndimage.sum(image * self.image_grid.x, self.mla_index, sub)
+        sum_y = ndimage.sum(image * self.image_grid.y, self.mla_index, sub)
+        centroids = np.array((sum_x / fluxes, sum_y / fluxes)) - self.mla_points[sub, :].T
+        return centroids  # [2, n_sub]
+
+
+def inverse_tikhonov(M, rcond=1e-15):
+    """hcipy.math_util.inverse_tikhonov: V diag(s / (s^2 + (rcond s_max)^2)) U^T."""
+    U, S, Vt = np.linalg.svd(M, full_matrices=False)
+    S_inv = S / (S ** 2 + (rcond * S.max()) ** 2)
+    return (Vt.T * S_inv).dot(U.T)
