@@ -278,6 +278,22 @@ class BatchedAOEnv:
             _lib.check(self.lib.aog_sh_update(self._handle, None, C.c_void_p(action.data_ptr()), self._stream()))
         return action, torch.tensor([1])
 
+    def sh_image(self):
+        """Noise-free Shack-Hartmann camera image of every env, [B, N*N] float64 (camera.read_out(), AO_env.py:274)."""
+        torch = self._torch
+        img = torch.empty((self.num_envs, self.num_pupil_pixels ** 2), dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.aog_sh_image(self._handle, C.c_void_p(img.data_ptr()), self._stream()))
+        return img
+
+    def sh_update(self, noisy_image):
+        """Estimator + leaky integrator on a caller-supplied (already noisy) image [B, N*N] float64 -> actions [B, A] float64."""
+        torch = self._torch
+        nd = torch.as_tensor(noisy_image, device=self.device).to(torch.float64).reshape(self.num_envs, -1).contiguous()
+        action = torch.empty((self.num_envs, self.num_modes), dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.aog_sh_update(self._handle, C.c_void_p(nd.data_ptr()), C.c_void_p(action.data_ptr()), self._stream()))
+        torch.cuda.current_stream(self.device).synchronize()
+        return action
+
     def _host_extrusion_noise(self):
         """Host-RNG (parity) mode: draw the normals of the coming step's extrusions from each env's numpy stream in hcipy's
         order (all x shifts, then all y shifts; ``normal(0, 1, N)`` per extrusion) and hand them to the library."""

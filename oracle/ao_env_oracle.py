@@ -178,6 +178,7 @@ class AOEnvOracle:
         wfs_image = self.camera.read_out()
         self.last_sh_image_noiseless = wfs_image.copy()
         wfs_image = H.large_poisson(wfs_image, rng=self.rng).astype("float")
+        self.last_sh_noisy = wfs_image.copy()
         slopes = self.shwfse.estimate([wfs_image + 1e-10])
         slopes = slopes - self.slopes_ref
         slopes = slopes.ravel()
