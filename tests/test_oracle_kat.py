@@ -268,3 +268,54 @@ def test_smf_ssim_reward_and_threshold():
         bad = AOEnvOracle(act_type="zernike", act_dim=6, obs_dim=2, rew_type="smf_ssim", num_pupil_pixels=N, screen=scr.ravel(), verbose=False)
         bad.reset()
         bad.step(a)
+
+
+def test_shack_hartmann_oracle_known_answers():
+    """SH chain of the oracle: flat wavefront -> slopes equal the reference slopes; a pure tilt -> one uniform slope component
+    proportional to the tilt; the leaky integrator (gain 0.3, leakage 0.01) raises the Strehl ratio of a static aberration."""
+    N, A = 96, 8
+    scr = ndimage.gaussian_filter(np.random.RandomState(3).randn(N, N), 5.0)
+    scr = scr / scr.std() * 1.5e-6
+    env = AOEnvOracle(act_type="zernike", act_dim=A, obs_dim=2, num_pupil_pixels=N, screen=np.zeros(N * N), SH_operation=True,
+                      timesteps_per_episode=50, rng=np.random.RandomState(0), verbose=False)
+    n_sub = len(env.shwfse.estimation_subapertures)
+    assert 60 < n_sub < 12 * 12 and env.reconstruction_matrix.shape == (A, 2 * n_sub)
+    assert env.shwfs.micro_lens_array.mla_index.max() < 24 * 24          # lenslet grid spans twice the pupil (arange(-D, D, d))
+    # flat: noise-free slopes == reference
+    wf = env.magnifier(env.wf_wfs)
+    env.camera.integrate(env.shwfs(wf), 1.0)
+    s = env.shwfse.estimate([env.camera.read_out()]) - env.slopes_ref
+    assert np.abs(s).max() < 1e-15
+    # pure x tilt of amplitude eps * (Zernike 2 / ptp): x slopes uniform and non-zero, y slopes ~ 0
+    env.deformable_mirror_shack.flatten()
+    act = np.zeros(A); act[1] = 2e-8
+    env.deformable_mirror_shack.actuators = act
+    env.camera.integrate(env.shwfs(env.magnifier(env.deformable_mirror_shack(env.wf_wfs))), 1.0)
+    s = env.shwfse.estimate([env.camera.read_out()]) - env.slopes_ref
+    inner = np.abs(s[0] - np.median(s[0])) < 0.2 * abs(np.median(s[0]))
+    assert inner.mean() > 0.7 and abs(np.median(s[0])) > 20 * np.abs(s[1]).max()
+    # the reference's poke formula sum(amp * slopes) / var([-p, p]) = (s+ - s-) / p is TWICE the derivative ds/da
+    # (AO_env.py:453-457), so response * a = 2 * slopes(a) in the linear regime
+    np.testing.assert_allclose(0.5 * env.response_matrix[:, 1] * 2e-8, s.ravel(), rtol=2e-2, atol=2e-2 * np.abs(s).max())
+    # closed loop on a static aberration
+    env2 = AOEnvOracle(act_type="zernike", act_dim=A, obs_dim=2, num_pupil_pixels=N, screen=scr.ravel(), SH_operation=True,
+                       timesteps_per_episode=50, rng=np.random.RandomState(1), verbose=False)
+    env2.reset()
+    st = []
+    for _ in range(10):
+        a, la = env2.SH_step()
+        assert la.tolist() == [1]
+        env2.step(a)
+        st.append(env2.last_strehl)
+    assert st[-1] > st[0] + 0.02
+
+
+def test_large_poisson_and_tikhonov():
+    rng = np.random.RandomState(0)
+    lam = np.array([0.5, 10.0, 2e6, 5e7])
+    out = np.stack([H.large_poisson(lam, rng=rng) for _ in range(4000)])
+    np.testing.assert_allclose(out.mean(0), lam, rtol=0.05)
+    np.testing.assert_allclose(out.var(0), lam, rtol=0.1)
+    assert np.all(out == np.round(out))
+    M = np.random.RandomState(1).randn(7, 4)
+    np.testing.assert_allclose(H.inverse_tikhonov(M, 1e-12), np.linalg.pinv(M), rtol=1e-8, atol=1e-10)
