@@ -77,6 +77,27 @@ void launch_fast(aog_env* e, hipStream_t s) {
   }
 }
 
+}  // namespace
+
+namespace aog_host {
+template <int A_PAD>
+static void launch_sh_phase_t(aog_env* e, hipStream_t s) {
+  hipLaunchKernelGGL((aog::k_phase_mfma<A_PAD>), dim3((e->n_ptiles + 3) / 4, e->n_etiles), dim3(256), 0, s,
+                     reinterpret_cast<const aog::f16x8*>(e->modes16), reinterpret_cast<const aog::f32x4*>(e->psi_tile),
+                     reinterpret_cast<const aog::f16x8*>(e->sh_act16), reinterpret_cast<aog::f32x4*>(e->sh_phase), e->n_ptiles, e->n_etiles);
+}
+void launch_sh_phase(aog_env* e, hipStream_t s) {
+  switch (e->A_pad) {
+    case 16: launch_sh_phase_t<16>(e, s); break;
+    case 32: launch_sh_phase_t<32>(e, s); break;
+    case 64: launch_sh_phase_t<64>(e, s); break;
+    default: launch_sh_phase_t<128>(e, s); break;
+  }
+}
+}  // namespace aog_host
+
+namespace {
+
 int launch_fused(aog_env* e, hipStream_t s) {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (e->profile) {
@@ -656,6 +677,8 @@ int aog_upload_sh(aog_env* e, const aog_sh_tables* t) {
   if ((rc = up(&e->sh_tf, t->transfer, N2 * 4 * 2)) != AOG_OK) return rc;
   if ((rc = up(&e->sh_xdet, t->x_det, (size_t)N)) != AOG_OK) return rc;
   if ((rc = dev_alloc(e, &e->sh_act, (size_t)e->B * e->A)) != AOG_OK) return rc;
+  if ((rc = dev_alloc(e, &e->sh_act16, (size_t)e->n_etiles * e->A_pad * 32 * 2)) != AOG_OK) return rc;
+  if ((rc = dev_alloc(e, &e->sh_phase, (size_t)e->n_etiles * e->n_ptiles * 1024)) != AOG_OK) return rc;
   if ((rc = dev_alloc(e, &e->sh_pad, (size_t)e->B * N2 * 4 * 2, false)) != AOG_OK) return rc;
   if ((rc = dev_alloc(e, &e->sh_image, (size_t)e->B * N2, false)) != AOG_OK) return rc;
   if ((rc = dev_alloc(e, &e->sh_noisy, (size_t)e->B * N2, false)) != AOG_OK) return rc;
@@ -682,9 +705,14 @@ int aog_sh_image(aog_env* e, double* image_dev, void* stream) {
   hipfftHandle plan = (hipfftHandle)(uintptr_t)e->sh_plan;
   if (hipfftSetStream(plan, s) != HIPFFT_SUCCESS) return fail(AOG_ERR_HIP, "hipfftSetStream failed");
   HIP_TRY(hipMemsetAsync(e->sh_pad, 0, sizeof(double) * 2 * per * e->B, s));
-  hipLaunchKernelGGL(aog::k_sh_field, dim3((e->n_ap + 255) / 256, e->B), dim3(256), 0, s, e->psi_tile, e->modes_f32, e->sh_act, e->ap_index,
-                     reinterpret_cast<const double2*>(e->sh_mla), reinterpret_cast<double2*>(e->sh_pad), e->n_ap, e->n_ptiles, e->A, e->A_pad, N,
-                     2.0 / e->cfg.wavelength_wfs, e->sh_amp);
+  {
+    const int n = e->B * e->A_pad;
+    hipLaunchKernelGGL(aog::k_sh_act16, dim3((n + 255) / 256), dim3(256), 0, s, e->sh_act, e->sh_act16, e->B, e->A, e->A_pad,
+                       2.0 / e->cfg.wavelength_wfs);
+    aog_host::launch_sh_phase(e, s);
+  }
+  hipLaunchKernelGGL(aog::k_sh_field, dim3((e->n_ap + 255) / 256, e->B), dim3(256), 0, s, e->sh_phase, e->ap_index,
+                     reinterpret_cast<const double2*>(e->sh_mla), reinterpret_cast<double2*>(e->sh_pad), e->n_ap, e->n_ptiles, N, e->sh_amp);
   HIP_TRY(hipGetLastError());
   hipfftDoubleComplex* buf = reinterpret_cast<hipfftDoubleComplex*>(e->sh_pad);
   if (hipfftExecZ2Z(plan, buf, buf, HIPFFT_FORWARD) != HIPFFT_SUCCESS) return fail(AOG_ERR_HIP, "hipfftExecZ2Z forward failed");

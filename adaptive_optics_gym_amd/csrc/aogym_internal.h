@@ -47,6 +47,8 @@ struct aog_env {
   double* sh_tf = nullptr;        // [2N][2N] complex
   double* sh_xdet = nullptr;
   double* sh_act = nullptr;       // [B][A] deformable_mirror_shack.actuators
+  _Float16* sh_act16 = nullptr;   // same, B-operand layout
+  float* sh_phase = nullptr;      // psi_tile layout: wfs phase (rev) through the shack mirror
   double* sh_pad = nullptr;       // [B][2N][2N] complex work buffer
   double* sh_image = nullptr;     // [B][N*N]
   double* sh_noisy = nullptr;     // [B][N*N]
@@ -114,4 +116,6 @@ void launch_fused_apad16(aog_env* e, hipStream_t s);
 void launch_fused_apad32(aog_env* e, hipStream_t s);
 void launch_fused_apad64(aog_env* e, hipStream_t s);
 void launch_fused_apad128(aog_env* e, hipStream_t s);
+// phase-only contraction with the Shack-Hartmann mirror's actuators (sh_act16 -> sh_phase)
+void launch_sh_phase(aog_env* e, hipStream_t s);
 }  // namespace aog_host

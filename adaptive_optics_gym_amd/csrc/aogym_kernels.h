@@ -586,6 +586,38 @@ __global__ __launch_bounds__(256, (MRW <= 12 ? 2 : 1)) void k_fused_mfma(const f
   }
 }
 
+// Phase-only form of the contraction: u = psi + Mt a for every (pixel, env), written back in the psi_tile layout.  Used by the
+// Shack-Hartmann chain, whose mirror (deformable_mirror_shack) carries its own actuators.  One wave per (env tile, pixel tile).
+template <int A_PAD>
+__global__ __launch_bounds__(256) void k_phase_mfma(const f16x8* __restrict__ modes16, const f32x4* __restrict__ psi_tile,
+                                                    const f16x8* __restrict__ act16, f32x4* __restrict__ out_tile, int n_ptiles,
+                                                    int n_etiles) {
+  constexpr int NSTEP = A_PAD / 16;
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int etile = blockIdx.y;
+  if (t >= n_ptiles || etile >= n_etiles) return;
+  const f16x8* asrc = act16 + ((size_t)etile * NSTEP * 2) * 64 + lane;
+  const f16x8* ms = modes16 + ((size_t)t * NSTEP * 2) * 64 + lane;
+  f32x16 d1 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, d2 = d1;
+#pragma unroll
+  for (int s = 0; s < NSTEP; ++s) {
+    const f16x8 mh = ms[(2 * s) * 64], ml = ms[(2 * s + 1) * 64], bh = asrc[(2 * s) * 64], bl = asrc[(2 * s + 1) * 64];
+    d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh, bh, d1, 0, 0, 0);
+    d2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh, bl, d2, 0, 0, 0);
+    d2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ml, bh, d2, 0, 0, 0);
+  }
+  const size_t base = (((size_t)etile * n_ptiles + t) * 4) * 64 + lane;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const f32x4 p = psi_tile[base + g * 64];
+    f32x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = d1[4 * g + r] * kD1Unscale + (p[r] + d2[4 * g + r] * kD2Unscale);
+    out_tile[base + g * 64] = o;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K3c  float64 validation form (AOG_PRECISION_FP64): one workgroup per env, everything in float64 from
 // float64 tables; also the general path for shapes the fast kernels are not instantiated for.
@@ -1311,14 +1343,12 @@ __global__ void k_screen_crop(const float2* __restrict__ field, float* __restric
 // centre of gravity per selected lenslet -> reconstructor GEMV + leaky integrator.
 // ------------------------------------------------------------------------------------------------
 #ifdef AOG_MAIN_TU
-__global__ void k_sh_field(const float* __restrict__ psi_tile, const float* __restrict__ modes_f32, const double* __restrict__ sh_act,
-                           const int32_t* __restrict__ ap_index, const double2* __restrict__ mla_phase, double2* __restrict__ pad, int n_ap,
-                           int n_ptiles, int A, int A_pad, int N, double two_over_lambda, double amplitude) {
+__global__ void k_sh_field(const float* __restrict__ phase_tile, const int32_t* __restrict__ ap_index, const double2* __restrict__ mla_phase,
+                           double2* __restrict__ pad, int n_ap, int n_ptiles, int N, double amplitude) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   const int env = blockIdx.y;
   if (p >= n_ap) return;
-  double rev = (double)psi_tile[psi_tile_index(env, p, n_ptiles)];
-  for (int k = 0; k < A; ++k) rev = fma((double)modes_f32[(size_t)p * A_pad + k], sh_act[(size_t)env * A + k] * two_over_lambda, rev);
+  const double rev = (double)phase_tile[psi_tile_index(env, p, n_ptiles)];   // revolutions at lambda_wfs (k_phase_mfma)
   double sn, cs;
   sincospi(2.0 * (rev - rint(rev)), &sn, &cs);
   const int flat = ap_index[p];
@@ -1326,6 +1356,14 @@ __global__ void k_sh_field(const float* __restrict__ psi_tile, const float* __re
   const double2 m = mla_phase[flat];
   // E * mla: (cs + i sn) * (m.x + i m.y)
   pad[(size_t)env * 4 * N * N + (size_t)iy * 2 * N + ix] = make_double2(amplitude * (cs * m.x - sn * m.y), amplitude * (cs * m.y + sn * m.x));
+}
+
+// deformable_mirror_shack.actuators (metres, float64) -> the f16 hi/lo B-operand layout
+__global__ void k_sh_act16(const double* __restrict__ sh_act, _Float16* __restrict__ act16, int B, int A, int A_pad, double two_over_lambda) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * A_pad) return;
+  const int env = idx / A_pad, i = idx % A_pad;
+  store_act16(act16, env, i, A_pad, (i < A) ? (float)(sh_act[(size_t)env * A + i] * two_over_lambda) : 0.f);
 }
 
 __global__ void k_sh_transfer(double2* __restrict__ f, const double2* __restrict__ tf, size_t per_env) {
