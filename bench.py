@@ -122,7 +122,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    distributed = world > 1
+    distributed = world > 1 or os.environ.get("AOG_FORCE_DIST") == "1"   # the latter: rehearse the RCCL path with one rank
     if args.gpus != world and distributed:
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     torch.cuda.set_device(local_rank)
