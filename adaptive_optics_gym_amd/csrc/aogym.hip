@@ -228,6 +228,16 @@ int evolve_layer(aog_env* e, hipStream_t s) {
       }
     hipLaunchKernelGGL(aog::k_extrude_finish, dim3((e->B + 255) / 256), dim3(256), 0, s, p, e->B);
     HIP_TRY(hipGetLastError());
+  } else if (!getenv("AOG_EXTRUDE_SIMPLE")) {
+    // default: float64 matrix-core form, 16 envs per workgroup (a workgroup owns whole envs: no cross-workgroup hazard)
+    const size_t lds = (size_t)aog::kExt16G * ((std::max(e->nz_v, e->nz_h) | 1) + (e->cfg.n_pupil | 1)) * sizeof(double);
+    if (lds > 64 * 1024 && !e->extrude_attr_set) {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(aog::k_extrude16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      e->extrude_attr_set = true;
+    }
+    p.origin = e->origin;
+    hipLaunchKernelGGL(aog::k_extrude16, dim3((e->B + aog::kExt16G - 1) / aog::kExt16G), dim3(512), lds, s, p, e->B);
+    HIP_TRY(hipGetLastError());
   } else {
     const size_t lds = (size_t)aog::kExtG * (std::max(e->nz_v, e->nz_h) + 2 * e->cfg.n_pupil) * sizeof(double);
     if (lds > 64 * 1024 && !e->extrude_attr_set) {

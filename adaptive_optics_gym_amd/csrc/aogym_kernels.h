@@ -998,6 +998,135 @@ __global__ __launch_bounds__(512) void k_extrude(ExtrudeArgs p, int B) {
   }
 }
 
+// ---- float64 matrix-core form: 16 envs per workgroup ---------------------------------------------------------------------
+// Same algorithm as k_extrude with the two contractions on v_mfma_f64_16x16x4_f64: D[16 rows][16 envs] += A[16 rows][4 k] B[4 k][16 envs],
+// A = transposed AR matrix rows straight from L2 (lane (row l&15, k l>>4)), B = stencil values / normals from LDS (lane (env l&15, k l>>4)).
+// C/D map of the f64 instruction: col = lane & 15, row = (lane >> 4) + 4 * reg.  Every matrix element is streamed once per 16 envs.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+constexpr int kExt16G = 16;
+#ifdef AOG_MAIN_TU
+__global__ __launch_bounds__(512) void k_extrude16(ExtrudeArgs p, int B) {
+  extern __shared__ double lds[];  // z [16][zs] | noise [16][ns]
+  constexpr int G = kExt16G;
+  const int N = p.N;
+  const int nzmax = max(p.nz_v, p.nz_h);
+  const int zs = nzmax | 1, ns = N | 1;   // odd strides: the 16 env rows fall on different LDS banks
+  double* zb = lds;
+  double* nb = lds + (size_t)G * zs;
+  __shared__ int s_ox[G], s_oy[G], s_dx[G], s_dy[G];
+  const int env0 = blockIdx.x * G;
+  if (threadIdx.x < G) {
+    const int env = env0 + threadIdx.x;
+    int dx = 0, dy = 0, ox = 0, oy = 0;
+    if (env < B) {
+      const double vx = p.velocity[2 * env], vy = p.velocity[2 * env + 1];
+      dx = (int)rint(vx * p.t_new / p.pitch) - (int)rint(vx * p.t_prev / p.pitch);
+      dy = (int)rint(vy * p.t_new / p.pitch) - (int)rint(vy * p.t_prev / p.pitch);
+      ox = p.origin[2 * env];
+      oy = p.origin[2 * env + 1];
+    }
+    s_dx[threadIdx.x] = dx; s_dy[threadIdx.x] = dy; s_ox[threadIdx.x] = ox; s_oy[threadIdx.x] = oy;
+  }
+  __syncthreads();
+  int rounds = 0;
+  for (int g = 0; g < G; ++g) rounds = max(rounds, abs(s_dx[g]) + abs(s_dy[g]));
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  for (int r = 0; r < rounds; ++r) {
+    auto cls = [&](int g) { return r < abs(s_dx[g]) ? 1 : (r < abs(s_dx[g]) + abs(s_dy[g]) ? 2 : 0); };
+    for (int g = 0; g < G; ++g) {
+      const int c = cls(g);
+      if (!c) continue;
+      const int env = env0 + g;
+      const bool horizontal = c == 1;
+      const bool flipped = horizontal ? s_dx[g] > 0 : s_dy[g] > 0;
+      const int nz = horizontal ? p.nz_h : p.nz_v;
+      const int32_t* st = horizontal ? p.stencil_h : p.stencil_v;
+      const double* master = p.master + (size_t)env * N * N;
+      const int ox = s_ox[g], oy = s_oy[g];
+      for (int k = threadIdx.x; k < nz; k += blockDim.x) {
+        int sy = st[k] / N, sx = st[k] - sy * N;
+        if (flipped) { sy = N - 1 - sy; sx = N - 1 - sx; }
+        int py = sy + oy, px = sx + ox;
+        if (py >= N) py -= N;
+        if (px >= N) px -= N;
+        zb[(size_t)g * zs + k] = master[(size_t)py * N + px];
+      }
+      const uint32_t ext = p.ext_counter[env] + (uint32_t)r;
+      for (int j = threadIdx.x; j < N; j += blockDim.x)
+        nb[(size_t)g * ns + j] = (p.noise && r < p.max_ext) ? p.noise[((size_t)env * p.max_ext + r) * N + j]
+                                                            : philox_normal(p.seed, (uint32_t)env, ext, (uint32_t)j);
+    }
+    __syncthreads();
+    const int my_cls = cls(li);     // class of the env this lane feeds as the B operand / owns as the D column
+    for (int c = 1; c <= 2; ++c) {
+      bool any = false;
+      for (int g = 0; g < G; ++g) any |= cls(g) == c;
+      if (!any) continue;
+      const bool horizontal = c == 1;
+      const int nz = horizontal ? p.nz_h : p.nz_v;
+      const double* At = horizontal ? p.At_h : p.At_v;
+      const double* Bt = horizontal ? p.Bt_h : p.Bt_v;
+      const bool feed = my_cls == c;
+      for (int rb = wave; rb * 16 < N; rb += nwaves) {
+        const int row = rb * 16 + li;
+        const bool row_ok = row < N;
+        f64x4 accA = {0.0, 0.0, 0.0, 0.0}, accB = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+        for (int k0 = 0; k0 < nz; k0 += 4) {
+          const int k = k0 + lk;
+          const double a = (k < nz && row_ok) ? At[(size_t)k * N + row] : 0.0;
+          const double b = (k < nz && feed) ? zb[(size_t)li * zs + k] : 0.0;
+          accA = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, accA, 0, 0, 0);
+        }
+#pragma unroll 4
+        for (int j0 = 0; j0 < N; j0 += 4) {
+          const int j = j0 + lk;
+          const double a = (j < N && row_ok) ? Bt[(size_t)j * N + row] : 0.0;
+          const double b = (j < N && feed) ? nb[(size_t)li * ns + j] : 0.0;
+          accB = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, accB, 0, 0, 0);
+        }
+        // this lane holds column (env) li, rows rb*16 + lk + 4*q
+        if (feed) {
+          const int g = li;
+          const bool flipped = horizontal ? s_dx[g] > 0 : s_dy[g] > 0;
+          int nox = s_ox[g], noy = s_oy[g];
+          if (horizontal) nox = flipped ? (nox + 1 == N ? 0 : nox + 1) : (nox == 0 ? N - 1 : nox - 1);
+          else noy = flipped ? (noy + 1 == N ? 0 : noy + 1) : (noy == 0 ? N - 1 : noy - 1);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int i = rb * 16 + lk + 4 * q;
+            if (i >= N) continue;
+            const double v = accA[q] + accB[q] * p.sqrt_cn2;
+            int ly, lx;
+            if (horizontal) { ly = flipped ? N - 1 - i : i; lx = flipped ? N - 1 : 0; }
+            else { ly = flipped ? N - 1 : 0; lx = flipped ? N - 1 - i : i; }
+            int py = ly + noy, px = lx + nox;
+            if (py >= N) py -= N;
+            if (px >= N) px -= N;
+            p.master[(size_t)(env0 + g) * N * N + (size_t)py * N + px] = v;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < G) {
+      const int g = threadIdx.x;
+      const int c = cls(g);
+      if (c == 1) s_ox[g] = s_dx[g] > 0 ? (s_ox[g] + 1 == N ? 0 : s_ox[g] + 1) : (s_ox[g] == 0 ? N - 1 : s_ox[g] - 1);
+      else if (c == 2) s_oy[g] = s_dy[g] > 0 ? (s_oy[g] + 1 == N ? 0 : s_oy[g] + 1) : (s_oy[g] == 0 ? N - 1 : s_oy[g] - 1);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < G && env0 + threadIdx.x < B) {
+    const int g = threadIdx.x, env = env0 + g;
+    p.origin[2 * env] = s_ox[g];
+    p.origin[2 * env + 1] = s_oy[g];
+    p.ext_counter[env] += (uint32_t)(abs(s_dx[g]) + abs(s_dy[g]));
+  }
+}
+#endif  // AOG_MAIN_TU
+
 // ---- lock-step rounds: one launch = the r-th x (phase 0) or y (phase 1) extrusion of EVERY env --------------------------
 // out[row][env] = sum_k At[k][row] z_env[k] + sqrt(Cn^2) sum_j Bt[j][row] n_env[j]  is a [N x (nz+N)] x [(nz+N) x B] float64 matrix
 // product per round, so the AR matrices are streamed once per 32-env tile instead of once per env.  A workgroup owns a
