@@ -194,6 +194,8 @@ int evolve_layer(aog_env* e, hipStream_t s) {
   p.velocity = e->velocity;
   p.stencil_v = e->stencil_v;
   p.stencil_h = e->stencil_h;
+  p.stencil_v_yx = e->stencil_v_yx;
+  p.stencil_h_yx = e->stencil_h_yx;
   p.At_v = e->At_v;
   p.Bt_v = e->Bt_v;
   p.At_h = e->At_h;
@@ -562,6 +564,15 @@ int aog_upload_layer(aog_env* e, const aog_layer_tables* t) {
   if ((rc = dev_alloc(e, &e->stencil_h, e->nz_h, false)) != AOG_OK) return rc;
   HIP_TRY(hipMemcpy(e->stencil_v, t->stencil_vertical, sizeof(int32_t) * e->nz_v, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(e->stencil_h, t->stencil_horizontal, sizeof(int32_t) * e->nz_h, hipMemcpyHostToDevice));
+  {
+    std::vector<int32_t> pv(e->nz_v), ph(e->nz_h);
+    for (int k = 0; k < e->nz_v; ++k) pv[k] = (int32_t)(((uint32_t)(t->stencil_vertical[k] / N) << 16) | (uint32_t)(t->stencil_vertical[k] % N));
+    for (int k = 0; k < e->nz_h; ++k) ph[k] = (int32_t)(((uint32_t)(t->stencil_horizontal[k] / N) << 16) | (uint32_t)(t->stencil_horizontal[k] % N));
+    if ((rc = dev_alloc(e, &e->stencil_v_yx, e->nz_v, false)) != AOG_OK) return rc;
+    if ((rc = dev_alloc(e, &e->stencil_h_yx, e->nz_h, false)) != AOG_OK) return rc;
+    HIP_TRY(hipMemcpy(e->stencil_v_yx, pv.data(), sizeof(int32_t) * e->nz_v, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->stencil_h_yx, ph.data(), sizeof(int32_t) * e->nz_h, hipMemcpyHostToDevice));
+  }
   e->layer_ready = true;
   return AOG_OK;
 }

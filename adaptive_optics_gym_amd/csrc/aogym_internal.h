@@ -90,6 +90,8 @@ struct aog_env {
   double* psi_sum = nullptr;     // [B] aperture sums accumulated by the last repack
   int32_t* stencil_v = nullptr;
   int32_t* stencil_h = nullptr;
+  int32_t* stencil_v_yx = nullptr;  // (sy << 16 | sx)
+  int32_t* stencil_h_yx = nullptr;
   double* At_v = nullptr;        // [nz_v][N]
   double* Bt_v = nullptr;        // [N][N]
   double* At_h = nullptr;

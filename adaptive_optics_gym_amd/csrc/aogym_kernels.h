@@ -817,6 +817,8 @@ struct ExtrudeArgs {
   const double* velocity;    // [B][2] m/s
   const int32_t* stencil_v;  // [nz_v] flat logical indices
   const int32_t* stencil_h;  // [nz_h]
+  const int32_t* stencil_v_yx;  // [nz_v] (sy << 16 | sx)
+  const int32_t* stencil_h_yx;  // [nz_h]
   const double* At_v;        // [nz_v][N]
   const double* Bt_v;        // [N][N]
   const double* At_h;
@@ -842,18 +844,18 @@ __device__ inline double philox_normal(unsigned long long seed, uint32_t env, ui
   uint32_t c[4] = {idx >> 1, ext, env, 0u};
   uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int rr = 0; rr < 10; ++rr) {
     philox_round(c, k0, k1);
     k0 += 0x9E3779B9u;
     k1 += 0xBB67AE85u;
   }
-  // two 52-bit-ish uniforms in (0,1] / [0,1) from the four words, Box-Muller, pick by parity of idx
-  const double u1 = ((double)c[0] * 4294967296.0 + (double)c[1] + 1.0) * (1.0 / 18446744073709551616.0);
-  const double u2 = ((double)c[2] * 4294967296.0 + (double)c[3]) * (1.0 / 18446744073709551616.0);
-  const double r = sqrt(-2.0 * log(u1));
-  double sn, cs;
-  sincospi(2.0 * u2, &sn, &cs);
-  return (idx & 1) ? r * sn : r * cs;
+  // Box-Muller on two 32-bit uniforms with the hardware log/sin/cos (fp32 accuracy is ample for a noise sample; parity runs
+  // supply their normals from the host instead), one of the two pairs by parity of idx
+  const uint32_t w0 = (idx & 1) ? c[2] : c[0], w1 = (idx & 1) ? c[3] : c[1];
+  const float u1 = ((float)(w0 >> 8) + 0.5f) * (1.0f / 16777216.0f);   // (0, 1)
+  const float u2 = (float)(w1 >> 8) * (1.0f / 16777216.0f);            // [0, 1) revolutions
+  const float r = sqrtf(-2.0f * __logf(u1));
+  return (double)(r * __builtin_amdgcn_cosf(u2));
 }
 
 #ifdef AOG_MAIN_TU
@@ -1034,28 +1036,43 @@ __global__ __launch_bounds__(512) void k_extrude16(ExtrudeArgs p, int B) {
   const int li = lane & 15, lk = lane >> 4;
   for (int r = 0; r < rounds; ++r) {
     auto cls = [&](int g) { return r < abs(s_dx[g]) ? 1 : (r < abs(s_dx[g]) + abs(s_dy[g]) ? 2 : 0); };
-    for (int g = 0; g < G; ++g) {
-      const int c = cls(g);
-      if (!c) continue;
-      const int env = env0 + g;
-      const bool horizontal = c == 1;
-      const bool flipped = horizontal ? s_dx[g] > 0 : s_dy[g] > 0;
-      const int nz = horizontal ? p.nz_h : p.nz_v;
-      const int32_t* st = horizontal ? p.stencil_h : p.stencil_v;
-      const double* master = p.master + (size_t)env * N * N;
-      const int ox = s_ox[g], oy = s_oy[g];
-      for (int k = threadIdx.x; k < nz; k += blockDim.x) {
-        int sy = st[k] / N, sx = st[k] - sy * N;
-        if (flipped) { sy = N - 1 - sy; sx = N - 1 - sx; }
-        int py = sy + oy, px = sx + ox;
-        if (py >= N) py -= N;
-        if (px >= N) px -= N;
-        zb[(size_t)g * zs + k] = master[(size_t)py * N + px];
+    // gather the stencil samples of all 16 envs in ONE flattened loop (env-major pairs, 4 independent loads in flight per
+    // thread); stencil coordinates come pre-split (sy << 16 | sx) so no integer division sits in front of the loads
+    for (int base = threadIdx.x; base < G * nzmax; base += 4 * blockDim.x) {
+      double v[4];
+      int dst[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = base + u * blockDim.x;
+        const int g = idx / nzmax, k = idx - g * nzmax;
+        dst[u] = -1;
+        v[u] = 0.0;
+        if (idx < G * nzmax) {
+          const int c = cls(g);
+          const bool horizontal = c == 1;
+          const int nz = horizontal ? p.nz_h : p.nz_v;
+          if (c && k < nz) {
+            const uint32_t pk = (uint32_t)(horizontal ? p.stencil_h_yx : p.stencil_v_yx)[k];
+            int sy = (int)(pk >> 16), sx = (int)(pk & 0xFFFFu);
+            if (horizontal ? s_dx[g] > 0 : s_dy[g] > 0) { sy = N - 1 - sy; sx = N - 1 - sx; }
+            int py = sy + s_oy[g], px = sx + s_ox[g];
+            if (py >= N) py -= N;
+            if (px >= N) px -= N;
+            v[u] = p.master[(size_t)(env0 + g) * N * N + (size_t)py * N + px];
+            dst[u] = g * zs + k;
+          }
+        }
       }
-      const uint32_t ext = p.ext_counter[env] + (uint32_t)r;
-      for (int j = threadIdx.x; j < N; j += blockDim.x)
-        nb[(size_t)g * ns + j] = (p.noise && r < p.max_ext) ? p.noise[((size_t)env * p.max_ext + r) * N + j]
-                                                            : philox_normal(p.seed, (uint32_t)env, ext, (uint32_t)j);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (dst[u] >= 0) zb[dst[u]] = v[u];
+    }
+    for (int idx = threadIdx.x; idx < G * N; idx += blockDim.x) {
+      const int g = idx / N, j = idx - g * N;
+      if (!cls(g)) continue;
+      const int env = env0 + g;
+      nb[(size_t)g * ns + j] = (p.noise && r < p.max_ext) ? p.noise[((size_t)env * p.max_ext + r) * N + j]
+                                                          : philox_normal(p.seed, (uint32_t)env, p.ext_counter[env] + (uint32_t)r, (uint32_t)j);
     }
     __syncthreads();
     const int my_cls = cls(li);     // class of the env this lane feeds as the B operand / owns as the D column
@@ -1072,20 +1089,36 @@ __global__ __launch_bounds__(512) void k_extrude16(ExtrudeArgs p, int B) {
         const int row = rb * 16 + li;
         const bool row_ok = row < N;
         f64x4 accA = {0.0, 0.0, 0.0, 0.0}, accB = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-        for (int k0 = 0; k0 < nz; k0 += 4) {
-          const int k = k0 + lk;
-          const double a = (k < nz && row_ok) ? At[(size_t)k * N + row] : 0.0;
-          const double b = (k < nz && feed) ? zb[(size_t)li * zs + k] : 0.0;
-          accA = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, accA, 0, 0, 0);
-        }
-#pragma unroll 4
-        for (int j0 = 0; j0 < N; j0 += 4) {
-          const int j = j0 + lk;
-          const double a = (j < N && row_ok) ? Bt[(size_t)j * N + row] : 0.0;
-          const double b = (j < N && feed) ? nb[(size_t)li * ns + j] : 0.0;
-          accB = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, accB, 0, 0, 0);
-        }
+        // software pipeline: the 8 matrix loads of a 32-deep chunk are issued unconditionally (clamped index, masked by a
+        // multiplier) before any is consumed, so 8 L2 round trips overlap instead of serialising behind per-element branches
+        const int rowc = row_ok ? row : 0;
+        const double rmask = row_ok ? 1.0 : 0.0;
+        const double* zrow = zb + (size_t)li * zs;
+        const double* nrow = nb + (size_t)li * ns;
+        // two register sets: the loads of chunk n+1 are in flight while the 8 matrix instructions of chunk n issue
+        auto load_chunk = [&](const double* __restrict__ W, const double* __restrict__ vec, int K, int k0, double (&av)[8], double (&bv)[8]) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int k = k0 + 4 * u + lk;
+            const int kc = min(k, K - 1);
+            av[u] = W[(size_t)kc * N + rowc];
+            bv[u] = (k < K && feed) ? vec[kc] : 0.0;   // beyond K the B operand is zero: surplus chunks add nothing
+          }
+        };
+        auto run = [&](const double* __restrict__ W, const double* __restrict__ vec, int K, f64x4& acc) {
+          double a0[8], b0[8], a1[8], b1[8];
+          load_chunk(W, vec, K, 0, a0, b0);
+          for (int k0 = 0; k0 < K; k0 += 64) {
+            load_chunk(W, vec, K, k0 + 32, a1, b1);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u] * rmask, b0[u], acc, 0, 0, 0);
+            load_chunk(W, vec, K, k0 + 64, a0, b0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u] * rmask, b1[u], acc, 0, 0, 0);
+          }
+        };
+        run(At, zrow, nz, accA);
+        run(Bt, nrow, N, accB);
         // this lane holds column (env) li, rows rb*16 + lk + 4*q
         if (feed) {
           const int g = li;
