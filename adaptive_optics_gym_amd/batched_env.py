@@ -409,6 +409,40 @@ class BatchedAOEnv:
         _lib.check(self.lib.aog_focal_image(self._handle, int(env_index), C.c_void_p(out.data_ptr()), self._stream()))
         return torch.view_as_complex(out)
 
+    def phase_screen(self, env_index=0):
+        """Atmospheric phase at the sensing wavelength [N, N] float32 radians (0 outside the aperture, aperture mean removed) — the
+        quantity render() displays as ``phase_screen_opd`` after scaling by lambda_wfs / (2 pi) * 1e6 (AO_env.py:87-88)."""
+        torch = self._torch
+        N = self.num_pupil_pixels
+        out = torch.empty((N, N), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.aog_get_phase_screen(self._handle, int(env_index), C.c_void_p(out.data_ptr()), self._stream()))
+        return out
+
+    def get_state(self):
+        """Snapshot of everything that evolves: library state blob (screens, actuators, counters) + Python-side counters and the
+        host RNG streams.  ``set_state`` on an env built with the same arguments resumes bit-identically."""
+        torch = self._torch
+        n = int(self.lib.aog_state_bytes(self._handle))
+        blob = torch.empty((n,), dtype=torch.uint8, device=self.device)
+        ts = C.c_int64()
+        _lib.check(self.lib.aog_get_state(self._handle, C.c_void_p(blob.data_ptr()), C.byref(ts), self._stream()))
+        torch.cuda.current_stream(self.device).synchronize()
+        rng = [self._env_rng(e).get_state() for e in range(self.num_envs)] if self._host_rng else None
+        return {"blob": blob, "lib_timestep": int(ts.value), "timestep": self.timestep, "episode_no": self.episode_no, "rng": rng}
+
+    def set_state(self, state):
+        torch = self._torch
+        blob = state["blob"].to(self.device).contiguous()
+        if blob.numel() != int(self.lib.aog_state_bytes(self._handle)):
+            raise ValueError("state blob does not match this environment's configuration")
+        _lib.check(self.lib.aog_set_state(self._handle, C.c_void_p(blob.data_ptr()), int(state["lib_timestep"]), self._stream()))
+        torch.cuda.current_stream(self.device).synchronize()
+        self.timestep = int(state["timestep"])
+        self.episode_no = int(state["episode_no"])
+        if state.get("rng") is not None:
+            for e, st in enumerate(state["rng"]):
+                self._env_rng(e).set_state(st)
+
     def profile(self, enable=True):
         _lib.check(self.lib.aog_profile_enable(self._handle, int(bool(enable))))
 

@@ -780,6 +780,89 @@ int aog_sh_update(aog_env* e, const double* noisy_image_dev, double* action_dev,
   return AOG_OK;
 }
 
+namespace {
+struct StatePart {
+  void* ptr;
+  size_t bytes;
+};
+std::vector<StatePart> state_parts(const aog_env* e) {
+  std::vector<StatePart> v;
+  const size_t N2 = (size_t)e->cfg.n_pupil * e->cfg.n_pupil;
+  auto add = [&](void* p, size_t b) { if (p && b) v.push_back({p, b}); };
+  add(e->act_dm, sizeof(double) * e->B * e->A);
+  add(e->t_render, sizeof(int32_t) * e->B);
+  if (e->cfg.precision == AOG_PRECISION_FAST) {
+    add(e->psi_tile, sizeof(float) * (size_t)e->n_etiles * e->n_ptiles * 1024);
+    add(e->psi_rev, sizeof(float) * (size_t)e->n_quads * e->Bp * 4);
+  } else {
+    add(e->psi64, sizeof(double) * (size_t)e->B * e->n_ap);
+  }
+  if (e->cfg.atm_dynamic) {
+    add(e->psi_master, sizeof(double) * e->B * N2);
+    add(e->origin, sizeof(int32_t) * 2 * e->B);
+    add(e->ext_counter, sizeof(uint32_t) * e->B);
+    add(e->psi_offset, sizeof(double) * e->B);
+    add(e->psi_sum, sizeof(double) * e->B);
+  }
+  if (e->sh_ready) add(e->sh_act, sizeof(double) * e->B * e->A);
+  return v;
+}
+}  // namespace
+
+int64_t aog_state_bytes(const aog_env* e) {
+  if (!e) return -1;
+  int64_t n = 0;
+  for (const auto& p : state_parts(e)) n += (int64_t)((p.bytes + 255) / 256 * 256);
+  return n;
+}
+
+int aog_get_state(aog_env* e, void* blob_dev, int64_t* timestep_out, void* stream) {
+  if (!e || !blob_dev) return fail(AOG_ERR_INVALID, "aog_get_state: null argument");
+  HIP_TRY(hipSetDevice(e->device));
+  size_t off = 0;
+  for (const auto& p : state_parts(e)) {
+    HIP_TRY(hipMemcpyAsync(static_cast<char*>(blob_dev) + off, p.ptr, p.bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+    off += (p.bytes + 255) / 256 * 256;
+  }
+  if (timestep_out) *timestep_out = e->timestep;
+  return AOG_OK;
+}
+
+int aog_set_state(aog_env* e, const void* blob_dev, int64_t timestep, void* stream) {
+  if (!e || !blob_dev) return fail(AOG_ERR_INVALID, "aog_set_state: null argument");
+  if (!e->tables_ready) return fail(AOG_ERR_STATE, "aog_set_state before aog_upload_tables");
+  HIP_TRY(hipSetDevice(e->device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  size_t off = 0;
+  for (const auto& p : state_parts(e)) {
+    HIP_TRY(hipMemcpyAsync(p.ptr, static_cast<const char*>(blob_dev) + off, p.bytes, hipMemcpyDeviceToDevice, s));
+    off += (p.bytes + 255) / 256 * 256;
+  }
+  e->timestep = timestep;
+  // derived operand layouts follow the restored actuators
+  const int n = e->B * e->A_pad;
+  hipLaunchKernelGGL(aog::k_load_actuators, dim3((n + 255) / 256), dim3(256), 0, s, e->act_dm, e->act_rev, e->act16, e->B, e->A, e->A_pad, e->Bp,
+                     2.0 / e->cfg.wavelength_wfs);
+  HIP_TRY(hipGetLastError());
+  e->screens_ready = true;
+  return AOG_OK;
+}
+
+int aog_get_phase_screen(aog_env* e, int env_index, float* phase_dev, void* stream) {
+  if (!e || !phase_dev) return fail(AOG_ERR_INVALID, "aog_get_phase_screen: null argument");
+  if (!e->screens_ready) return fail(AOG_ERR_STATE, "aog_get_phase_screen before aog_set_screens");
+  if (e->cfg.precision != AOG_PRECISION_FAST) return fail(AOG_ERR_UNSUPPORTED, "aog_get_phase_screen: fast precision handles only");
+  if (env_index < 0 || env_index >= e->B) return fail(AOG_ERR_INVALID, "aog_get_phase_screen: env %d outside [0,%d)", env_index, e->B);
+  HIP_TRY(hipSetDevice(e->device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t N2 = (size_t)e->cfg.n_pupil * e->cfg.n_pupil;
+  HIP_TRY(hipMemsetAsync(phase_dev, 0, sizeof(float) * N2, s));
+  hipLaunchKernelGGL(aog::k_phase_screen, dim3((e->n_ap + 255) / 256), dim3(256), 0, s, e->psi_tile, e->ap_index, phase_dev, env_index, e->n_ap,
+                     e->n_ptiles);
+  HIP_TRY(hipGetLastError());
+  return AOG_OK;
+}
+
 int aog_get_actuators(aog_env* e, double* act_dev, void* stream) {
   if (!e || !act_dev) return fail(AOG_ERR_INVALID, "aog_get_actuators: null argument");
   HIP_TRY(hipSetDevice(e->device));

@@ -1617,6 +1617,16 @@ __global__ __launch_bounds__(256) void k_sh_estimate(ShEstimateArgs p) {
 }
 #endif  // AOG_MAIN_TU
 
+#ifdef AOG_MAIN_TU
+// atmosphere phase (radians at lambda_wfs) of one env on the full grid, from the tiled fp32 screens
+__global__ void k_phase_screen(const float* __restrict__ psi_tile, const int32_t* __restrict__ ap_index, float* __restrict__ out, int env,
+                               int n_ap, int n_ptiles) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_ap) return;
+  out[ap_index[p]] = 6.2831853071795865f * psi_tile[psi_tile_index(env, p, n_ptiles)];
+}
+#endif  // AOG_MAIN_TU
+
 // self-test hook: the three sin/cos flavours of the fused kernels on caller-supplied revolutions
 #ifdef AOG_MAIN_TU
 __global__ void k_selftest_sincos(const float* __restrict__ u, float* __restrict__ s, float* __restrict__ c, int n, int flavour) {

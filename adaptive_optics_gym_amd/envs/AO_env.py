@@ -58,8 +58,35 @@ class AOEnv(env_base()):
         self.last_strehl = float(info["strehl"][0].item())
         return obs[0].cpu().numpy(), float(reward[0].item()), d, False, {"power": float(info["power"][0].item())}
 
+    def render_data(self):
+        """The three images the reference's render() draws (AO_env.py:156-194), as numpy arrays: atmospheric phase screen OPD in
+        micrometres [N, N], sensing-arm focal-plane power [128, 128], photodetector (observation) power [o, o]."""
+        e = self._env
+        opd = e.phase_screen(0).cpu().numpy().astype(np.float64) * (e.wavelength_wfs / (2 * np.pi)) * 1e6
+        focal = (e.focal_image(0).abs() ** 2).cpu().numpy().astype(np.float64) * e.tables.focal_pixel_area
+        obs = np.asarray(self.last_obs_raw, dtype=np.float64).reshape(e.obs_dim, e.obs_dim)
+        return {"phase_screen_opd": opd, "focal_power": focal, "obs_power": obs}
+
     def render(self, close=False):
-        raise NotImplementedError("render() (matplotlib UI, AO_env.py:156-194) is outside the device hot path")
+        """AO_env.py:156-194 with matplotlib when it is importable; always returns ``render_data()``."""
+        data = self.render_data()
+        try:
+            import matplotlib.pyplot as plt
+        except Exception:
+            return data
+        plt.suptitle("episode %d - timestep %d / %d" % (self.episode_no + 1, self.timestep_render + 1, self.max_steps))
+        plt.subplots_adjust(wspace=1, hspace=1)
+        for pos, key, title, kw in ((1, "phase_screen_opd", "Atmospheric phase screen $ [\\mu m]$", dict(vmin=-6, vmax=6, cmap="RdBu")),
+                                    (3, "focal_power", "Wavefront power on focal plane", dict(vmin=0)),
+                                    (4, "obs_power", "Wavefront power on photodetector", dict(vmin=0))):
+            plt.subplot(2, 2, pos)
+            plt.title(title)
+            plt.imshow(data[key], origin="lower", **kw)
+            plt.colorbar()
+        plt.show(block=False)
+        plt.pause(0.05)
+        plt.clf()
+        return data
 
     def SH_step(self):
         """AO_env.py:254-290: (actuators [A] float64, torch.tensor([1]))."""

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define AOG_ABI_VERSION 8
+#define AOG_ABI_VERSION 9
 
 typedef struct aog_env aog_env;
 
@@ -180,6 +180,18 @@ int aog_sh_image(aog_env* env, double* image_dev, void* stream);
  * are also returned in action_dev [B][A] float64 (the action SH_step hands to step()).  noisy_image_dev: the image after the
  * caller's own large_poisson (parity with a host RNG stream), or NULL = photon noise from the handle's Philox stream. */
 int aog_sh_update(aog_env* env, const double* noisy_image_dev, double* action_dev, void* stream);
+
+/* Checkpointing (the reference has none for the env): every piece of per-env state the handle owns — screens
+ * (and ring-buffer origins / RNG stream positions for dynamic handles), mirror and Shack-Hartmann actuators, per-episode step
+ * counters — as one opaque device blob of aog_state_bytes() bytes, plus the global step counter.  A blob is only valid for a
+ * handle created with the same configuration. */
+int64_t aog_state_bytes(const aog_env* env);
+int aog_get_state(aog_env* env, void* blob_dev, int64_t* timestep_out, void* stream);
+int aog_set_state(aog_env* env, const void* blob_dev, int64_t timestep, void* stream);
+
+/* The sensing-arm pupil phase of one env in radians on the full N x N grid (0 outside the aperture, aperture mean removed):
+ * atmosphere only (what render() shows as the phase screen, AO_env.py:87-88,128-129).  float32 [N*N]. */
+int aog_get_phase_screen(aog_env* env, int env_index, float* phase_dev, void* stream);
 
 /* deformable_mirror.actuators for all envs (metres; AO_env.py:116).  [B][A] float64 device pointers. */
 int aog_get_actuators(aog_env* env, double* act_dev, void* stream);

@@ -627,3 +627,62 @@ def test_shack_hartmann_device_noise_closed_loop():
         s.append(env.step(a)[4]["strehl"].cpu().numpy())
     assert np.all(s[-1] > s[0]) and np.all(s[-1] <= 1.0)
     env.close()
+
+
+def test_state_save_restore_resumes_bit_identically():
+    """get_state / set_state (checkpointing; the reference has none for the env): a dynamic-atmosphere batch with Shack-Hartmann
+    state resumes from a snapshot with bit-identical observations, rewards and screens."""
+    torch = _torch()
+    from adaptive_optics_gym_amd import BatchedAOEnv
+
+    def make():
+        return BatchedAOEnv(5, "cuda:0", atm_type="dynamic", atm_vel=30, atm_fried=0.15, act_dim=8, act_type="zernike", obs_dim=2,
+                            num_pupil_pixels=48, timesteps_per_episode=4, seed=9, screen_oversampling=4, SH_operation=True, verbose=False)
+
+    env = make()
+    env.reset()
+    def run(e, n):
+        out = []
+        for _ in range(n):
+            a, _ = e.SH_step()
+            o, r, d, _, info = e.step(a)
+            out.append((o.cpu().numpy().copy(), r.cpu().numpy().copy(), d.cpu().numpy().copy(), info["obs_raw"].cpu().numpy().copy()))
+            if bool(d.all()):
+                e.reset()
+        return out
+
+    run(env, 3)
+    snap = env.get_state()
+    first = run(env, 5)
+    scr_first = env.get_screens().cpu().numpy()
+    other = make()          # a different object: fresh handle, same configuration
+    other.set_state(snap)
+    second = run(other, 5)
+    for x, y in zip(first, second):
+        for u, v in zip(x, y):
+            np.testing.assert_array_equal(u, v)
+    np.testing.assert_array_equal(other.get_screens().cpu().numpy(), scr_first)
+    assert other.timestep == env.timestep
+    with pytest.raises(ValueError):
+        BatchedAOEnv(2, "cuda:0", act_dim=8, act_type="zernike", num_pupil_pixels=48, screens=smooth_screens(2, 48, 1), verbose=False).set_state(snap)
+    env.close(); other.close()
+
+
+def test_render_data_and_phase_screen():
+    _torch()
+    from adaptive_optics_gym_amd.envs import AOEnv
+
+    N = 64
+    scr = smooth_screens(1, N, 4)
+    env = AOEnv(act_dim=8, act_type="zernike", obs_dim=5, num_pupil_pixels=N, screens=scr, rng=np.random.RandomState(0), verbose=False)
+    env.reset()
+    env.step(np.ones(8, dtype=np.float32))
+    d = env.render_data()
+    assert d["phase_screen_opd"].shape == (N, N) and d["focal_power"].shape == (128, 128) and d["obs_power"].shape == (5, 5)
+    ap = env._env.tables.ap_index
+    expect = scr[0].ravel()[ap]
+    expect = (expect - expect.mean()) * 1e6 / (2 * np.pi)            # achromatic screen (phase x lambda) -> OPD in micrometres
+    np.testing.assert_allclose(d["phase_screen_opd"].ravel()[ap], expect, rtol=1e-5, atol=1e-6)
+    assert np.count_nonzero(np.delete(d["phase_screen_opd"].ravel(), ap)) == 0
+    assert abs(d["focal_power"].sum() - 1.0) < 0.2 and d["focal_power"].min() >= 0      # power-1 beam, most of it in the window
+    env.close()
