@@ -809,9 +809,17 @@ std::vector<StatePart> state_parts(const aog_env* e) {
 }
 }  // namespace
 
+namespace {
+struct StateTail {  // host-side counters that steer the device RNG streams; stored in the last 256 bytes of the blob
+  int64_t timestep;
+  uint64_t rng_seed;
+  uint32_t sh_calls, screen_generation;
+};
+}  // namespace
+
 int64_t aog_state_bytes(const aog_env* e) {
   if (!e) return -1;
-  int64_t n = 0;
+  int64_t n = 256;
   for (const auto& p : state_parts(e)) n += (int64_t)((p.bytes + 255) / 256 * 256);
   return n;
 }
@@ -824,6 +832,9 @@ int aog_get_state(aog_env* e, void* blob_dev, int64_t* timestep_out, void* strea
     HIP_TRY(hipMemcpyAsync(static_cast<char*>(blob_dev) + off, p.ptr, p.bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
     off += (p.bytes + 255) / 256 * 256;
   }
+  StateTail tail{e->timestep, e->rng_seed, e->sh_calls, e->screen_generation};
+  HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+  HIP_TRY(hipMemcpy(static_cast<char*>(blob_dev) + off, &tail, sizeof tail, hipMemcpyHostToDevice));
   if (timestep_out) *timestep_out = e->timestep;
   return AOG_OK;
 }
@@ -838,7 +849,13 @@ int aog_set_state(aog_env* e, const void* blob_dev, int64_t timestep, void* stre
     HIP_TRY(hipMemcpyAsync(p.ptr, static_cast<const char*>(blob_dev) + off, p.bytes, hipMemcpyDeviceToDevice, s));
     off += (p.bytes + 255) / 256 * 256;
   }
+  StateTail tail{};
+  HIP_TRY(hipStreamSynchronize(s));
+  HIP_TRY(hipMemcpy(&tail, static_cast<const char*>(blob_dev) + off, sizeof tail, hipMemcpyDeviceToHost));
   e->timestep = timestep;
+  e->rng_seed = tail.rng_seed;
+  e->sh_calls = tail.sh_calls;
+  e->screen_generation = tail.screen_generation;
   // derived operand layouts follow the restored actuators
   const int n = e->B * e->A_pad;
   hipLaunchKernelGGL(aog::k_load_actuators, dim3((n + 255) / 256), dim3(256), 0, s, e->act_dm, e->act_rev, e->act16, e->B, e->A, e->A_pad, e->Bp,

@@ -684,5 +684,5 @@ def test_render_data_and_phase_screen():
     expect = (expect - expect.mean()) * 1e6 / (2 * np.pi)            # achromatic screen (phase x lambda) -> OPD in micrometres
     np.testing.assert_allclose(d["phase_screen_opd"].ravel()[ap], expect, rtol=1e-5, atol=1e-6)
     assert np.count_nonzero(np.delete(d["phase_screen_opd"].ravel(), ap)) == 0
-    assert abs(d["focal_power"].sum() - 1.0) < 0.2 and d["focal_power"].min() >= 0      # power-1 beam, most of it in the window
+    assert 0.05 < d["focal_power"].sum() <= 1.0 and d["focal_power"].min() >= 0      # power-1 beam; the aberrated part misses the window
     env.close()
