@@ -443,6 +443,12 @@ class BatchedAOEnv:
             for e, st in enumerate(state["rng"]):
                 self._env_rng(e).set_state(st)
 
+    def device_status(self):
+        """Synchronise and return the library's sticky device status word (0 = fine)."""
+        v = C.c_int32()
+        _lib.check(self.lib.aog_device_status(self._handle, C.byref(v)))
+        return int(v.value)
+
     def profile(self, enable=True):
         _lib.check(self.lib.aog_profile_enable(self._handle, int(bool(enable))))
 

@@ -168,7 +168,7 @@ int pack_from_master(aog_env* e, int first, int count, hipStream_t s, bool per_s
   if (per_step && e->kernel == AOG_KERNEL_MFMA && e->cfg.precision == AOG_PRECISION_FAST && first == 0 && count == e->B) {
     // fast path: offsets = means measured by the previous repack, whole-row writes
     hipLaunchKernelGGL(aog::k_refresh_offsets, dim3((e->B + 255) / 256), dim3(256), 0, s, e->psi_offset, e->psi_sum, e->B, e->n_ap);
-    dim3 grid((e->n_ptiles + 1) / 2, e->n_etiles);
+    dim3 grid(((e->n_ptiles + 1) / 2 + aog::kRepackIters - 1) / aog::kRepackIters, e->n_etiles);
     hipLaunchKernelGGL(aog::k_repack_master, grid, dim3(256), 0, s, e->psi_master, e->origin, e->ap_index, e->psi_offset, e->psi_sum,
                        e->psi_tile, e->B, e->cfg.n_pupil, e->n_ap, e->n_ptiles, inv);
     HIP_TRY(hipGetLastError());
@@ -185,6 +185,11 @@ int pack_from_master(aog_env* e, int first, int count, hipStream_t s, bool per_s
 }
 
 // layer.t = timestep * delta_t (AO_env.py:125): wind extrusion of every env, then refresh the fp32 layouts
+constexpr size_t kLdsBytes = 160 * 1024;   // LDS per CU on gfx950
+size_t ext16_lds(const aog_env* e) {
+  return (size_t)aog::kExt16G * ((std::max(e->nz_v, e->nz_h) | 1) + (e->cfg.n_pupil | 1)) * sizeof(double);
+}
+
 int evolve_layer(aog_env* e, hipStream_t s) {
   if (!e->layer_ready) return fail(AOG_ERR_STATE, "dynamic atmosphere: aog_upload_layer / aog_set_wind not called");
   aog::ExtrudeArgs p{};
@@ -200,6 +205,10 @@ int evolve_layer(aog_env* e, hipStream_t s) {
   p.Bt_v = e->Bt_v;
   p.At_h = e->At_h;
   p.Bt_h = e->Bt_h;
+  p.Wa_v = e->Wa_v;
+  p.Wb_v = e->Wb_v;
+  p.Wa_h = e->Wa_h;
+  p.Wb_h = e->Wb_h;
   p.noise = e->next_noise;
   p.max_ext = e->next_noise_max_ext;
   p.N = e->cfg.n_pupil;
@@ -230,7 +239,19 @@ int evolve_layer(aog_env* e, hipStream_t s) {
       }
     hipLaunchKernelGGL(aog::k_extrude_finish, dim3((e->B + 255) / 256), dim3(256), 0, s, p, e->B);
     HIP_TRY(hipGetLastError());
-  } else if (!getenv("AOG_EXTRUDE_SIMPLE")) {
+  } else if (e->ext_bar && !getenv("AOG_EXTRUDE_SIMPLE") && !getenv("AOG_EXTRUDE_NOSPLIT") && ext16_lds(e) + (size_t)(aog::kExtKs - 1) * 4 * 256 * 8 <= kLdsBytes) {
+    // float64 matrix-core form with each 16-env group's rows split over four workgroups + group barrier
+    const size_t lds = ((size_t)aog::kExt16G * ((std::max(e->nz_v, e->nz_h) | 1) + (e->cfg.n_pupil | 1)) + (size_t)(aog::kExtKs - 1) * 4 * 256) * sizeof(double);
+    if (lds > 64 * 1024 && !e->extrude_split_attr_set) {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(aog::k_extrude16_split), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      e->extrude_split_attr_set = true;
+    }
+    HIP_TRY(hipMemsetAsync(e->ext_bar, 0, sizeof(unsigned) * round_up(e->n_ext_groups, 4), s));
+    p.origin = e->origin;
+    const int groups8 = round_up(e->n_ext_groups, 8);
+    hipLaunchKernelGGL(aog::k_extrude16_split, dim3(groups8 * aog::kExtParts), dim3(1024), lds, s, p, e->B, e->ext_perm, e->ext_bar, e->dev_status);
+    HIP_TRY(hipGetLastError());
+  } else if (!getenv("AOG_EXTRUDE_SIMPLE") && ext16_lds(e) <= kLdsBytes) {
     // default: float64 matrix-core form, 16 envs per workgroup (a workgroup owns whole envs: no cross-workgroup hazard)
     const size_t lds = (size_t)aog::kExt16G * ((std::max(e->nz_v, e->nz_h) | 1) + (e->cfg.n_pupil | 1)) * sizeof(double);
     if (lds > 64 * 1024 && !e->extrude_attr_set) {
@@ -381,12 +402,24 @@ int aog_create(const aog_config* cfg, int device, aog_env** out) {
   TRY_ALLOC(dev_alloc(e, &e->act_rev, (size_t)e->A_pad * e->Bp));
   TRY_ALLOC(dev_alloc(e, &e->act16, (size_t)e->n_etiles * e->A_pad * 32 * 2));
   TRY_ALLOC(dev_alloc(e, &e->t_render, e->B));
+  TRY_ALLOC(dev_alloc(e, &e->dev_status, 16));
   TRY_ALLOC(dev_alloc(e, &e->partials, e->partial_elems));
   if (cfg->atm_dynamic) {
     const size_t N2 = (size_t)cfg->n_pupil * cfg->n_pupil;
     TRY_ALLOC(dev_alloc(e, &e->psi_master, (size_t)e->B * N2));
     TRY_ALLOC(dev_alloc(e, &e->origin, (size_t)e->B * 2));
     TRY_ALLOC(dev_alloc(e, &e->origin_alt, (size_t)e->B * 2));
+    e->n_ext_groups = (e->B + aog::kExt16G - 1) / aog::kExt16G;
+    TRY_ALLOC(dev_alloc(e, &e->ext_bar, (size_t)round_up(e->n_ext_groups, 8)));
+    TRY_ALLOC(dev_alloc(e, &e->ext_perm, (size_t)e->n_ext_groups * aog::kExt16G));
+    {
+      std::vector<int32_t> ident((size_t)e->n_ext_groups * aog::kExt16G, -1);
+      for (int i = 0; i < e->B; ++i) ident[i] = i;
+      if (hipMemcpy(e->ext_perm, ident.data(), sizeof(int32_t) * ident.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        aog_destroy(e);
+        return fail(AOG_ERR_HIP, "aog_create: hipMemcpy failed");
+      }
+    }
     TRY_ALLOC(dev_alloc(e, &e->ext_counter, (size_t)e->B));
     TRY_ALLOC(dev_alloc(e, &e->velocity, (size_t)e->B * 2));
     TRY_ALLOC(dev_alloc(e, &e->psi_offset, (size_t)e->B));
@@ -555,7 +588,25 @@ int aog_upload_layer(aog_env* e, const aog_layer_tables* t) {
     HIP_TRY(hipMemcpy(*dst, tr.data(), sizeof(double) * tr.size(), hipMemcpyHostToDevice));
     return AOG_OK;
   };
+  // src [rows][cols] -> [row block][k / 8][lane = (k % 4) * 16 + row % 16][(k / 4) % 2], zero padded: one 16-B load per lane
+  // feeds the A operands of two consecutive v_mfma_f64_16x16x4 k-steps
+  auto upload_blocked = [&](const double* src, int rows, int cols, double** dst) -> int {
+    const int nrb = (rows + 15) / 16, k8 = (cols + 7) / 8;
+    std::vector<double> blk((size_t)nrb * k8 * 128, 0.0);
+    for (int r = 0; r < rows; ++r)
+      for (int c = 0; c < cols; ++c) {
+        const int lane = (c & 3) * 16 + (r & 15);
+        blk[(((size_t)(r >> 4) * k8 + (c >> 3)) * 64 + lane) * 2 + ((c >> 2) & 1)] = src[(size_t)r * cols + c];
+      }
+    if (!*dst && (rc = dev_alloc(e, dst, blk.size(), false)) != AOG_OK) return rc;
+    HIP_TRY(hipMemcpy(*dst, blk.data(), sizeof(double) * blk.size(), hipMemcpyHostToDevice));
+    return AOG_OK;
+  };
   if (e->layer_ready) return fail(AOG_ERR_STATE, "aog_upload_layer: already uploaded");
+  if ((rc = upload_blocked(t->A_vertical, N, e->nz_v, &e->Wa_v)) != AOG_OK) return rc;
+  if ((rc = upload_blocked(t->B_vertical, N, N, &e->Wb_v)) != AOG_OK) return rc;
+  if ((rc = upload_blocked(t->A_horizontal, N, e->nz_h, &e->Wa_h)) != AOG_OK) return rc;
+  if ((rc = upload_blocked(t->B_horizontal, N, N, &e->Wb_h)) != AOG_OK) return rc;
   if ((rc = upload_t(t->A_vertical, N, e->nz_v, &e->At_v)) != AOG_OK) return rc;
   if ((rc = upload_t(t->B_vertical, N, N, &e->Bt_v)) != AOG_OK) return rc;
   if ((rc = upload_t(t->A_horizontal, N, e->nz_h, &e->At_h)) != AOG_OK) return rc;
@@ -582,7 +633,26 @@ int aog_set_wind(aog_env* e, const double* velocity_dev, double max_abs_componen
   e->max_wind = max_abs_component;
   if (!e->cfg.atm_dynamic) return fail(AOG_ERR_STATE, "aog_set_wind: handle was not created with atm_dynamic = 1");
   HIP_TRY(hipSetDevice(e->device));
-  HIP_TRY(hipMemcpyAsync(e->velocity, velocity_dev, sizeof(double) * 2 * e->B, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  HIP_TRY(hipMemcpyAsync(e->velocity, velocity_dev, sizeof(double) * 2 * e->B, hipMemcpyDeviceToDevice, s));
+  // Group envs of similar per-step shift (|dx|, |dy|) for k_extrude16_split: a 16-env group runs max(|dx| + |dy|) rounds and a
+  // round whose envs are split between column and row extrusion costs two matrix passes.  Results do not depend on the grouping.
+  std::vector<double> v((size_t)2 * e->B);
+  HIP_TRY(hipMemcpyAsync(v.data(), velocity_dev, sizeof(double) * v.size(), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  std::vector<int32_t> perm((size_t)e->n_ext_groups * aog::kExt16G, -1);
+  std::vector<int32_t> order(e->B);
+  for (int i = 0; i < e->B; ++i) order[i] = i;
+  const double per_step = e->pitch > 0 ? e->delta_t / e->pitch : 1.0;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+    const double ax = std::fabs(v[2 * a]) * per_step, bx = std::fabs(v[2 * b]) * per_step;
+    const long qa = std::lround(ax * 2), qb = std::lround(bx * 2);   // half-pixel bins of |dx|, then by |dy|
+    if (qa != qb) return qa < qb;
+    return std::fabs(v[2 * a + 1]) < std::fabs(v[2 * b + 1]);
+  });
+  for (int i = 0; i < e->B; ++i) perm[i] = order[i];
+  HIP_TRY(hipMemcpyAsync(e->ext_perm, perm.data(), sizeof(int32_t) * perm.size(), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));
   return AOG_OK;
 }
 
@@ -877,6 +947,21 @@ int aog_get_phase_screen(aog_env* e, int env_index, float* phase_dev, void* stre
   hipLaunchKernelGGL(aog::k_phase_screen, dim3((e->n_ap + 255) / 256), dim3(256), 0, s, e->psi_tile, e->ap_index, phase_dev, env_index, e->n_ap,
                      e->n_ptiles);
   HIP_TRY(hipGetLastError());
+  return AOG_OK;
+}
+
+int aog_device_status(aog_env* e, int32_t* status_out) {
+  if (!e || !status_out) return fail(AOG_ERR_INVALID, "aog_device_status: null argument");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipDeviceSynchronize());
+  int v[16];
+  HIP_TRY(hipMemcpy(v, e->dev_status, sizeof v, hipMemcpyDeviceToHost));
+  *status_out = v[0];
+  if (getenv("AOG_EXTRUDE_TIMING")) {   // developer aid: phase clocks (10 ns ticks) of workgroup 0 of k_extrude16_split
+    if (v[1]) fprintf(stderr, "[aogym] extrude16_split WG0 ticks: gather %d noise %d compute %d barrier %d rounds %d\n", v[4], v[5], v[6], v[7], v[8]);
+    const int one = 1;
+    HIP_TRY(hipMemcpy(e->dev_status + 1, &one, sizeof one, hipMemcpyHostToDevice));
+  }
   return AOG_OK;
 }
 

@@ -78,8 +78,13 @@ struct aog_env {
   // dynamic atmosphere (cfg.atm_dynamic)
   bool layer_ready = false;
   bool extrude_attr_set = false;
+  bool extrude_split_attr_set = false;
   bool rounds_ok = false;        // stencils never sample the dropped row/column -> lock-step round kernel is race-free
   int32_t* origin_alt = nullptr; // second origin buffer (rounds ping-pong)
+  unsigned* ext_bar = nullptr;   // group-barrier tickets of k_extrude16_split (zeroed before every launch)
+  int* dev_status = nullptr;     // sticky device-side error word (1 = a bounded spin timed out)
+  int n_ext_groups = 0;
+  int32_t* ext_perm = nullptr;   // [n_ext_groups * 16] group slot -> env id, -1 = padding (envs sorted by wind, see aog_set_wind)
   double max_wind = 0;           // max |component| of any env's velocity (bounds the rounds per step)
   long long timestep = 0;        // AOEnv.timestep: monotone over episodes (AO_env.py:123)
   double* psi_master = nullptr;  // [B][N*N] float64 toroidal screens
@@ -96,6 +101,10 @@ struct aog_env {
   double* Bt_v = nullptr;        // [N][N]
   double* At_h = nullptr;
   double* Bt_h = nullptr;
+  double* Wa_v = nullptr;        // MFMA-blocked copies [row block][k/8][lane][2] (k_extrude16_split)
+  double* Wb_v = nullptr;
+  double* Wa_h = nullptr;
+  double* Wb_h = nullptr;
   int nz_v = 0, nz_h = 0;
   double sqrt_cn2 = 0, pitch = 0, delta_t = 0;
   const double* next_noise = nullptr;

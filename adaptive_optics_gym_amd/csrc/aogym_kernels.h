@@ -823,6 +823,10 @@ struct ExtrudeArgs {
   const double* Bt_v;        // [N][N]
   const double* At_h;
   const double* Bt_h;
+  const double* Wa_v;        // the same matrices blocked for the f64 MFMA A operand: [row block][k/8][lane][2]
+  const double* Wb_v;
+  const double* Wa_h;
+  const double* Wb_h;
   const double* noise;       // nullable: [B][max_ext][N]
   int N, nz_v, nz_h, max_ext;
   double t_prev, t_new, pitch, sqrt_cn2;
@@ -1160,6 +1164,222 @@ __global__ __launch_bounds__(512) void k_extrude16(ExtrudeArgs p, int B) {
 }
 #endif  // AOG_MAIN_TU
 
+// ---- same matrix-core extrusion with the rows of a 16-env group split over FOUR workgroups (all 256 CUs at B = 1024) ------
+// The four workgroups of a group gather the same stencil samples, each computes a quarter of the new slice's row blocks and
+// writes it in place; before the next round reads those rows they meet at a group barrier: plain stores -> every wave
+// s_waitcnt vmcnt(0) -> __syncthreads -> lane 0: agent-scope release fence, ticket add on the group's counter, relaxed poll
+// (bounded) until all four tickets of this round are in, agent-scope acquire fence -> __syncthreads (cdna_hip_programming.md
+// Guideline 16, counter form).  Counters are zeroed by a memset ahead of every launch.  Workgroup L sits on XCD L % 8; the map
+// below keeps a group's four workgroups on one XCD (speed only).  A timed-out spin sets *status and the kernel still terminates.
+constexpr int kExtParts = 4;
+constexpr int kExtKs = 4;   // slices of the contraction per row block (16 waves per workgroup)
+#ifdef AOG_MAIN_TU
+__global__ __launch_bounds__(1024) void k_extrude16_split(ExtrudeArgs p, int B, const int* __restrict__ perm, unsigned* __restrict__ bar, int* __restrict__ status) {
+  extern __shared__ double lds[];  // z [16][zs] | noise [16][ns] | partial sums [kExtKs-1][4][256]
+  constexpr int G = kExt16G;
+  const int N = p.N;
+  const int nzmax = max(p.nz_v, p.nz_h);
+  const int zs = nzmax | 1, ns = N | 1;
+  double* zb = lds;
+  double* nb = lds + (size_t)G * zs;
+  double* pb = nb + (size_t)G * ns;
+  __shared__ int s_ox[G], s_oy[G], s_dx[G], s_dy[G], s_env[G];
+  const int L = blockIdx.x;
+  const int part = (L >> 3) & (kExtParts - 1);
+  const int group = (L >> 5) * 8 + (L & 7);
+  const int env0 = group * G;
+  if (env0 >= B) return;   // whole groups only: no barrier partner is left waiting
+  if (threadIdx.x < G) {
+    const int env = perm[env0 + threadIdx.x];   // slot -> env id (envs of similar wind share a group); -1 = padding slot
+    int dx = 0, dy = 0, ox = 0, oy = 0;
+    s_env[threadIdx.x] = max(env, 0);
+    if (env >= 0) {
+      const double vx = p.velocity[2 * env], vy = p.velocity[2 * env + 1];
+      dx = (int)rint(vx * p.t_new / p.pitch) - (int)rint(vx * p.t_prev / p.pitch);
+      dy = (int)rint(vy * p.t_new / p.pitch) - (int)rint(vy * p.t_prev / p.pitch);
+      ox = p.origin[2 * env];
+      oy = p.origin[2 * env + 1];
+    }
+    s_dx[threadIdx.x] = dx; s_dy[threadIdx.x] = dy; s_ox[threadIdx.x] = ox; s_oy[threadIdx.x] = oy;
+  }
+  __syncthreads();
+  int rounds = 0;
+  for (int g = 0; g < G; ++g) rounds = max(rounds, abs(s_dx[g]) + abs(s_dy[g]));
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int rbl = wave & 3, ks = wave >> 2;   // 16 waves: 4 row blocks x 4 slices of the contraction
+  const int li = lane & 15, lk = lane >> 4;
+  const bool dbg = status[1] != 0 && blockIdx.x == 0 && threadIdx.x == 0;
+  long long tm[6] = {0, 0, 0, 0, 0, 0};
+  for (int r = 0; r < rounds; ++r) {
+    long long t0 = dbg ? wall_clock64() : 0;
+    auto cls = [&](int g) { return r < abs(s_dx[g]) ? 1 : (r < abs(s_dx[g]) + abs(s_dy[g]) ? 2 : 0); };
+    for (int base = threadIdx.x; base < G * nzmax; base += 4 * blockDim.x) {
+      double v[4];
+      int dst[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = base + u * blockDim.x;
+        const int g = idx / nzmax, k = idx - g * nzmax;
+        dst[u] = -1;
+        v[u] = 0.0;
+        if (idx < G * nzmax) {
+          const int c = cls(g);
+          const bool horizontal = c == 1;
+          const int nz = horizontal ? p.nz_h : p.nz_v;
+          if (c && k < nz) {
+            const uint32_t pk = (uint32_t)(horizontal ? p.stencil_h_yx : p.stencil_v_yx)[k];
+            int sy = (int)(pk >> 16), sx = (int)(pk & 0xFFFFu);
+            if (horizontal ? s_dx[g] > 0 : s_dy[g] > 0) { sy = N - 1 - sy; sx = N - 1 - sx; }
+            int py = sy + s_oy[g], px = sx + s_ox[g];
+            if (py >= N) py -= N;
+            if (px >= N) px -= N;
+            v[u] = p.master[(size_t)s_env[g] * N * N + (size_t)py * N + px];
+            dst[u] = g * zs + k;
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (dst[u] >= 0) zb[dst[u]] = v[u];
+    }
+    __syncthreads();
+    if (dbg) { long long t = wall_clock64(); tm[0] += t - t0; t0 = t; }
+    for (int idx = threadIdx.x; idx < G * N; idx += blockDim.x) {
+      const int g = idx / N, j = idx - g * N;
+      if (!cls(g)) continue;
+      const int env = s_env[g];
+      nb[(size_t)g * ns + j] = (p.noise && r < p.max_ext) ? p.noise[((size_t)env * p.max_ext + r) * N + j]
+                                                          : philox_normal(p.seed, (uint32_t)env, p.ext_counter[env] + (uint32_t)r, (uint32_t)j);
+    }
+    __syncthreads();
+    if (dbg) { long long t = wall_clock64(); tm[1] += t - t0; t0 = t; }
+    const int my_cls = cls(li);
+    for (int c = 1; c <= 2; ++c) {
+      bool any = false;
+      for (int g = 0; g < G; ++g) any |= cls(g) == c;
+      if (!any) continue;
+      const bool horizontal = c == 1;
+      const int nz = horizontal ? p.nz_h : p.nz_v;
+      const double2* WA = reinterpret_cast<const double2*>(horizontal ? p.Wa_h : p.Wa_v);
+      const double2* WB = reinterpret_cast<const double2*>(horizontal ? p.Wb_h : p.Wb_v);
+      const int nz8 = (nz + 7) >> 3, n8 = (N + 7) >> 3;
+      const bool feed = my_cls == c;
+      for (int rb0 = 0; rb0 * 16 < N; rb0 += 4 * kExtParts) {   // uniform trip count: the partial-sum exchange syncs inside
+        const int rb = rb0 + part * 4 + rbl;
+        const int rbc = rb * 16 < N ? rb : 0;   // waves past the last row block compute a dummy tile and store nothing
+        f64x4 accA = {0.0, 0.0, 0.0, 0.0}, accB = {0.0, 0.0, 0.0, 0.0};
+        const double* zrow = zb + (size_t)li * zs;
+        const double* nrow = nb + (size_t)li * ns;
+        // weights arrive MFMA-ready: one 16-B load per lane = the A operands of two consecutive k-steps (blocked on the host)
+        auto load_chunk = [&](const double2* __restrict__ W, int K8, const double* __restrict__ vec, int K, int k0, int kend, double (&av)[8], double (&bv)[8]) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int blk = min((k0 >> 3) + u, K8 - 1);
+            const double2 w = W[(size_t)blk * 64 + lane];
+            av[2 * u] = w.x;
+            av[2 * u + 1] = w.y;
+            const int ka = k0 + 8 * u + lk, kb = ka + 4;
+            bv[2 * u] = (ka < kend && feed) ? vec[min(ka, K - 1)] : 0.0;
+            bv[2 * u + 1] = (kb < kend && feed) ? vec[min(kb, K - 1)] : 0.0;
+          }
+        };
+        auto run = [&](const double2* __restrict__ W, int K8, const double* __restrict__ vec, int K, int kbeg, int kend, f64x4& acc) {
+          double a0[8], b0[8], a1[8], b1[8];
+          load_chunk(W, K8, vec, K, kbeg, kend, a0, b0);
+          for (int k0 = kbeg; k0 < kend; k0 += 64) {
+            load_chunk(W, K8, vec, K, k0 + 32, kend, a1, b1);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[u], acc, 0, 0, 0);
+            load_chunk(W, K8, vec, K, k0 + 64, kend, a0, b0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b1[u], acc, 0, 0, 0);
+          }
+        };
+        {
+          const int ka = ((nz + 32 * kExtKs - 1) / (32 * kExtKs)) * 32, kb = ((N + 32 * kExtKs - 1) / (32 * kExtKs)) * 32;
+          const int a0 = min(ks * ka, nz), a1 = min(a0 + ka, nz), b0 = min(ks * kb, N), b1 = min(b0 + kb, N);
+          if (a1 > a0) run(WA + (size_t)rbc * nz8 * 64, nz8, zrow, nz, a0, a1, accA);
+          if (b1 > b0) run(WB + (size_t)rbc * n8 * 64, n8, nrow, N, b0, b1, accB);
+        }
+        double part_v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) part_v[q] = accA[q] + accB[q] * p.sqrt_cn2;
+        if (ks > 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) pb[((size_t)(ks - 1) * 4 + rbl) * 256 + q * 64 + lane] = part_v[q];
+        }
+        __syncthreads();
+        if (ks == 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            for (int t = 0; t < kExtKs - 1; ++t) part_v[q] += pb[((size_t)t * 4 + rbl) * 256 + q * 64 + lane];
+        }
+        __syncthreads();
+        if (feed && ks == 0) {
+          const int g = li;
+          const bool flipped = horizontal ? s_dx[g] > 0 : s_dy[g] > 0;
+          int nox = s_ox[g], noy = s_oy[g];
+          if (horizontal) nox = flipped ? (nox + 1 == N ? 0 : nox + 1) : (nox == 0 ? N - 1 : nox - 1);
+          else noy = flipped ? (noy + 1 == N ? 0 : noy + 1) : (noy == 0 ? N - 1 : noy - 1);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int i = rb * 16 + lk + 4 * q;
+            if (i >= N) continue;
+            const double v = part_v[q];
+            int ly, lx;
+            if (horizontal) { ly = flipped ? N - 1 - i : i; lx = flipped ? N - 1 : 0; }
+            else { ly = flipped ? N - 1 : 0; lx = flipped ? N - 1 - i : i; }
+            int py = ly + noy, px = lx + nox;
+            if (py >= N) py -= N;
+            if (px >= N) px -= N;
+            p.master[(size_t)s_env[g] * N * N + (size_t)py * N + px] = v;
+          }
+        }
+      }
+    }
+    // ---- group barrier: this round's rows of all four workgroups are visible before anyone gathers again ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores
+    __syncthreads();
+    if (dbg) { long long t = wall_clock64(); tm[2] += t - t0; t0 = t; }
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_fetch_add(&bar[group], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned target = (unsigned)kExtParts * (unsigned)(r + 1);
+      unsigned spins = 0;
+      while (__hip_atomic_load(&bar[group], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1u << 24)) {   // ~seconds: a partner never arrived (not co-resident); flag it and carry on
+          atomicExch(status, 1);
+          break;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (dbg) { long long t = wall_clock64(); tm[3] += t - t0; t0 = t; }
+    if (threadIdx.x < G) {
+      const int g = threadIdx.x;
+      const int c = cls(g);
+      if (c == 1) s_ox[g] = s_dx[g] > 0 ? (s_ox[g] + 1 == N ? 0 : s_ox[g] + 1) : (s_ox[g] == 0 ? N - 1 : s_ox[g] - 1);
+      else if (c == 2) s_oy[g] = s_dy[g] > 0 ? (s_oy[g] + 1 == N ? 0 : s_oy[g] + 1) : (s_oy[g] == 0 ? N - 1 : s_oy[g] - 1);
+    }
+    __syncthreads();
+  }
+  if (dbg) {
+    for (int i = 0; i < 4; ++i) status[4 + i] += (int)tm[i];
+    status[8] += rounds;
+  }
+  if (part == 0 && threadIdx.x < G && perm[env0 + threadIdx.x] >= 0) {
+    const int g = threadIdx.x, env = s_env[g];
+    p.origin[2 * env] = s_ox[g];
+    p.origin[2 * env + 1] = s_oy[g];
+    p.ext_counter[env] += (uint32_t)(abs(s_dx[g]) + abs(s_dy[g]));
+  }
+}
+#endif  // AOG_MAIN_TU
+
 // ---- lock-step rounds: one launch = the r-th x (phase 0) or y (phase 1) extrusion of EVERY env --------------------------
 // out[row][env] = sum_k At[k][row] z_env[k] + sqrt(Cn^2) sum_j Bt[j][row] n_env[j]  is a [N x (nz+N)] x [(nz+N) x B] float64 matrix
 // product per round, so the AR matrices are streamed once per 32-env tile instead of once per env.  A workgroup owns a
@@ -1331,6 +1551,7 @@ __global__ void k_store_master(const T* __restrict__ psi, double* __restrict__ m
 // (coalesced along x), the block transposes through LDS and every wave then writes whole 1-KiB rows of psi_tile.
 // The piston offset subtracted is the aperture mean measured by the PREVIOUS repack (outputs are invariant to a global
 // phase; the offset only keeps the fp32 magnitudes small), and this pass accumulates the sums for the next one.
+constexpr int kRepackIters = 8;   // pixel-tile pairs per workgroup: one float64 atomic per (wave, env) per 8 x 64 pixels
 __global__ __launch_bounds__(256) void k_repack_master(const double* __restrict__ master, const int32_t* __restrict__ origin,
                                                         const int32_t* __restrict__ ap_index, const double* __restrict__ offset,
                                                         double* __restrict__ sum_next, float* __restrict__ psi_tile, int B, int N,
@@ -1338,46 +1559,59 @@ __global__ __launch_bounds__(256) void k_repack_master(const double* __restrict_
   constexpr int LD = 68;  // padded row (floats) of the [32 envs][64 pixels] staging tile
   __shared__ float stage[32 * LD];
   const int et = blockIdx.y;
-  const int pt0 = blockIdx.x * 2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int p = pt0 * 32 + lane;
-  // logical pupil coordinates of this lane's packed pixel (same for every env)
-  int iy = 0, ix = 0;
-  const bool valid_p = p < n_ap;
-  if (valid_p) {
-    const int flat = ap_index[p];
-    iy = flat / N;
-    ix = flat - iy * N;
-  }
+  int oy[8], ox[8];
+  double off[8], sum[8];
+  const double* base[8];
+#pragma unroll
   for (int q = 0; q < 8; ++q) {
-    const int e = wave * 8 + q;
-    const int env = et * 32 + e;
-    float out = 0.f;
-    if (env < B) {
-      double v = 0.0;
-      if (valid_p) {
-        int py = iy + origin[2 * env + 1], px = ix + origin[2 * env];
-        if (py >= N) py -= N;
-        if (px >= N) px -= N;
-        v = master[(size_t)env * N * N + (size_t)py * N + px];
-        out = (float)((v - offset[env]) * inv_two_pi_lambda);
-      }
-      double sum = v;
-      for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
-      if (lane == 0) atomicAdd(&sum_next[env], sum);
-    }
-    stage[e * LD + lane] = out;
+    const int env = min(et * 32 + wave * 8 + q, B - 1);
+    ox[q] = origin[2 * env];
+    oy[q] = origin[2 * env + 1];
+    off[q] = offset[env];
+    sum[q] = 0.0;
+    base[q] = master + (size_t)env * N * N;
   }
-  __syncthreads();
-  // rows of psi_tile: [et][pt][g][lane = 32 h + e][4]; this block owns pt0, pt0 + 1 (8 rows); wave w writes rows 2w, 2w+1
-  for (int rr = 0; rr < 2; ++rr) {
-    const int row = wave * 2 + rr, tl = row >> 2, g = row & 3;
-    const int pt = pt0 + tl;
-    if (pt >= n_ptiles) continue;
-    const int h = lane >> 5, e = lane & 31;
-    const float* src = stage + e * LD + tl * 32 + 8 * g + 4 * h;
-    float4 v = make_float4(src[0], src[1], src[2], src[3]);
-    reinterpret_cast<float4*>(psi_tile)[(((size_t)et * n_ptiles + pt) * 4 + g) * 64 + lane] = v;
+  for (int it = 0; it < kRepackIters; ++it) {
+    const int pt0 = (blockIdx.x * kRepackIters + it) * 2;
+    if (pt0 >= n_ptiles) break;   // uniform
+    const int p = pt0 * 32 + lane;
+    const bool valid_p = p < n_ap;
+    const int flat = ap_index[valid_p ? p : n_ap - 1];   // logical pupil coordinates of this lane's packed pixel (same for every env)
+    const int iy = flat / N, ix = flat - iy * N;
+    double v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {   // all eight loads in flight before anything consumes them
+      int py = iy + oy[q], px = ix + ox[q];
+      if (py >= N) py -= N;
+      if (px >= N) px -= N;
+      v[q] = base[q][(size_t)py * N + px];
+    }
+    if (it) __syncthreads();   // the previous iteration's rows have left the staging tile
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int e = wave * 8 + q;
+      const bool ok = valid_p && et * 32 + e < B;
+      sum[q] += ok ? v[q] : 0.0;
+      stage[e * LD + lane] = ok ? (float)((v[q] - off[q]) * inv_two_pi_lambda) : 0.f;
+    }
+    __syncthreads();
+    // rows of psi_tile: [et][pt][g][lane = 32 h + e][4]; this pass owns pt0, pt0 + 1 (8 rows); wave w writes rows 2w, 2w+1
+    for (int rr = 0; rr < 2; ++rr) {
+      const int row = wave * 2 + rr, tl = row >> 2, g = row & 3;
+      const int pt = pt0 + tl;
+      if (pt >= n_ptiles) continue;
+      const int h = lane >> 5, e = lane & 31;
+      const float* src = stage + e * LD + tl * 32 + 8 * g + 4 * h;
+      float4 w = make_float4(src[0], src[1], src[2], src[3]);
+      reinterpret_cast<float4*>(psi_tile)[(((size_t)et * n_ptiles + pt) * 4 + g) * 64 + lane] = w;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    double t = sum[q];
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o, 64);
+    if (lane == 0 && et * 32 + wave * 8 + q < B) atomicAdd(&sum_next[et * 32 + wave * 8 + q], t);
   }
 }
 

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define AOG_ABI_VERSION 9
+#define AOG_ABI_VERSION 10
 
 typedef struct aog_env aog_env;
 
@@ -137,7 +137,8 @@ typedef struct {
 int aog_upload_layer(aog_env* env, const aog_layer_tables* layer);
 
 /* layer.velocity of every env: [B][2] float64 (vx, vy) in m/s (hcipy draws the direction at construction).
- * max_abs_component >= max over envs of max(|vx|, |vy|): bounds the whole-pixel shifts per step. */
+ * max_abs_component >= max over envs of max(|vx|, |vy|): bounds the whole-pixel shifts per step.
+ * Reads the velocities back once to group envs of similar wind for the extrusion kernel: synchronises `stream`. */
 int aog_set_wind(aog_env* env, const double* velocity_dev, double max_abs_component, void* stream);
 
 /* Standard normals for the extrusions of the NEXT aog_step: [B][max_ext][N] float64, consumed in hcipy's order (x shifts
@@ -192,6 +193,10 @@ int aog_set_state(aog_env* env, const void* blob_dev, int64_t timestep, void* st
 /* The sensing-arm pupil phase of one env in radians on the full N x N grid (0 outside the aperture, aperture mean removed):
  * atmosphere only (what render() shows as the phase screen, AO_env.py:87-88,128-129).  float32 [N*N]. */
 int aog_get_phase_screen(aog_env* env, int env_index, float* phase_dev, void* stream);
+
+/* Synchronises the device and returns the handle's sticky device-side status word: 0 = fine, 1 = a bounded inter-workgroup wait
+ * timed out (results of that step are invalid). */
+int aog_device_status(aog_env* env, int32_t* status_out);
 
 /* deformable_mirror.actuators for all envs (metres; AO_env.py:116).  [B][A] float64 device pointers. */
 int aog_get_actuators(aog_env* env, double* act_dev, void* stream);

@@ -450,15 +450,17 @@ def test_focal_image_matches_literal_propagation(precision):
 
 
 def test_dynamic_extrusion_kernel_variants_agree(monkeypatch):
-    """The three extrusion kernels — float64 matrix-core form (default), per-group vector form (AOG_EXTRUDE_SIMPLE) and the
+    """The four extrusion kernels — float64 matrix-core form with a group's rows split over four workgroups and a group barrier
+    (default), the same in one workgroup per group (AOG_EXTRUDE_NOSPLIT), per-group vector form (AOG_EXTRUDE_SIMPLE) and the
     lock-step round form (AOG_EXTRUDE_ROUNDS) — give the same screens on the same Philox stream (only the float64 summation
-    order differs)."""
+    order differs; the two matrix-core forms agree to 1e-12), and no inter-workgroup wait timed out."""
     torch = _torch()
     from adaptive_optics_gym_amd import BatchedAOEnv
 
     def run(mode):
         monkeypatch.delenv("AOG_EXTRUDE_ROUNDS", raising=False)
         monkeypatch.delenv("AOG_EXTRUDE_SIMPLE", raising=False)
+        monkeypatch.delenv("AOG_EXTRUDE_NOSPLIT", raising=False)
         if mode:
             monkeypatch.setenv(mode, "1")
         env = BatchedAOEnv(70, "cuda:0", atm_type="dynamic", atm_vel=35, atm_fried=0.15, act_dim=6, act_type="zernike", obs_dim=2,
@@ -469,14 +471,20 @@ def test_dynamic_extrusion_kernel_variants_agree(monkeypatch):
         for _ in range(7):
             obs = env.step(a)[4]["obs_raw"]
         out = env.get_screens().cpu().numpy(), obs.cpu().numpy()
+        assert env.device_status() == 0
         env.close()
         return out
 
     s_simple, o_simple = run("AOG_EXTRUDE_SIMPLE")
-    for mode in (None, "AOG_EXTRUDE_ROUNDS"):
+    s_split = None
+    for mode in (None, "AOG_EXTRUDE_NOSPLIT", "AOG_EXTRUDE_ROUNDS"):
         s_other, o_other = run(mode)
         np.testing.assert_allclose(s_other, s_simple, rtol=1e-9, atol=1e-12 * np.abs(s_simple).max())
         _assert_obs_close(o_other, o_simple)
+        if mode is None:
+            s_split = s_other
+        elif mode == "AOG_EXTRUDE_NOSPLIT":
+            np.testing.assert_allclose(s_other, s_split, rtol=1e-12, atol=1e-14 * np.abs(s_split).max())
 
 
 @pytest.mark.parametrize("precision", ["fast", "fp64"])

@@ -8,7 +8,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--B", type=int, default=1024); ap.add_argument("--N", type=int, default=256)
 ap.add_argument("--A", type=int, default=64); ap.add_argument("--o", type=int, default=2)
 ap.add_argument("--steps", type=int, default=20); ap.add_argument("--kernel", default="auto")
-ap.add_argument("--chunks", type=int, default=0); ap.add_argument("--atm", default="quasi_static"); ap.add_argument("--vel", type=float, default=0.0); ap.add_argument("--act_type", default="num_actuators")
+ap.add_argument("--chunks", type=int, default=0); ap.add_argument("--atm", default="quasi_static"); ap.add_argument("--vel", type=float, default=0.0); ap.add_argument("--act_type", default="num_actuators"); ap.add_argument("--wind_dir", type=float, default=None, help="degrees; same for every env (default: random per env)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 g = torch.Generator(dev).manual_seed(1)
@@ -17,15 +17,25 @@ scr = torch.nn.functional.interpolate(torch.randn(args.B, 1, 16, 16, device=dev,
                                       mode="bicubic").squeeze(1) * 2e-6
 env = BatchedAOEnv(args.B, dev, atm_type=args.atm, atm_vel=args.vel, num_pupil_pixels=args.N, act_dim=args.A, obs_dim=args.o, act_type=args.act_type,
                    timesteps_per_episode=1000000, kernel=args.kernel, pixel_chunks=args.chunks, screens=scr, verbose=False)
+if args.wind_dir is not None and args.atm == "dynamic":
+    import ctypes as C, numpy as np
+    from adaptive_optics_gym_amd import _lib
+    th = np.deg2rad(args.wind_dir)
+    env.velocity_vectors = float(env.velocity) * np.tile([[np.cos(th), np.sin(th)]], (args.B, 1))
+    v = torch.from_numpy(np.ascontiguousarray(env.velocity_vectors)).to(dev)
+    _lib.check(env.lib.aog_set_wind(env._handle, C.c_void_p(v.data_ptr()), float(np.abs(env.velocity_vectors).max()), env._stream()))
+    torch.cuda.synchronize()
 a = torch.randn(args.B, args.A, device=dev, generator=g) * 0.7071
 env.reset()
 for _ in range(3): env.step(a)
 torch.cuda.synchronize()
+env.device_status()
 env.profile(True)
 t0 = time.perf_counter()
 for _ in range(args.steps): env.step(a)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 ms, n = env.profile_read()
+env.device_status()
 print(f"B={args.B} N={args.N} A={args.A} o={args.o} kernel={env.info.kernel} chunks={env.info.pixel_chunks} "
       f"wall {args.B*args.steps/dt/1e6:.3f} Msteps/s  fused {ms*1e3:.1f} us -> {args.B/ms/1e3:.3f} Msteps/s", flush=True)
