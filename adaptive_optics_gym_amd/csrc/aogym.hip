@@ -190,6 +190,11 @@ size_t ext16_lds(const aog_env* e) {
   return (size_t)aog::kExt16G * ((std::max(e->nz_v, e->nz_h) | 1) + (e->cfg.n_pupil | 1)) * sizeof(double);
 }
 
+size_t ext_split_lds(const aog_env* e) {
+  return ((size_t)aog::kExt16G * (aog::ext_split_stride(std::max(e->nz_v, e->nz_h)) + aog::ext_split_stride(e->cfg.n_pupil)) +
+          (size_t)(aog::kExtKsMax - 1) * 4 * 256) * sizeof(double);
+}
+
 int evolve_layer(aog_env* e, hipStream_t s) {
   if (!e->layer_ready) return fail(AOG_ERR_STATE, "dynamic atmosphere: aog_upload_layer / aog_set_wind not called");
   aog::ExtrudeArgs p{};
@@ -239,17 +244,19 @@ int evolve_layer(aog_env* e, hipStream_t s) {
       }
     hipLaunchKernelGGL(aog::k_extrude_finish, dim3((e->B + 255) / 256), dim3(256), 0, s, p, e->B);
     HIP_TRY(hipGetLastError());
-  } else if (e->ext_bar && !getenv("AOG_EXTRUDE_SIMPLE") && !getenv("AOG_EXTRUDE_NOSPLIT") && ext16_lds(e) + (size_t)(aog::kExtKs - 1) * 4 * 256 * 8 <= kLdsBytes) {
+  } else if (e->ext_bar && !getenv("AOG_EXTRUDE_SIMPLE") && !getenv("AOG_EXTRUDE_NOSPLIT") && ext_split_lds(e) <= kLdsBytes) {
     // float64 matrix-core form with each 16-env group's rows split over four workgroups + group barrier
-    const size_t lds = ((size_t)aog::kExt16G * ((std::max(e->nz_v, e->nz_h) | 1) + (e->cfg.n_pupil | 1)) + (size_t)(aog::kExtKs - 1) * 4 * 256) * sizeof(double);
+    const size_t lds = ext_split_lds(e);
+    static const int ks = getenv("AOG_EXTRUDE_KS") ? atoi(getenv("AOG_EXTRUDE_KS")) : 2;
+    auto kern = ks == 4 ? aog::k_extrude16_split<4> : ks == 1 ? aog::k_extrude16_split<1> : aog::k_extrude16_split<2>;
     if (lds > 64 * 1024 && !e->extrude_split_attr_set) {
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(aog::k_extrude16_split), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       e->extrude_split_attr_set = true;
     }
     HIP_TRY(hipMemsetAsync(e->ext_bar, 0, sizeof(unsigned) * round_up(e->n_ext_groups, 4), s));
     p.origin = e->origin;
     const int groups8 = round_up(e->n_ext_groups, 8);
-    hipLaunchKernelGGL(aog::k_extrude16_split, dim3(groups8 * aog::kExtParts), dim3(1024), lds, s, p, e->B, e->ext_perm, e->ext_bar, e->dev_status);
+    hipLaunchKernelGGL(kern, dim3(groups8 * aog::kExtParts), dim3(256 * (ks == 4 ? 4 : ks == 1 ? 1 : 2)), lds, s, p, e->B, e->ext_perm, e->ext_bar, e->dev_status);
     HIP_TRY(hipGetLastError());
   } else if (!getenv("AOG_EXTRUDE_SIMPLE") && ext16_lds(e) <= kLdsBytes) {
     // default: float64 matrix-core form, 16 envs per workgroup (a workgroup owns whole envs: no cross-workgroup hazard)
@@ -958,7 +965,7 @@ int aog_device_status(aog_env* e, int32_t* status_out) {
   HIP_TRY(hipMemcpy(v, e->dev_status, sizeof v, hipMemcpyDeviceToHost));
   *status_out = v[0];
   if (getenv("AOG_EXTRUDE_TIMING")) {   // developer aid: phase clocks (10 ns ticks) of workgroup 0 of k_extrude16_split
-    if (v[1]) fprintf(stderr, "[aogym] extrude16_split WG0 ticks: gather %d noise %d compute %d barrier %d rounds %d\n", v[4], v[5], v[6], v[7], v[8]);
+    if (v[1]) fprintf(stderr, "[aogym] extrude16_split WG0 ticks: gather %d noise %d compute %d (matrix passes %d, exchange %d) barrier %d rounds %d\n", v[4], v[5], v[6], v[9], v[10], v[7], v[8]);
     const int one = 1;
     HIP_TRY(hipMemcpy(e->dev_status + 1, &one, sizeof one, hipMemcpyHostToDevice));
   }

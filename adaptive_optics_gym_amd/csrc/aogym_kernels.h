@@ -1172,21 +1172,28 @@ __global__ __launch_bounds__(512) void k_extrude16(ExtrudeArgs p, int B) {
 // Guideline 16, counter form).  Counters are zeroed by a memset ahead of every launch.  Workgroup L sits on XCD L % 8; the map
 // below keeps a group's four workgroups on one XCD (speed only).  A timed-out spin sets *status and the kernel still terminates.
 constexpr int kExtParts = 4;
-constexpr int kExtKs = 4;   // slices of the contraction per row block (16 waves per workgroup)
+__host__ __device__ inline int ext_split_stride(int n) { return ((n + 27) / 32) * 32 + 4; }   // smallest s >= n, s = 4 mod 32
+constexpr int kExtKsMax = 4;   // slices of the contraction per row block (template parameter KS: 4 KS waves per workgroup)
 #ifdef AOG_MAIN_TU
-__global__ __launch_bounds__(1024) void k_extrude16_split(ExtrudeArgs p, int B, const int* __restrict__ perm, unsigned* __restrict__ bar, int* __restrict__ status) {
-  extern __shared__ double lds[];  // z [16][zs] | noise [16][ns] | partial sums [kExtKs-1][4][256]
+template <int KS>
+__global__ __launch_bounds__(256 * KS) void k_extrude16_split(ExtrudeArgs p, int B, const int* __restrict__ perm, unsigned* __restrict__ bar, int* __restrict__ status) {
+  extern __shared__ double lds[];  // z [16][zs] | noise [16][ns] | partial sums [KS-1][4][256]
   constexpr int G = kExt16G;
   const int N = p.N;
   const int nzmax = max(p.nz_v, p.nz_h);
-  const int zs = nzmax | 1, ns = N | 1;
+  // row strides = 4 mod 32 doubles: the B-operand read (lane = 16 k + env, 8 B) then spreads over all banks (an odd stride
+  // puts env + k on the same bank pair: 4-way conflicts, as expensive as the matrix passes themselves)
+  const int zs = ext_split_stride(nzmax), ns = ext_split_stride(N);
   double* zb = lds;
   double* nb = lds + (size_t)G * zs;
   double* pb = nb + (size_t)G * ns;
   __shared__ int s_ox[G], s_oy[G], s_dx[G], s_dy[G], s_env[G];
   const int L = blockIdx.x;
   const int part = (L >> 3) & (kExtParts - 1);
-  const int group = (L >> 5) * 8 + (L & 7);
+  // groups are sorted by wind (aog_set_wind): an XCD takes a contiguous run of them, so its workgroups want the same class of
+  // matrices at the same time
+  const int groups_per_xcd = (int)gridDim.x >> 5;
+  const int group = (L & 7) * groups_per_xcd + (L >> 5);
   const int env0 = group * G;
   if (env0 >= B) return;   // whole groups only: no barrier partner is left waiting
   if (threadIdx.x < G) {
@@ -1206,7 +1213,7 @@ __global__ __launch_bounds__(1024) void k_extrude16_split(ExtrudeArgs p, int B, 
   int rounds = 0;
   for (int g = 0; g < G; ++g) rounds = max(rounds, abs(s_dx[g]) + abs(s_dy[g]));
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int rbl = wave & 3, ks = wave >> 2;   // 16 waves: 4 row blocks x 4 slices of the contraction
+  const int rbl = wave & 3, ks = wave >> 2;   // 4 KS waves: 4 row blocks x KS slices of the contraction
   const int li = lane & 15, lk = lane >> 4;
   const bool dbg = status[1] != 0 && blockIdx.x == 0 && threadIdx.x == 0;
   long long tm[6] = {0, 0, 0, 0, 0, 0};
@@ -1279,24 +1286,33 @@ __global__ __launch_bounds__(1024) void k_extrude16_split(ExtrudeArgs p, int B, 
             av[2 * u] = w.x;
             av[2 * u + 1] = w.y;
             const int ka = k0 + 8 * u + lk, kb = ka + 4;
-            bv[2 * u] = (ka < kend && feed) ? vec[min(ka, K - 1)] : 0.0;
-            bv[2 * u + 1] = (kb < kend && feed) ? vec[min(kb, K - 1)] : 0.0;
+            // unconditional reads, masked bitwise: a select here is turned back into a branch around the read, which
+            // serialises the chunk (every read then waits for its own lgkmcnt)
+            const long long za = __double_as_longlong(vec[min(ka, K - 1)]), zb2 = __double_as_longlong(vec[min(kb, K - 1)]);
+            bv[2 * u] = __longlong_as_double(za & -(long long)(ka < kend && feed));
+            bv[2 * u + 1] = __longlong_as_double(zb2 & -(long long)(kb < kend && feed));
           }
         };
         auto run = [&](const double2* __restrict__ W, int K8, const double* __restrict__ vec, int K, int kbeg, int kend, f64x4& acc) {
           double a0[8], b0[8], a1[8], b1[8];
           load_chunk(W, K8, vec, K, kbeg, kend, a0, b0);
           for (int k0 = kbeg; k0 < kend; k0 += 64) {
+            // the scheduling fences keep the next chunk's loads AHEAD of this chunk's matrix ops (left alone the compiler sinks
+            // every load to just before its use and the prefetch distance is gone)
             load_chunk(W, K8, vec, K, k0 + 32, kend, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[u], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
             load_chunk(W, K8, vec, K, k0 + 64, kend, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b1[u], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
           }
         };
         {
-          const int ka = ((nz + 32 * kExtKs - 1) / (32 * kExtKs)) * 32, kb = ((N + 32 * kExtKs - 1) / (32 * kExtKs)) * 32;
+          const int ka = ((nz + 32 * KS - 1) / (32 * KS)) * 32, kb = ((N + 32 * KS - 1) / (32 * KS)) * 32;
           const int a0 = min(ks * ka, nz), a1 = min(a0 + ka, nz), b0 = min(ks * kb, N), b1 = min(b0 + kb, N);
           if (a1 > a0) run(WA + (size_t)rbc * nz8 * 64, nz8, zrow, nz, a0, a1, accA);
           if (b1 > b0) run(WB + (size_t)rbc * n8 * 64, n8, nrow, N, b0, b1, accB);
@@ -1304,6 +1320,8 @@ __global__ __launch_bounds__(1024) void k_extrude16_split(ExtrudeArgs p, int B, 
         double part_v[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) part_v[q] = accA[q] + accB[q] * p.sqrt_cn2;
+        long long t1 = 0;
+        if (dbg) { t1 = wall_clock64(); tm[4] += t1 - t0; }
         if (ks > 0) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) pb[((size_t)(ks - 1) * 4 + rbl) * 256 + q * 64 + lane] = part_v[q];
@@ -1312,9 +1330,10 @@ __global__ __launch_bounds__(1024) void k_extrude16_split(ExtrudeArgs p, int B, 
         if (ks == 0) {
 #pragma unroll
           for (int q = 0; q < 4; ++q)
-            for (int t = 0; t < kExtKs - 1; ++t) part_v[q] += pb[((size_t)t * 4 + rbl) * 256 + q * 64 + lane];
+            for (int t = 0; t < KS - 1; ++t) part_v[q] += pb[((size_t)t * 4 + rbl) * 256 + q * 64 + lane];
         }
         __syncthreads();
+        if (dbg) tm[5] += wall_clock64() - t1;
         if (feed && ks == 0) {
           const int g = li;
           const bool flipped = horizontal ? s_dx[g] > 0 : s_dy[g] > 0;
@@ -1369,6 +1388,8 @@ __global__ __launch_bounds__(1024) void k_extrude16_split(ExtrudeArgs p, int B, 
   }
   if (dbg) {
     for (int i = 0; i < 4; ++i) status[4 + i] += (int)tm[i];
+    status[9] += (int)tm[4];
+    status[10] += (int)tm[5];
     status[8] += rounds;
   }
   if (part == 0 && threadIdx.x < G && perm[env0 + threadIdx.x] >= 0) {

@@ -27,14 +27,23 @@ if args.wind_dir is not None and args.atm == "dynamic":
     torch.cuda.synchronize()
 a = torch.randn(args.B, args.A, device=dev, generator=g) * 0.7071
 env.reset()
-for _ in range(3): env.step(a)
+for _ in range(20): env.step(a)
 torch.cuda.synchronize()
 env.device_status()
 env.profile(True)
+blocks = []
 t0 = time.perf_counter()
-for _ in range(args.steps): env.step(a)
-torch.cuda.synchronize()
+done = 0
+while done < args.steps:
+    nb = min(50, args.steps - done)
+    tb = time.perf_counter()
+    for _ in range(nb): env.step(a)
+    torch.cuda.synchronize()
+    blocks.append((time.perf_counter() - tb) / nb)
+    done += nb
 dt = time.perf_counter() - t0
+blocks.sort()
+print(f"per-step wall over blocks of <=50: min {blocks[0]*1e6:.1f} us  median {blocks[len(blocks)//2]*1e6:.1f} us  max {blocks[-1]*1e6:.1f} us")
 ms, n = env.profile_read()
 env.device_status()
 print(f"B={args.B} N={args.N} A={args.A} o={args.o} kernel={env.info.kernel} chunks={env.info.pixel_chunks} "
