@@ -74,6 +74,7 @@ SYMBOLS = {
     "aog_set_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "aog_get_phase_screen": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "aog_device_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "aog_debug_read_partials": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "aog_get_actuators": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "aog_set_actuators": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "aog_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -957,6 +957,14 @@ int aog_get_phase_screen(aog_env* e, int env_index, float* phase_dev, void* stre
   return AOG_OK;
 }
 
+int aog_debug_read_partials(aog_env* e, void* dst_host, size_t nbytes) {
+  if (!e || !dst_host) return fail(AOG_ERR_INVALID, "aog_debug_read_partials: null argument");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(dst_host, e->partials, nbytes, hipMemcpyDeviceToHost));
+  return AOG_OK;
+}
+
 int aog_device_status(aog_env* e, int32_t* status_out) {
   if (!e || !status_out) return fail(AOG_ERR_INVALID, "aog_device_status: null argument");
   HIP_TRY(hipSetDevice(e->device));

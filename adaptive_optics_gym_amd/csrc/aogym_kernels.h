@@ -291,6 +291,7 @@ __global__ __launch_bounds__(256) void k_fused_valu(const float* __restrict__ mo
 // ------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // Operands are pre-scaled into the middle of the f16 range so that neither half is ever subnormal for values that matter:
 //   modes (|M| <= 1) by 2^14, actuators in revolutions (|a| < 255) by 2^8;  u = psi + 2^-22 D1 + 2^-33 D2.
@@ -330,6 +331,11 @@ __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
+// fp32 partial sums of the table reduction are folded into the float64 accumulators every kFlushTiles tiles (16 pixels per lane
+// each): the conversions + float64 adds are half-rate vector work, 16 of ~115 issue cycles per (pixel, env) if done every tile
+constexpr int kFlushTiles = 4;
+constexpr int kSkewNops = 150;   // x 16 cycles: start-up skew of the second workgroup of a CU (about half a stage)
+
 template <int A_PAD, int MRW, int MRS, int SINCOS>
 struct Plan {
   static constexpr int MR = MRW + MRS, NS = 2 * MR;
@@ -339,7 +345,7 @@ struct Plan {
   static constexpr int LEAD_PCT = 40;
   static constexpr int PREFETCH_CAP = 4;
   static constexpr int U_SC = SINCOS == 0 ? 44 : (SINCOS == 1 ? 13 : 9);
-  static constexpr int U_TB = 9, N_FL = 3, U_FL = NS;
+  static constexpr int U_TB = 5, N_FL = 3, U_FL = NS / kFlushTiles + 1;
   static constexpr int N_OPS = 16 + 4 * MR + N_FL;
   struct Table {
     int type[N_OPS], a[N_OPS], b[N_OPS];
@@ -394,7 +400,8 @@ struct Plan {
 };
 
 // ABL (diagnostic builds only, never the product path): 1 = skip the matrix instructions, 2 = skip the vector work,
-// 3 = matrix instructions only with no global loads inside the loop, 4 = global loads only
+// 3 = matrix instructions only with no global loads inside the loop, 4 = global loads only, 5 = vector work only (no loads in the
+// loop, no matrix instructions), 6 = full kernel that records a per-wave timeline into `partials` (tools/fused_timeline.py)
 template <int A_PAD, int MRW, int MRS, int SINCOS, int ABL = 0>
 __global__ __launch_bounds__(256, (MRW <= 12 ? 2 : 1)) void k_fused_mfma(const f16x8* __restrict__ modes16, const f32x4* __restrict__ tabs_tile,
                                                     const f32x4* __restrict__ psi_tile, const f16x8* __restrict__ act16,
@@ -402,6 +409,7 @@ __global__ __launch_bounds__(256, (MRW <= 12 ? 2 : 1)) void k_fused_mfma(const f
   using PL = Plan<A_PAD, MRW, MRS, SINCOS>;
   constexpr int NS = PL::NS, MR = PL::MR, NSTEP = PL::NSTEP, NM = PL::NM, NSLOT = PL::NSLOT;
   constexpr int MAXTB = PL::T.max_tb;
+  const long long t_kernel = ABL == 6 ? wall_clock64() : 0;
   extern __shared__ f32x4 lds_tabs[];  // [tile in chunk][g][h][MR]
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -415,59 +423,84 @@ __global__ __launch_bounds__(256, (MRW <= 12 ? 2 : 1)) void k_fused_mfma(const f
   const int t0 = (int)(((long long)c * geo.n_ptiles) / geo.P);
   const int t1 = (int)(((long long)(c + 1) * geo.n_ptiles) / geo.P);
 
-  // stage this chunk's tables (contiguous in global memory) into LDS
-  {
-    const int n4 = (t1 - t0) * 8 * MR;
-    const f32x4* src = tabs_tile + (size_t)t0 * 8 * MR;
-    for (int i = threadIdx.x; i < n4; i += 256) lds_tabs[i] = src[i];
-  }
-  __syncthreads();
-  if (etile >= geo.n_etiles) return;
-
+  // Everything the first tile needs is requested BEFORE the chunk's tables are staged, so its latency overlaps the staging.
   const int h = lane >> 5;
+  const int etile_c = min(etile, geo.n_etiles - 1);   // waves past the last env tile load in-bounds dummies and leave after the barrier
+  const int first = t0 + w_p;
+  const int n = first < t1 ? (t1 - first + wp - 1) / wp : 0;
+  const int last = n > 0 ? first + (n - 1) * wp : min(t0, geo.n_ptiles - 1);   // loads clamp to it: always a valid tile
   f16x8 bh[NSTEP], bl[NSTEP];   // actuators of this env tile, hi / lo halves (B operand)
   {
-    const f16x8* asrc = act16 + ((size_t)etile * NSTEP * 2) * 64 + lane;
+    const f16x8* asrc = act16 + ((size_t)etile_c * NSTEP * 2) * 64 + lane;
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) {
       bh[s] = asrc[(2 * s) * 64];
       bl[s] = asrc[(2 * s + 1) * 64];
     }
   }
+  const size_t psi_base = (size_t)etile_c * geo.n_ptiles;
+  auto load_modes = [&](f16x8 (&mh)[NSTEP], f16x8 (&ml)[NSTEP], int t) {
+    const f16x8* ms = modes16 + ((size_t)min(t, last) * NSTEP * 2) * 64 + lane;
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+      mh[s] = ms[(2 * s) * 64];
+      ml[s] = ms[(2 * s + 1) * 64];
+    }
+  };
+  auto load_psi = [&](int t) {
+    const f32x4* ps = psi_tile + ((psi_base + min(t, last)) * 4) * 64 + lane;
+    f32x16 d;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 v = ps[g * 64];
+      d[4 * g + 0] = v[0]; d[4 * g + 1] = v[1]; d[4 * g + 2] = v[2]; d[4 * g + 3] = v[3];
+    }
+    return d;
+  };
+  f16x8 mh[NSTEP], ml[NSTEP];
+  load_modes(mh, ml, first);
+  f32x16 p_first = load_psi(first);
+  f32x16 p_next = load_psi(first + wp);   // the screen stream comes from HBM: kept TWO tiles ahead (the mode halves, shared by every
+                                          // env tile, are L2 hits and stay one tile ahead)
+  __builtin_amdgcn_sched_barrier(0);
+  // stage this chunk's tables (contiguous in global memory) into LDS, 8 loads in flight per thread
+  {
+    const int n4 = (t1 - t0) * 8 * MR;
+    const f32x4* src = tabs_tile + (size_t)t0 * 8 * MR;
+    for (int i0 = threadIdx.x; i0 < n4; i0 += 8 * 256) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[min(i0 + u * 256, n4 - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i0 + u * 256 < n4) lds_tabs[i0 + u * 256] = v[u];
+    }
+  }
+  __syncthreads();
+  if (etile >= geo.n_etiles) return;
+  // Workgroups j and j + 32 of an XCD share a CU (two passes of the dispatcher over its 32 CUs) and would run in lock step: both
+  // waves of every SIMD issuing their 12 loads, then both doing vector work.  Half a stage of skew lets one wave's load issue
+  // overlap the other's arithmetic.  The delay is a counted s_nop loop on purpose: with s_sleep here (loads of the first tiles
+  // still in flight) 16-lane pieces of those loads came back wrong, run to run — measured, not understood; never sleep with
+  // vector loads outstanding.
+  if constexpr (ABL == 0 || ABL == 6) {
+    if ((j & 32) != 0 && kSkewNops > 0) {
+      for (int q = 0; q < kSkewNops; ++q) asm volatile("s_nop 15");
+    }
+  }
+
   double acc[NS];
 #pragma unroll
   for (int i = 0; i < NS; ++i) acc[i] = 0.0;
-  float ts[NS];
+  f32x2 ts[MR];   // (sum cos * g, sum sin * g) of table m: one v_pk_fma_f32 per (pixel, table) feeds both halves
 #pragma unroll
-  for (int i = 0; i < NS; ++i) ts[i] = 0.f;
+  for (int i = 0; i < MR; ++i) ts[i] = f32x2{0.f, 0.f};
 
   // This wave's tiles: t0 + w_p + i*wp, i < n.  Stage i (all inside one wave):
-  //   issue the loads of tile i+1 (screen + mode halves), run slot 0 of tile i's vector work while they land, then the
+  //   issue the loads of tile i+1 (mode halves) and i+2 (screen), run slot 0 of tile i's vector work while they land, then the
   //   NM matrix instructions of tile i+1 with the rest of tile i's vector work dealt behind them, then
   //   d(i+1) = screen + D1 + 2^-11 D2.
-  const int first = t0 + w_p;
-  const int n = first < t1 ? (t1 - first + wp - 1) / wp : 0;
   if (n > 0) {
-    const size_t psi_base = (size_t)etile * geo.n_ptiles;
-    const int last = first + (n - 1) * wp;
-    auto load_modes = [&](f16x8 (&mh)[NSTEP], f16x8 (&ml)[NSTEP], int t) {
-      const f16x8* ms = modes16 + ((size_t)min(t, last) * NSTEP * 2) * 64 + lane;
-#pragma unroll
-      for (int s = 0; s < NSTEP; ++s) {
-        mh[s] = ms[(2 * s) * 64];
-        ml[s] = ms[(2 * s + 1) * 64];
-      }
-    };
-    auto load_psi = [&](int t) {
-      const f32x4* ps = psi_tile + ((psi_base + min(t, last)) * 4) * 64 + lane;
-      f32x16 d;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 v = ps[g * 64];
-        d[4 * g + 0] = v[0]; d[4 * g + 1] = v[1]; d[4 * g + 2] = v[2]; d[4 * g + 3] = v[3];
-      }
-      return d;
-    };
     // matrix instruction q of a tile: s = q / 3; (Mh.ah -> D1), (Mh.al -> D2), (Ml.ah -> D2)
     auto mfma_q = [&](auto qc, const f16x8 (&mh)[NSTEP], const f16x8 (&ml)[NSTEP], f32x16& d1, f32x16& d2) {
       constexpr int q = decltype(qc)::v, s = q / 3, w = q % 3;
@@ -478,7 +511,10 @@ __global__ __launch_bounds__(256, (MRW <= 12 ? 2 : 1)) void k_fused_mfma(const f
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     f32x16 d;                      // phases (revolutions at lambda_wfs) of the tile being reduced
-    float sw[2][4], cw[2][4], ss[2][4], cs[2][4];  // sincos of two register groups in flight
+    bool flush = false;            // does the tile being reduced end a group of kFlushTiles?
+    long long tdbg[4] = {0, 0, 0, 0};
+    const long long t_enter = ABL == 6 ? wall_clock64() : 0;
+    f32x2 ew[2][4], es[2][4];      // (cos, sin) at the sensing / science wavelength of two register groups in flight
     f32x4 gvb[2][MAXTB];           // table rows read one slot ahead
 
     // one micro-op of the plan, on tile `d` with table rows at `lt`; k < 0: unplanned (rows read in place)
@@ -489,14 +525,15 @@ __global__ __launch_bounds__(256, (MRW <= 12 ? 2 : 1)) void k_fused_mfma(const f
         constexpr int g = a >> 2, r = a & 3, par = g & 1;
         const float u = d[a];
         if constexpr (SINCOS == 2) {
-          sw[par][r] = __builtin_amdgcn_sinf(u);
-          cw[par][r] = __builtin_amdgcn_cosf(u);
+          ew[par][r] = f32x2{__builtin_amdgcn_cosf(u), __builtin_amdgcn_sinf(u)};
           const float us = u * ratio;
-          ss[par][r] = __builtin_amdgcn_sinf(us);
-          cs[par][r] = __builtin_amdgcn_cosf(us);
+          es[par][r] = f32x2{__builtin_amdgcn_cosf(us), __builtin_amdgcn_sinf(us)};
         } else {
-          sincos_rev<SINCOS>(u, sw[par][r], cw[par][r]);
-          sincos_rev<SINCOS>(u * ratio, ss[par][r], cs[par][r]);
+          float sn, cc;
+          sincos_rev<SINCOS>(u, sn, cc);
+          ew[par][r] = f32x2{cc, sn};
+          sincos_rev<SINCOS>(u * ratio, sn, cc);
+          es[par][r] = f32x2{cc, sn};
         }
       } else if constexpr (type == 1) {
         constexpr int g = a, m = bb, par = g & 1;
@@ -505,17 +542,18 @@ __global__ __launch_bounds__(256, (MRW <= 12 ? 2 : 1)) void k_fused_mfma(const f
         else gv = lt[(g * 2) * MR + m];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float cc = m < MRW ? cw[par][r] : cs[par][r];
-          const float sn = m < MRW ? sw[par][r] : ss[par][r];
-          ts[2 * m] = fmaf(cc, gv[r], ts[2 * m]);
-          ts[2 * m + 1] = fmaf(sn, gv[r], ts[2 * m + 1]);
+          const f32x2 e = m < MRW ? ew[par][r] : es[par][r];
+          ts[m] = __builtin_elementwise_fma(e, f32x2{gv[r], gv[r]}, ts[m]);
         }
       } else {
-        constexpr int lo = a * NS / PL::N_FL, hi = (a + 1) * NS / PL::N_FL;
+        constexpr int lo = a * MR / PL::N_FL, hi = (a + 1) * MR / PL::N_FL;
+        if (flush) {   // wave-uniform: the fp32 pair sums go to the float64 accumulators every kFlushTiles tiles
 #pragma unroll
-        for (int i = lo; i < hi; ++i) {
-          acc[i] += (double)ts[i];
-          ts[i] = 0.f;
+          for (int i = lo; i < hi; ++i) {
+            acc[2 * i] += (double)ts[i][0];
+            acc[2 * i + 1] += (double)ts[i][1];
+            ts[i] = f32x2{0.f, 0.f};
+          }
         }
       }
     };
@@ -538,23 +576,29 @@ __global__ __launch_bounds__(256, (MRW <= 12 ? 2 : 1)) void k_fused_mfma(const f
     };
     auto lds_row = [&](int t) { return lds_tabs + (size_t)(t - t0) * 8 * MR + h * MR; };
 
-    f16x8 mh[NSTEP], ml[NSTEP];
-    {  // first tile: nothing to overlap with
-      load_modes(mh, ml, first);
+    {  // first tile: nothing to overlap with (its operands were requested at kernel entry)
       f32x16 d1 = zero16, d2 = zero16;
       static_for<NM>([&](auto qc) { mfma_q(qc, mh, ml, d1, d2); });
-      d = d1 * kD1Unscale + (load_psi(first) + d2 * kD2Unscale);
+      d = d1 * kD1Unscale + (p_first + d2 * kD2Unscale);
     }
-    for (int i = 0, t = first; i + 1 < n; ++i, t += wp) {
-      f32x16 d1 = zero16, d2 = zero16, p;
-      if constexpr (ABL == 3) {
-        p = d;
+    if constexpr (ABL == 6) { asm volatile("" ::"v"(d[0])); tdbg[3] = wall_clock64(); }
+    // One stage: vector work of tile t, matrix work of tile t + wp; `p_use` already holds the screen of tile t + wp and the
+    // screen of tile t + 2 wp is requested into `p_load`.  The loop alternates the two register sets so that no copy (and with
+    // it no full drain of the loads just issued) sits between stages.
+    auto stage = [&](int i, int t, f32x16& p_use, f32x16& p_load) {
+      f32x16 d1 = zero16, d2 = zero16;
+      if constexpr (ABL == 3 || ABL == 5) {
+        p_use = d;
       } else {
-        p = load_psi(t + wp);             // consumed at the end of the stage
         load_modes(mh, ml, t + wp);       // consumed from slot 1 on
+        __builtin_amdgcn_sched_barrier(0);
+        p_load = load_psi(t + 2 * wp);    // issued AFTER the mode halves: vmcnt retires in order, and the matrix ops wait for those only
       }
       const f32x4* lt = lds_row(t);
-      if constexpr (ABL == 0 || ABL == 1) {
+      flush = (i % kFlushTiles) == kFlushTiles - 1;
+      long long tq0 = 0;
+      if constexpr (ABL == 6) tq0 = wall_clock64();
+      if constexpr (ABL == 0 || ABL == 1 || ABL >= 5) {
         fetch_rows(IC<0>{}, lt);
         fetch_rows(IC<1>{}, lt);
         run_slot(IC<0>{}, lt);
@@ -562,19 +606,38 @@ __global__ __launch_bounds__(256, (MRW <= 12 ? 2 : 1)) void k_fused_mfma(const f
         acc[0] += (double)d[0];
       }
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (ABL == 6) { const long long tq = wall_clock64(); tdbg[0] += tq - tq0; tq0 = tq; }
       static_for<NM>([&](auto qc) {
         constexpr int q = decltype(qc)::v, k = q + 1;
-        if constexpr (ABL != 1 && ABL != 4) mfma_q(qc, mh, ml, d1, d2);
+        if constexpr (ABL != 1 && ABL != 4 && ABL != 5) mfma_q(qc, mh, ml, d1, d2);
         else asm volatile("" ::"v"(mh[q / 3]), "v"(ml[q / 3]));
-        if constexpr (ABL == 0 || ABL == 1) {
+        if constexpr (ABL == 0 || ABL == 1 || ABL >= 5) {
           if constexpr (k + 1 < NSLOT) fetch_rows(IC<k + 1>{}, lt);
           run_slot(IC<k>{}, lt);
         }
         __builtin_amdgcn_sched_barrier(0);
       });
-      d = d1 * kD1Unscale + (p + d2 * kD2Unscale);
+      d = d1 * kD1Unscale + (p_use + d2 * kD2Unscale);
+      if constexpr (ABL == 6) { asm volatile("" ::"v"(d[0])); tdbg[1] += wall_clock64() - tq0; }
+    };
+    {
+      f32x16 p_alt = zero16;
+      int i = 0, t = first;
+      for (; i + 2 < n; i += 2, t += 2 * wp) {
+        stage(i, t, p_next, p_alt);
+        stage(i + 1, t + wp, p_alt, p_next);
+      }
+      if (i + 1 < n) stage(i, t, p_next, p_alt);
     }
+    if constexpr (ABL == 6) tdbg[2] = wall_clock64();
+    flush = true;
     reduce_plain(lds_row(last));
+    if constexpr (ABL == 6) {
+      if ((threadIdx.x & 63) == 0) {   // timeline record (overwrites the partial sums: this build's results are meaningless)
+        long long* rec = reinterpret_cast<long long*>(partials) + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;
+        rec[0] = t_enter; rec[1] = tdbg[0]; rec[2] = tdbg[1]; rec[3] = tdbg[2]; rec[4] = wall_clock64(); rec[5] = t_kernel; rec[6] = tdbg[3];
+      }
+    }
   }
   // the two half waves hold different pixels of the same 32 envs: fold h=1 into h=0, then store
   const int chunk = c * wp + w_p;

@@ -49,6 +49,8 @@ void launch_mfma(aog_env* e, hipStream_t s) {
     AOG_ABL_CASE(2)
     AOG_ABL_CASE(3)
     AOG_ABL_CASE(4)
+    AOG_ABL_CASE(5)
+    AOG_ABL_CASE(6)
 #undef AOG_ABL_CASE
   }
   hipLaunchKernelGGL((aog::k_fused_mfma<A_PAD, MRW, 1, SC>), grid, dim3(256), lds, s,

@@ -194,6 +194,10 @@ int aog_set_state(aog_env* env, const void* blob_dev, int64_t timestep, void* st
  * atmosphere only (what render() shows as the phase screen, AO_env.py:87-88,128-129).  float32 [N*N]. */
 int aog_get_phase_screen(aog_env* env, int env_index, float* phase_dev, void* stream);
 
+/* Developer aid: copies the first nbytes of the fused kernel's partial-sum buffer to host memory (synchronises).  With the
+ * AOG_ABLATE=6 diagnostic build of the fused kernel that buffer holds per-wave timeline records instead of sums. */
+int aog_debug_read_partials(aog_env* env, void* dst_host, size_t nbytes);
+
 /* Synchronises the device and returns the handle's sticky device-side status word: 0 = fine, 1 = a bounded inter-workgroup wait
  * timed out (results of that step are invalid). */
 int aog_device_status(aog_env* env, int32_t* status_out);
