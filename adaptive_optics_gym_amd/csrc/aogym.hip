@@ -154,8 +154,11 @@ int launch_epilogue(aog_env* e, bool is_step, float* obs_raw, uint16_t* obs, flo
   p.ssim_peak = e->cfg.ssim_ref_peak;
   p.ssim_alpha = e->cfg.ssim_alpha;
   const int NS = 2 * (p.MRW + p.MRS);
-  const size_t lds = ((size_t)(aog::kEpiQuarters * NS + p.n_obs) * aog::kEpiEnvs + (size_t)(p.n_obs + p.n_fiber) * p.MRW_used * 2 +
-                      (size_t)p.MRS_used * 2) * sizeof(double);
+  const size_t lds = aog::epilogue_lds_bytes(NS, p.n_obs, p.n_fiber, p.MRW_used, p.MRS_used);
+  if (lds > 64 * 1024 && !e->epilogue_attr_set) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(aog::k_epilogue), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    e->epilogue_attr_set = true;
+  }
   hipLaunchKernelGGL(aog::k_epilogue, dim3((e->Bp + aog::kEpiEnvs - 1) / aog::kEpiEnvs), dim3(1024), lds, s, p);
   HIP_TRY(hipGetLastError());
   return AOG_OK;
@@ -1032,7 +1035,9 @@ int aog_step(aog_env* e, const float* action, float* obs_raw, uint16_t* obs, flo
     int rce = evolve_layer(e, s);
     if (rce != AOG_OK) return rce;
   }
-  hipLaunchKernelGGL(aog::k_prologue, dim3(e->B), dim3(64), 0, s, action, e->gram, e->act_dm, e->act_rev, e->act16, e->A,
+  // each fused kernel reads one operand layout: write only that one (the float64 device kernel and the VALU kernel read act_rev)
+  const bool mfma_fast = e->kernel == AOG_KERNEL_MFMA && e->cfg.precision == AOG_PRECISION_FAST && !e->sh_ready;
+  hipLaunchKernelGGL(aog::k_prologue, dim3(e->B), dim3(64), 0, s, action, e->gram, e->act_dm, mfma_fast ? nullptr : e->act_rev, e->act16, e->A,
                      e->A_pad, e->Bp, e->cfg.sh_operation, e->cfg.surface_rms_target, 2.0 / e->cfg.wavelength_wfs);
   HIP_TRY(hipGetLastError());
   int rc = launch_fused(e, s);

@@ -78,6 +78,7 @@ struct aog_env {
   // dynamic atmosphere (cfg.atm_dynamic)
   bool layer_ready = false;
   bool extrude_attr_set = false;
+  bool epilogue_attr_set = false;
   bool extrude_split_attr_set = false;
   bool rounds_ok = false;        // stencils never sample the dropped row/column -> lock-step round kernel is race-free
   int32_t* origin_alt = nullptr; // second origin buffer (rounds ping-pong)

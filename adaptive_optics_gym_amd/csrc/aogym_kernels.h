@@ -156,9 +156,9 @@ __global__ __launch_bounds__(64) void k_prologue(const float* __restrict__ actio
   if (!sh_operation) {
     double part = 0;
     for (int i = lane; i < A; i += 64) {
-      const double* grow = gram + (size_t)i * A;
+      const double* gcol = gram + i;   // G is symmetric: column i read with the lanes along a row (coalesced)
       double r = 0;
-      for (int j = 0; j < A; ++j) r = fma(grow[j], ap[j], r);
+      for (int j = 0; j < A; ++j) r = fma(gcol[(size_t)j * A], ap[j], r);
       part = fma(ap[i], r, part);
     }
     for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(64) void k_prologue(const float* __restrict__ actio
     const double a = (i < A) ? ap[i] * scale : 0.0;
     if (i < A) act_dm[(size_t)env * A + i] = a;
     const float ar = (float)(a * two_over_lambda);
-    act_rev[(size_t)i * Bp + env] = ar;
+    if (act_rev) act_rev[(size_t)i * Bp + env] = ar;
     store_act16(act16, env, i, A_pad, ar);
   }
 }
@@ -767,91 +767,95 @@ __device__ inline double ssim_1d_delta_ref(const double* x, int stride, int n, d
   return sum / cnt;
 }
 
-// block = 16 envs x 16 sum slots x 4 chunk quarters (1024 threads, grid = ceil(Bp/16)): thread (e, q, cq) reduces sums
-// s = q, q+16, ... over chunks cq, cq+4, ... (8 independent loads in flight, 128-B coalesced rows); the quarters and the
-// sums meet in LDS, then the 16 threads with q == cq == 0 finish one env each.
-// dynamic LDS: (4 * NS + n_obs) * 16 doubles.
-constexpr int kEpiEnvs = 16;
-constexpr int kEpiQuarters = 4;
+// block = 4 envs x 16 sum slots x 16 chunk groups (1024 threads, grid = ceil(Bp / 4): 256 workgroups at B = 1024, one per CU):
+// thread (e, q, cq) adds sums s = q, q + 16, ... over chunks cq, cq + 16, ... (independent loads in flight); the chunk groups meet
+// in LDS; then one thread per (env, output) forms |coef . sums|^2, and one thread per env finishes reward / done / power.
+// dynamic LDS: see epilogue_lds_bytes().
+constexpr int kEpiEnvs = 4;
+constexpr int kEpiGroups = 16;
+constexpr int kEpiOutSlots = 16;   // threads per env in the output phase
+__host__ __device__ inline size_t epilogue_lds_bytes(int NS, int n_obs, int n_fiber, int MRW_used, int MRS_used) {
+  return ((size_t)kEpiGroups * NS * kEpiEnvs + (size_t)NS * kEpiEnvs + (size_t)(n_obs + n_fiber + 1) * kEpiEnvs +
+          (size_t)(n_obs + n_fiber) * MRW_used * 2 + (size_t)MRS_used * 2) * sizeof(double);
+}
 #ifdef AOG_MAIN_TU
 __global__ __launch_bounds__(1024) void k_epilogue(EpilogueArgs p) {
   extern __shared__ double sm[];
-  const int lane = threadIdx.x & (kEpiEnvs - 1);
-  const int wave = (threadIdx.x / kEpiEnvs) & 15;       // sum slot q
-  const int cq = threadIdx.x / (kEpiEnvs * 16);         // chunk quarter
-  const int nw = 16;
-  const int env = blockIdx.x * kEpiEnvs + lane;  // < Bp: padded envs read defined (ignored) slabs
+  const int e = threadIdx.x & (kEpiEnvs - 1);
+  const int q = (threadIdx.x / kEpiEnvs) & 15;            // sum slot
+  const int cq = threadIdx.x / (kEpiEnvs * 16);           // chunk group (= wave index)
+  const int env = blockIdx.x * kEpiEnvs + e;              // < Bp: padded envs read defined (ignored) slabs
   const int MR = p.MRW + p.MRS;
   const int NS = 2 * MR;
-  const size_t cstride = (size_t)NS * p.Bp;
-  double* part = sm + (size_t)(NS + p.n_obs) * kEpiEnvs;  // [quarter 1..3][NS][16]
-  // the small coefficient matrices go to LDS once (the finishing threads would otherwise chase them through L2 serially)
-  const int n_out_all = p.n_obs + p.n_fiber;
-  double* cfs = part + (size_t)(kEpiQuarters - 1) * NS * kEpiEnvs;  // [n_out][MRW_used][2] then [MRS_used][2]
-  for (int i = threadIdx.x; i < n_out_all * p.MRW_used * 2; i += blockDim.x) cfs[i] = p.wfs_coef[i];
-  double* cfsci = cfs + (size_t)n_out_all * p.MRW_used * 2;
-  for (int i = threadIdx.x; i < p.MRS_used * 2; i += blockDim.x) cfsci[i] = p.sci_coef[i];
-  for (int s = wave; s < NS; s += nw) {
-    const double* src = p.partials + (size_t)s * p.Bp + env;
-    double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int c = cq;
-    for (; c + 28 < p.n_chunks; c += 32) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) a[u] += src[(size_t)(c + 4 * u) * cstride];
-    }
-    for (; c < p.n_chunks; c += 4) a[0] += src[(size_t)c * cstride];
-    const double v = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-    if (cq == 0) sm[s * kEpiEnvs + lane] = v;
-    else part[((size_t)(cq - 1) * NS + s) * kEpiEnvs + lane] = v;
-  }
-  __syncthreads();
-  if (cq == 0) {
-    for (int s = wave; s < NS; s += nw) {
-      double v = sm[s * kEpiEnvs + lane];
-#pragma unroll
-      for (int k = 0; k < kEpiQuarters - 1; ++k) v += part[((size_t)k * NS + s) * kEpiEnvs + lane];
-      sm[s * kEpiEnvs + lane] = v;
-    }
-  }
-  __syncthreads();
-  if (wave != 0 || cq != 0 || env >= p.B) return;
-  const double* U = sm + lane;             // U_m = U[(2m) * kEpiEnvs], V_m = U[(2m + 1) * kEpiEnvs]
-  double* obsv = sm + (size_t)NS * kEpiEnvs + lane;  // obsv[j * kEpiEnvs]
-  double power = 0;
   const int n_out = p.n_obs + p.n_fiber;
-  for (int j = 0; j < n_out; ++j) {
-    double zr = 0, zi = 0;
-    const double* cf = cfs + (size_t)j * p.MRW_used * 2;
-    for (int m = 0; m < p.MRW_used; ++m) {
-      const double u = U[(2 * m) * kEpiEnvs], v = U[(2 * m + 1) * kEpiEnvs];
-      zr += cf[2 * m] * u - cf[2 * m + 1] * v;
-      zi += cf[2 * m] * v + cf[2 * m + 1] * u;
+  const size_t cstride = (size_t)NS * p.Bp;
+  double* part = sm;                                              // [group][NS][4]
+  double* U = part + (size_t)kEpiGroups * NS * kEpiEnvs;          // [NS][4]: U_m = U[(2m) * 4 + e], V_m = U[(2m + 1) * 4 + e]
+  double* pw = U + (size_t)NS * kEpiEnvs;                         // [n_out + 1][4]: powers of the outputs, then Strehl
+  double* cfs = pw + (size_t)(n_out + 1) * kEpiEnvs;              // [n_out][MRW_used][2] then [MRS_used][2]
+  double* cfsci = cfs + (size_t)n_out * p.MRW_used * 2;
+  // the small coefficient matrices go to LDS once (the output threads would otherwise chase them through L2 serially)
+  for (int i = threadIdx.x; i < n_out * p.MRW_used * 2; i += blockDim.x) cfs[i] = p.wfs_coef[i];
+  for (int i = threadIdx.x; i < p.MRS_used * 2; i += blockDim.x) cfsci[i] = p.sci_coef[i];
+  for (int s = q; s < NS; s += 16) {
+    const double* src = p.partials + (size_t)s * p.Bp + env;
+    double a[4] = {0, 0, 0, 0};
+    int c = cq;
+    for (; c + 3 * kEpiGroups < p.n_chunks; c += 4 * kEpiGroups) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a[u] += src[(size_t)(c + kEpiGroups * u) * cstride];
     }
-    const double pw = zr * zr + zi * zi;
-    if (j < p.n_obs) {
-      obsv[(size_t)j * kEpiEnvs] = pw;
-      if (p.obs_raw) p.obs_raw[(size_t)env * p.n_obs + j] = (float)pw;
-      if (p.obs) {
-        const _Float16 hv = (_Float16)pw;  // round-to-nearest-even from float64, like np.array(x, float16)
-        p.obs[(size_t)env * p.n_obs + j] = *reinterpret_cast<const uint16_t*>(&hv);
+    for (; c < p.n_chunks; c += kEpiGroups) a[0] += src[(size_t)c * cstride];
+    part[((size_t)cq * NS + s) * kEpiEnvs + e] = (a[0] + a[1]) + (a[2] + a[3]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NS * kEpiEnvs; i += blockDim.x) {
+    double v = 0;
+#pragma unroll
+    for (int g = 0; g < kEpiGroups; ++g) v += part[(size_t)g * NS * kEpiEnvs + i];
+    U[i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kEpiEnvs * kEpiOutSlots) {
+    const int oe = threadIdx.x & (kEpiEnvs - 1), slot = threadIdx.x / kEpiEnvs;
+    const int oenv = blockIdx.x * kEpiEnvs + oe;
+    for (int j = slot; j <= n_out; j += kEpiOutSlots) {
+      double zr = 0, zi = 0;
+      if (j < n_out) {
+        const double* cf = cfs + (size_t)j * p.MRW_used * 2;
+        for (int m = 0; m < p.MRW_used; ++m) {
+          const double u = U[(2 * m) * kEpiEnvs + oe], v = U[(2 * m + 1) * kEpiEnvs + oe];
+          zr += cf[2 * m] * u - cf[2 * m + 1] * v;
+          zi += cf[2 * m] * v + cf[2 * m + 1] * u;
+        }
+      } else {
+        for (int m = 0; m < p.MRS_used; ++m) {
+          const double u = U[(2 * (p.MRW + m)) * kEpiEnvs + oe], v = U[(2 * (p.MRW + m) + 1) * kEpiEnvs + oe];
+          zr += cfsci[2 * m] * u - cfsci[2 * m + 1] * v;
+          zi += cfsci[2 * m] * v + cfsci[2 * m + 1] * u;
+        }
       }
-    } else {
-      power += pw;
+      const double w = zr * zr + zi * zi;
+      pw[(size_t)j * kEpiEnvs + oe] = w;
+      if (j < p.n_obs && oenv < p.B) {
+        if (p.obs_raw) p.obs_raw[(size_t)oenv * p.n_obs + j] = (float)w;
+        if (p.obs) {
+          const _Float16 hv = (_Float16)w;  // round-to-nearest-even from float64, like np.array(x, float16)
+          p.obs[(size_t)oenv * p.n_obs + j] = *reinterpret_cast<const uint16_t*>(&hv);
+        }
+      }
     }
   }
-  if (!p.is_step) return;
-  double zr = 0, zi = 0;
-  for (int m = 0; m < p.MRS_used; ++m) {
-    const double u = U[(2 * (p.MRW + m)) * kEpiEnvs], v = U[(2 * (p.MRW + m) + 1) * kEpiEnvs];
-    zr += cfsci[2 * m] * u - cfsci[2 * m + 1] * v;
-    zi += cfsci[2 * m] * v + cfsci[2 * m + 1] * u;
-  }
-  const double strehl = zr * zr + zi * zi;
+  __syncthreads();
+  if (threadIdx.x >= kEpiEnvs || env >= p.B || !p.is_step) return;
+  double power = 0;
+  for (int j = p.n_obs; j < n_out; ++j) power += pw[(size_t)j * kEpiEnvs + e];
+  const double strehl = pw[(size_t)n_out * kEpiEnvs + e];
   double reward;
   if (p.reward_type == 0) {
     reward = -(100.0 - strehl * 100.0);
   } else {
-    const double ssim = ssim_1d_delta_ref(obsv, kEpiEnvs, p.n_obs, p.ssim_peak, p.n_obs / 2);
+    const double ssim = ssim_1d_delta_ref(pw + e, kEpiEnvs, p.n_obs, p.ssim_peak, p.n_obs / 2);
     reward = p.ssim_alpha * power + (1.0 - p.ssim_alpha) * ssim;
   }
   if (p.has_thr && reward < p.thr) reward = -1.0;
@@ -1741,7 +1745,8 @@ __global__ void k_focal_field(const float* __restrict__ psi_tile, const double* 
     rev = (psi64[(size_t)env * n_ap + p] + 4.0 * M_PI * surf) / (2.0 * M_PI * lambda_wfs);
   } else {
     double acc = (double)psi_tile[psi_tile_index(env, p, n_ptiles)];
-    for (int k = 0; k < A; ++k) acc = fma((double)modes_f32[(size_t)p * A_pad + k], (double)act_rev[(size_t)k * Bp + env], acc);
+    const double two_over_lambda = 2.0 / lambda_wfs;   // actuators (metres) -> revolutions per unit mode, as the prologue does
+    for (int k = 0; k < A; ++k) acc = fma((double)modes_f32[(size_t)p * A_pad + k], act_dm[(size_t)env * A + k] * two_over_lambda, acc);
     rev = acc;
   }
   double sn, cs;

@@ -8,7 +8,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--B", type=int, default=1024); ap.add_argument("--N", type=int, default=256)
 ap.add_argument("--A", type=int, default=64); ap.add_argument("--o", type=int, default=2)
 ap.add_argument("--steps", type=int, default=20); ap.add_argument("--kernel", default="auto")
-ap.add_argument("--chunks", type=int, default=0); ap.add_argument("--atm", default="quasi_static"); ap.add_argument("--vel", type=float, default=0.0); ap.add_argument("--act_type", default="num_actuators"); ap.add_argument("--wind_dir", type=float, default=None, help="degrees; same for every env (default: random per env)")
+ap.add_argument("--chunks", type=int, default=0); ap.add_argument("--atm", default="quasi_static"); ap.add_argument("--vel", type=float, default=0.0); ap.add_argument("--act_type", default="num_actuators"); ap.add_argument("--graph", action="store_true", help="replay one captured step (torch.cuda.CUDAGraph) instead of calling step()"); ap.add_argument("--wind_dir", type=float, default=None, help="degrees; same for every env (default: random per env)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 g = torch.Generator(dev).manual_seed(1)
@@ -31,13 +31,21 @@ for _ in range(20): env.step(a)
 torch.cuda.synchronize()
 env.device_status()
 env.profile(True)
+step = lambda: env.step(a)
+if args.graph:
+    g_ = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g_):
+        env.step(a)
+    step = g_.replay
+    for _ in range(5): step()
+    torch.cuda.synchronize()
 blocks = []
 t0 = time.perf_counter()
 done = 0
 while done < args.steps:
     nb = min(50, args.steps - done)
     tb = time.perf_counter()
-    for _ in range(nb): env.step(a)
+    for _ in range(nb): step()
     torch.cuda.synchronize()
     blocks.append((time.perf_counter() - tb) / nb)
     done += nb
