@@ -704,6 +704,56 @@ int aog_generate_screens(aog_env* e, int first, int count, int oversampling, dou
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int N = e->cfg.n_pupil, m = N * oversampling;
   if ((m & 1) != 0) return fail(AOG_ERR_UNSUPPORTED, "aog_generate_screens: odd FFT size");
+  // pruned synthesis (no (qN)^2 array): power-of-two N in [64, 512] and power-of-two oversampling
+  const bool pow2 = (N & (N - 1)) == 0 && (oversampling & (oversampling - 1)) == 0;
+  if (pow2 && N >= 64 && N <= 512 && !getenv("AOG_SCREENS_FULLFFT")) {
+    const size_t per_env = (size_t)m * N * 2;   // floats of T
+    int batch = (int)std::max<size_t>(1, std::min<size_t>((size_t)e->B, ((size_t)2 << 30) / (per_env * sizeof(float))));
+    if (e->syn_m != m) {   // (a different oversampling later on allocates afresh; the old workspace is released with the handle)
+      int rc;
+      e->syn_T = nullptr;
+      e->syn_out = nullptr;
+      if ((rc = dev_alloc(e, &e->syn_T, per_env * batch, false)) != AOG_OK) return rc;
+      if ((rc = dev_alloc(e, &e->syn_out, (size_t)batch * N * N, false)) != AOG_OK) return rc;
+      e->syn_batch = batch;
+      e->syn_m = m;
+    }
+    const double du = 2.0 * M_PI / ((double)m * pixel_pitch);
+    const double u0 = 2.0 * M_PI / outer_scale;
+    const double r0 = std::pow(0.423 * 4.0 * M_PI * M_PI, -3.0 / 5.0);
+    const double amp_scale = std::sqrt(0.0229 * std::pow(r0, -5.0 / 3.0)) * std::pow(2.0 * M_PI, 11.0 / 6.0) * (2.0 * M_PI) / du;
+    e->screen_generation += 1;
+    aog::ScreenSynthArgs a{};
+    a.T = reinterpret_cast<float2*>(e->syn_T);
+    a.out = e->syn_out;
+    a.N = N;
+    a.q = oversampling;
+    a.seed = e->rng_seed;
+    a.generation = e->screen_generation;
+    a.du = (float)du;
+    a.u0sq = (float)(u0 * u0);
+    a.amp_scale = (float)amp_scale;
+    a.crop_scale = (float)(std::sqrt(cn_squared) / ((double)m * m * pixel_pitch * pixel_pitch));
+    const size_t lds = (size_t)4 * 64 * 65 * sizeof(float);
+    const int R = N / 64;
+    auto rows = R == 1 ? aog::k_screen_rows<1> : R == 2 ? aog::k_screen_rows<2> : R == 4 ? aog::k_screen_rows<4> : aog::k_screen_rows<8>;
+    auto cols = R == 1 ? aog::k_screen_cols<1> : R == 2 ? aog::k_screen_cols<2> : R == 4 ? aog::k_screen_cols<4> : aog::k_screen_cols<8>;
+    if (!e->syn_attr_set) {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(rows), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(cols), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      e->syn_attr_set = true;
+    }
+    for (int done = 0; done < count; done += e->syn_batch) {
+      const int nb = std::min(e->syn_batch, count - done);
+      a.first_env = first + done;
+      hipLaunchKernelGGL(rows, dim3((m + 3) / 4, nb), dim3(256), lds, s, a);
+      hipLaunchKernelGGL(cols, dim3((N + 3) / 4, nb), dim3(256), lds, s, a);
+      HIP_TRY(hipGetLastError());
+      int rc = set_screens<float>(e, e->syn_out, first + done, nb, s);
+      if (rc != AOG_OK) return rc;
+    }
+    return AOG_OK;
+  }
   if (e->fft_m != m) {
     if (e->fft_plan) {
       hipfftDestroy((hipfftHandle)(uintptr_t)e->fft_plan);

@@ -60,6 +60,10 @@ struct aog_env {
   int fft_m = 0, fft_batch = 0;
   float* fft_work = nullptr;     // [fft_batch][m][m] complex64
   float* fft_crop = nullptr;     // [fft_batch][N][N]
+  float* syn_T = nullptr;        // pruned synthesis: [syn_batch][m][N] complex64 (lines after pass A)
+  float* syn_out = nullptr;      // [syn_batch][N][N]
+  int syn_batch = 0, syn_m = 0;
+  bool syn_attr_set = false;
   uint32_t screen_generation = 0;
   // focal-image export (optional)
   int n_focal = 0;

@@ -1823,6 +1823,244 @@ __global__ void k_screen_crop(const float2* __restrict__ field, float* __restric
 #endif  // AOG_MAIN_TU
 
 // ------------------------------------------------------------------------------------------------
+// K8 (pruned form)  The centred N x N crop of the (qN)^2 inverse transform never needs the (qN)^2 array in memory:
+//   out[i - N/2] = sum_{k < m} S[k] e^{2 pi i k (i - N/2) / m},  m = q N,  i < N.   With k = q a + b:
+//   out = sum_b e^{2 pi i b (i - N/2) / m} F_b[i],   F_b = length-N inverse DFT over a of  (-1)^a S[q a + b].
+// One wave = one line of length m.  Lane l holds a = l + 64 r (r < R = N / 64) for a group of b's; radix-R butterflies over r in
+// registers, twiddle, an LDS transpose so that every lane owns one 64-point sequence, a 64-point transform entirely in registers,
+// the b-twiddles by recurrence, a second LDS transpose and the sum over b.  Pass A (k_screen_rows) draws the spectrum line from
+// Philox on the fly (same counter -> sample mapping as k_spectrum_fill) and writes T[v][i]; pass B (k_screen_cols) runs the same
+// transform down the columns of T and writes Re(.) * scale.  Per env: 8 MB written + read instead of ~1 GB at N = 256, q = 16.
+// ------------------------------------------------------------------------------------------------
+struct cf32 { float x, y; };
+__device__ __forceinline__ cf32 cmul(cf32 a, cf32 b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+__device__ __forceinline__ cf32 cadd(cf32 a, cf32 b) { return {a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ cf32 csub(cf32 a, cf32 b) { return {a.x - b.x, a.y - b.y}; }
+struct Tw64 { float c[32][2]; };
+__device__ constexpr Tw64 kTw64 = {{{1.000000000e+00f, 0.000000000e+00f}, {9.951847267e-01f, 9.801714033e-02f}, {9.807852804e-01f, 1.950903220e-01f}, {9.569403357e-01f, 2.902846773e-01f}, {9.238795325e-01f, 3.826834324e-01f}, {8.819212643e-01f, 4.713967368e-01f}, {8.314696123e-01f, 5.555702330e-01f}, {7.730104534e-01f, 6.343932842e-01f}, {7.071067812e-01f, 7.071067812e-01f}, {6.343932842e-01f, 7.730104534e-01f}, {5.555702330e-01f, 8.314696123e-01f}, {4.713967368e-01f, 8.819212643e-01f}, {3.826834324e-01f, 9.238795325e-01f}, {2.902846773e-01f, 9.569403357e-01f}, {1.950903220e-01f, 9.807852804e-01f}, {9.801714033e-02f, 9.951847267e-01f}, {6.123233996e-17f, 1.000000000e+00f}, {-9.801714033e-02f, 9.951847267e-01f}, {-1.950903220e-01f, 9.807852804e-01f}, {-2.902846773e-01f, 9.569403357e-01f}, {-3.826834324e-01f, 9.238795325e-01f}, {-4.713967368e-01f, 8.819212643e-01f}, {-5.555702330e-01f, 8.314696123e-01f}, {-6.343932842e-01f, 7.730104534e-01f}, {-7.071067812e-01f, 7.071067812e-01f}, {-7.730104534e-01f, 6.343932842e-01f}, {-8.314696123e-01f, 5.555702330e-01f}, {-8.819212643e-01f, 4.713967368e-01f}, {-9.238795325e-01f, 3.826834324e-01f}, {-9.569403357e-01f, 2.902846773e-01f}, {-9.807852804e-01f, 1.950903220e-01f}, {-9.951847267e-01f, 9.801714033e-02f}}};
+constexpr int bitrev_c(int i, int bits) {
+  int r = 0;
+  for (int b = 0; b < bits; ++b) r |= ((i >> b) & 1) << (bits - 1 - b);
+  return r;
+}
+constexpr int log2_c(int n) { return n <= 1 ? 0 : 1 + log2_c(n / 2); }
+// in-register inverse DFT (e^{+}) of NP points, decimation in frequency: X[i] ends up in x[bitrev(i)].  All indices are compile-time.
+template <int NP>
+__device__ __forceinline__ void dft_reg(cf32 (&x)[NP]) {
+  static_for<log2_c(NP)>([&](auto sc) {
+    constexpr int half = NP >> (decltype(sc)::v + 1);
+    static_for<NP>([&](auto ic) {
+      constexpr int i = decltype(ic)::v;
+      if constexpr ((i & half) == 0) {
+        constexpr int j = i | half;
+        constexpr int k = (i & (half - 1)) * (32 / half);   // W_64^{k 64/(2 half)} = e^{2 pi i (i mod half) / (2 half)}
+        const cf32 a = x[i], b = x[j];
+        x[i] = cadd(a, b);
+        const cf32 t = csub(a, b);
+        if constexpr (k == 0) x[j] = t;
+        else if constexpr (k == 16) x[j] = cf32{-t.y, t.x};
+        else x[j] = cmul(t, cf32{kTw64.c[k][0], kTw64.c[k][1]});
+      }
+    });
+  });
+}
+
+struct ScreenSynthArgs {
+  float2* T;                 // [env in batch][m][N] complex64
+  float* out;                // [env in batch][N][N]
+  int N, q, first_env;
+  unsigned long long seed;
+  uint32_t generation;
+  float du, u0sq, amp_scale, crop_scale;
+};
+
+// the shared transform: `load(bb_global, r)` supplies sample (a = lane + 64 r, b = bb_global) already multiplied by (-1)^a;
+// on return acc[p] (p < R) holds out[(p + R * lane) - N/2 ... i.e. output index i = p + R * lane of the centred crop.
+template <int R, class Load>
+__device__ __forceinline__ void pruned_line(Load&& load, int q, int N, float* __restrict__ lbuf, cf32 (&acc)[R]) {
+  // lbuf: this wave's private [64][65] float plane; real and imaginary parts cross it one after the other (half the LDS of a
+  // complex plane: two workgroups fit a CU)
+  constexpr int BCmax = 64 / R;
+  const int lane = threadIdx.x & 63;
+  const int m = q * N;
+  const int BC = min(q, BCmax);
+  auto lds_fence = [] {
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS traffic has landed (the plane is private to the wave)
+    __builtin_amdgcn_wave_barrier();
+  };
+#pragma unroll
+  for (int p = 0; p < R; ++p) acc[p] = cf32{0.f, 0.f};
+  // W_N^{lane p}, p < R
+  cf32 wl[R];
+#pragma unroll
+  for (int p = 0; p < R; ++p) {
+    float sn, cs;
+    __sincosf(6.2831853071795865f * (float)(lane * p) / (float)N, &sn, &cs);
+    wl[p] = cf32{cs, sn};
+  }
+  for (int b0 = 0; b0 < q; b0 += BC) {
+    // 1) radix-R over r, twiddle, first transpose: sequence s = p * BC + bb holds one point per lane
+    cf32 z[64];
+    const bool active = lane < R * BC;
+    const float* row = lbuf + (size_t)(active ? lane : 0) * 65;
+    // imaginary parts wait in z[].y (not live yet) while the real parts cross; compile-time indices keep them in registers
+    static_for<BCmax>([&](auto bc) {
+      constexpr int bb = decltype(bc)::v;
+      if (bb < BC) {
+        cf32 x[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) x[r] = load(b0 + bb, r, IC<(bb & 1)>{});   // b0 is a multiple of BC: parity of b = parity of bb when q > 1
+        dft_reg<R>(x);
+#pragma unroll
+        for (int p = 0; p < R; ++p) {
+          const cf32 y = cmul(x[bitrev_c(p, log2_c(R))], wl[p]);
+          lbuf[(p * BC + bb) * 65 + lane] = y.x;
+          z[bb * R + p].y = y.y;
+        }
+      }
+    });
+    lds_fence();
+#pragma unroll
+    for (int t = 0; t < 64; ++t) z[t].x = row[t];
+    lds_fence();
+    static_for<BCmax>([&](auto bc) {
+      constexpr int bb = decltype(bc)::v;
+      if (bb < BC) {
+#pragma unroll
+        for (int p = 0; p < R; ++p) lbuf[(p * BC + bb) * 65 + lane] = z[bb * R + p].y;
+      }
+    });
+    lds_fence();
+#pragma unroll
+    for (int t = 0; t < 64; ++t) z[t].y = row[t];
+    // 2) every lane s < R * BC owns a 64-point sequence
+    dft_reg<64>(z);
+    // 3) b-twiddles e^{2 pi i b (i - N/2) / m}, i = p + R i2, by recurrence over i2 (exact restart every 16 steps)
+    const int p_of = lane / BC, b_of = b0 + (lane - p_of * BC);
+    cf32 tw, step;
+    {
+      float sn, cs;
+      __sincosf(6.2831853071795865f * (float)b_of * ((float)(p_of - N / 2) / (float)m), &sn, &cs);
+      tw = cf32{cs, sn};
+      __sincosf(6.2831853071795865f * (float)b_of * ((float)R / (float)m), &sn, &cs);
+      step = cf32{cs, sn};
+    }
+    static_for<64>([&](auto tc) {
+      constexpr int i2 = decltype(tc)::v;
+      z[bitrev_c(i2, 6)] = cmul(z[bitrev_c(i2, 6)], tw);
+      if constexpr ((i2 & 15) == 15 && i2 != 63) {
+        float sn, cs;
+        __sincosf(6.2831853071795865f * (float)b_of * ((float)(p_of + R * (i2 + 1) - N / 2) / (float)m), &sn, &cs);
+        tw = cf32{cs, sn};
+      } else {
+        tw = cmul(tw, step);
+      }
+    });
+    // 4) second transpose (real plane, then imaginary): lane j sums over the b's of this group for its R outputs i = p + R j
+    lds_fence();
+    static_for<64>([&](auto tc) {
+      constexpr int i2 = decltype(tc)::v;
+      if (active) lbuf[lane * 65 + i2] = z[bitrev_c(i2, 6)].x;
+    });
+    lds_fence();
+#pragma unroll
+    for (int p = 0; p < R; ++p) {
+      float sum = acc[p].x;
+      for (int bb = 0; bb < BC; ++bb) sum += lbuf[(p * BC + bb) * 65 + lane];
+      acc[p].x = sum;
+    }
+    lds_fence();
+    static_for<64>([&](auto tc) {
+      constexpr int i2 = decltype(tc)::v;
+      if (active) lbuf[lane * 65 + i2] = z[bitrev_c(i2, 6)].y;
+    });
+    lds_fence();
+#pragma unroll
+    for (int p = 0; p < R; ++p) {
+      float sum = acc[p].y;
+      for (int bb = 0; bb < BC; ++bb) sum += lbuf[(p * BC + bb) * 65 + lane];
+      acc[p].y = sum;
+    }
+    lds_fence();
+  }
+}
+
+// Pass A: grid (m / 4, envs in batch), 4 waves, one spectrum line v per wave.  LDS 4 x 64 x 65 x 4 B.
+template <int R>
+__global__ __launch_bounds__(256) void k_screen_rows(ScreenSynthArgs p) {
+  extern __shared__ float lds_syn[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int N = p.N, q = p.q, m = q * N;
+  const int v = blockIdx.x * 4 + wave;
+  const int b = blockIdx.y;
+  if (v >= m) return;
+  const float fv = p.du * (float)(v < m / 2 ? v : v - m);
+  const float sign = (lane & 1) ? -1.f : 1.f;   // (-1)^a, a = lane + 64 r
+  cf32 pending[R];   // second sample of the Philox pair drawn for (a, b even): consumed as (a, b + 1)
+  auto load = [&](int bg, int r, auto oddc) -> cf32 {
+    // samples come in Philox pairs (u even, u + 1): b even draws, b odd uses the second half
+    const int a = lane + 64 * r;
+    const int u = q * a + bg;
+    if constexpr (decltype(oddc)::v == 1) return pending[r];   // (only reached with q > 1: q = 1 has the single b = 0)
+    const size_t idx = (size_t)v * m + (u & ~1);
+    const size_t pair = idx >> 1;
+    uint32_t c[4] = {(uint32_t)pair, (uint32_t)(pair >> 32) ^ (p.generation * 0x9E3779B9u), (uint32_t)(p.first_env + b), 0x5C4EE7u};
+    uint32_t k0 = (uint32_t)p.seed, k1 = (uint32_t)(p.seed >> 32);
+#pragma unroll
+    for (int rr = 0; rr < 10; ++rr) {
+      philox_round(c, k0, k1);
+      k0 += 0x9E3779B9u;
+      k1 += 0xBB67AE85u;
+    }
+    cf32 o[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int uu = (u & ~1) + hh;
+      const float fu = p.du * (float)(uu < m / 2 ? uu : uu - m);
+      const float f2 = fu * fu + fv * fv;
+      // raw hardware transcendentals (v_log = log2, v_exp = 2^x, v_sqrt, v_sin / v_cos in revolutions): arguments are normal
+      // floats in range by construction (u1 in (0, 1), f2 + u0^2 > 0), the library forms' special-case handling is dead weight
+      const float amp = f2 == 0.f ? 0.f : p.amp_scale * __builtin_amdgcn_exp2f((-11.0f / 12.0f) * __builtin_amdgcn_logf(f2 + p.u0sq));
+      const float u1 = ((float)c[2 * hh] + 0.5f) * (1.0f / 4294967296.0f);
+      const float u2 = ((float)c[2 * hh + 1] + 0.5f) * (1.0f / 4294967296.0f);
+      const float rad = sign * amp * __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));   // sqrt(-2 ln u1)
+      o[hh] = cf32{rad * __builtin_amdgcn_cosf(u2), rad * __builtin_amdgcn_sinf(u2)};
+    }
+    if (q == 1) return o[u & 1];   // no oversampling: one sample per call (the pair partner belongs to the next a)
+    pending[r] = o[1];
+    return o[0];
+  };
+  cf32 acc[R];
+  pruned_line<R>(load, q, N, lds_syn + (size_t)wave * 64 * 65, acc);
+  float2* dst = p.T + ((size_t)b * m + v) * N + (size_t)R * lane;
+#pragma unroll
+  for (int pp = 0; pp < R; ++pp) dst[pp] = make_float2(acc[pp].x, acc[pp].y);
+}
+
+// Pass B: grid (N / 4, envs in batch), one column ix per wave; reads T[v][ix] (the 4 waves of a workgroup share its cache lines).
+template <int R>
+__global__ __launch_bounds__(256, 2) void k_screen_cols(ScreenSynthArgs p) {
+  extern __shared__ float lds_syn[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int N = p.N, q = p.q, m = q * N;
+  const int ix = blockIdx.x * 4 + wave;
+  const int b = blockIdx.y;
+  if (ix >= N) return;
+  const float sign = (lane & 1) ? -1.f : 1.f;
+  const float2* src = p.T + (size_t)b * m * N + ix;
+  auto load = [&](int bg, int r, auto) -> cf32 {
+    const int vv = q * (lane + 64 * r) + bg;
+    const float2 t = src[(size_t)vv * N];
+    return cf32{sign * t.x, sign * t.y};
+  };
+  cf32 acc[R];
+  pruned_line<R>(load, q, N, lds_syn + (size_t)wave * 64 * 65, acc);
+  float* dst = p.out + (size_t)b * N * N + ix;
+#pragma unroll
+  for (int pp = 0; pp < R; ++pp) dst[(size_t)(pp + R * lane) * N] = acc[pp].x * p.crop_scale;
+}
+
+// ------------------------------------------------------------------------------------------------
 // K10  Shack-Hartmann chain (AO_env.py:254-290): field on the magnified pupil x micro-lens phase -> angular-spectrum
 // Fresnel propagation over one lenslet focal length (2x zero-padded hipFFT, float64) -> detector image -> photon noise ->
 // centre of gravity per selected lenslet -> reconstructor GEMV + leaky integrator.

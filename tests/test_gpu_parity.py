@@ -580,6 +580,36 @@ def test_device_screen_synthesis_statistics():
     env.close()
 
 
+@pytest.mark.parametrize("N,q", [(64, 8), (128, 4), (256, 16), (512, 2)])
+def test_pruned_screen_synthesis_matches_full_transform(monkeypatch, N, q):
+    """K8, power-of-two pupils: the pruned two-pass synthesis (Philox lines -> length-N transforms in registers/LDS, never the
+    (qN)^2 array) gives the same screens as spectrum fill + hipFFT + centred crop on the same Philox stream; only fp32 rounding
+    (and the float amplitude law) differs.  Covers 1, 2, 4 and 8 points per lane and one or two b-groups per line."""
+    torch = _torch()
+    from adaptive_optics_gym_amd import BatchedAOEnv
+
+    def run(full):
+        if full:
+            monkeypatch.setenv("AOG_SCREENS_FULLFFT", "1")
+        else:
+            monkeypatch.delenv("AOG_SCREENS_FULLFFT", raising=False)
+        env = BatchedAOEnv(3, "cuda:0", atm_type="semi_dynamic", atm_fried=0.15, act_dim=6, act_type="zernike", obs_dim=2,
+                           num_pupil_pixels=N, timesteps_per_episode=5, seed=7, screen_oversampling=q, verbose=False)
+        env.reset()
+        first = np.stack([env.phase_screen(i).cpu().numpy() for i in range(3)])
+        env.reset()                                   # semi_dynamic: a new screen per episode
+        second = env.phase_screen(0).cpu().numpy()
+        env.close()
+        return first, second
+
+    f1, f2 = run(True)
+    p1, p2 = run(False)
+    rms = f1.std()
+    assert rms > 0 and not np.allclose(f1[0], f1[1]) and not np.allclose(f1[0], f2)
+    assert np.abs(p1 - f1).max() < 3e-5 * rms
+    assert np.abs(p2 - f2).max() < 3e-5 * rms
+
+
 def test_shack_hartmann_chain_matches_oracle():
     """SH_step (AO_env.py:254-290) on the device vs the oracle, stage by stage: the noise-free sensor image; then the
     estimator + reconstructor + leaky integrator fed with the ORACLE's photon-noisy image (a Poisson stream cannot be replayed
