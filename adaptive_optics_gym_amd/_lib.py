@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libaogym.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 AOG_REWARD = {"strehl_ratio": 0, "smf_ssim": 1}
 AOG_PRECISION = {"fast": 0, "fp64": 1}
@@ -44,6 +44,13 @@ class AogShTables(C.Structure):
         "field_amplitude", "image_scale", "gain", "leakage")]
 
 
+class AogActor(C.Structure):  # mirrors aog_actor in include/aogym.h
+    _fields_ = [("batch", C.c_int32), ("state_dim", C.c_int32), ("hidden_dim", C.c_int32), ("act_dim", C.c_int32),
+                ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p), ("w3", C.c_void_p), ("b3", C.c_void_p),
+                ("wo", C.c_void_p), ("bo", C.c_void_p), ("dropout_p", C.c_float), ("cov_var", C.c_float),
+                ("seed", C.c_uint64), ("call_index", C.c_uint64)]
+
+
 class AogInfo(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "abi_version", "num_envs", "num_envs_padded", "n_ap", "n_ap_padded", "n_modes_padded", "pixel_chunks",
@@ -73,6 +80,7 @@ SYMBOLS = {
     "aog_get_state": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]),
     "aog_set_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "aog_get_phase_screen": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "aog_actor_act": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "aog_device_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "aog_debug_read_partials": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "aog_get_actuators": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

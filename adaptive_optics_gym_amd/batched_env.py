@@ -355,10 +355,12 @@ class BatchedAOEnv:
         self.last_obs_raw = obs_raw
         return obs, {}
 
-    def step(self, actions):
+    def step(self, actions, out=None):
         """AOEnv.step (AO_env.py:106-153).  ``actions``: [B, A] float32 tensor on the device.
         Returns (obs float16 [B, o^2], reward float32 [B], done bool [B], trunc bool [B] (all False),
-        {"power": [B] float32, "obs_raw": [B, o^2] float32, "strehl": [B] float32})."""
+        {"power": [B] float32, "obs_raw": [B, o^2] float32, "strehl": [B] float32}).
+        ``out`` (optional): (obs float16 [B, o^2], reward float32 [B], done bool/uint8 [B]) contiguous device tensors to write
+        into — a rollout hands in slices of its transition buffers, so nothing is copied afterwards."""
         torch = self._torch
         a = torch.as_tensor(actions, device=self.device)
         if a.dtype != torch.float32:
@@ -368,23 +370,31 @@ class BatchedAOEnv:
             self._host_extrusion_noise()
         n = self.obs_dim ** 2
         B = self.num_envs
-        # three allocations per step: fp32 block (obs_raw | reward | power | strehl), fp16 obs, uint8 done
+        # allocations per step: fp32 block (obs_raw | power | strehl [| reward]), and unless handed in: fp16 obs, uint8 done
         f32 = torch.empty((B * (n + 3),), dtype=torch.float32, device=self.device)
         obs_raw = f32[: B * n].view(B, n)
-        reward = f32[B * n: B * (n + 1)]
         power = f32[B * (n + 1): B * (n + 2)]
         strehl = f32[B * (n + 2):]
-        obs = torch.empty((B, n), dtype=torch.float16, device=self.device)
-        done = torch.empty((B,), dtype=torch.uint8, device=self.device)
+        if out is None:
+            reward = f32[B * n: B * (n + 1)]
+            obs = torch.empty((B, n), dtype=torch.float16, device=self.device)
+            done = torch.empty((B,), dtype=torch.uint8, device=self.device)
+        else:
+            obs, reward, done = out
+            ok = (obs.dtype == torch.float16 and tuple(obs.shape) == (B, n) and reward.dtype == torch.float32 and tuple(reward.shape) == (B,)
+                  and done.dtype in (torch.bool, torch.uint8) and tuple(done.shape) == (B,)
+                  and obs.is_contiguous() and reward.is_contiguous() and done.is_contiguous())
+            if not ok:
+                raise ValueError("step(out=...): expected contiguous (float16 [B, o^2], float32 [B], bool/uint8 [B]) device tensors")
         base = f32.data_ptr()
         _lib.check(self.lib.aog_step(self._handle, C.c_void_p(a.data_ptr()), C.c_void_p(base), C.c_void_p(obs.data_ptr()),
-                                     C.c_void_p(base + 4 * B * n), C.c_void_p(done.data_ptr()),
+                                     C.c_void_p(reward.data_ptr()), C.c_void_p(done.data_ptr()),
                                      C.c_void_p(base + 4 * B * (n + 1)), C.c_void_p(base + 4 * B * (n + 2)), self._stream()))
         self.timestep += 1
         self.last_obs_raw = obs_raw
         if self._trunc is None:
             self._trunc = torch.zeros((B,), dtype=torch.bool, device=self.device)
-        return obs, reward, done.view(torch.bool), self._trunc, {"power": power, "obs_raw": obs_raw, "strehl": strehl}
+        return obs, reward, done if done.dtype == torch.bool else done.view(torch.bool), self._trunc, {"power": power, "obs_raw": obs_raw, "strehl": strehl}
 
     # ------------------------------------------------------------------------------------------------
     def get_actuators(self):

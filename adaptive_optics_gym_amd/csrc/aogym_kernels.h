@@ -1823,6 +1823,142 @@ __global__ void k_screen_crop(const float2* __restrict__ field, float* __restric
 #endif  // AOG_MAIN_TU
 
 // ------------------------------------------------------------------------------------------------
+// R1  policy query of the rollout (network.py:48-69): a 3-hidden-layer ReLU MLP with active dropout, Gaussian action sampling
+// and its log-probability, one launch.  Workgroup = 16 envs (the 16 columns of v_mfma_f32_16x16x4_f32, exact fp32), 4 waves
+// share the output-unit tiles of a layer; activations [unit][16 envs] ping-pong in LDS; nn.Linear weights [out][in] are read
+// straight from global memory as the A operand (lane = unit % 16 + 16 (k % 4)).
+// ------------------------------------------------------------------------------------------------
+struct ActorArgs {
+  const void* obs;
+  const float *w1, *b1, *w2, *b2, *w3, *b3, *wo, *bo;
+  float *mean, *action, *log_prob;
+  int B, S, H, A, obs_f16, kpad;
+  float p_drop, keep_scale, std, logp_const;
+  unsigned long long seed;
+  uint32_t call_lo, call_hi;
+};
+#ifdef AOG_MAIN_TU
+__device__ __forceinline__ void actor_philox(uint32_t (&c)[4], unsigned long long seed) {
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+// out[m][e] = act(sum_k W[m][k] xin[k][e] + b[m]) for this workgroup's 16 envs; LAYER 1..3 hidden (relu + dropout), 4 output.
+// The weights cross HBM/L2 -> LDS as one linear 16-byte-per-lane copy per row chunk (every load of the chunk in flight at once:
+// one memory round trip), then the four waves take the chunk's 16-row tiles with both MFMA operands coming from LDS.
+constexpr int kActorWFloats = 24576;   // LDS floats for a weight chunk (96 KB)
+constexpr int kActorThreads = 640;     // 10 waves: one 16-unit tile each for the reference's 150 hidden units
+template <int LAYER>
+__device__ __forceinline__ void actor_layer(const ActorArgs& p, const float* __restrict__ W, const float* __restrict__ bias, int K, int M,
+                                            const float* xin, float* xout, float* lp_sum, float* wl, int env0) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int el = lane & 15, kq = lane >> 4;
+  const int n_steps = (K + 3) >> 2;
+  const int rows_max = max(16, ((kActorWFloats / K) >> 4) << 4);
+  for (int r0 = 0; r0 < M; r0 += rows_max) {
+    const int rc = min(rows_max, M - r0);
+    const int n_fl = rc * K;
+    const float* src = W + (size_t)r0 * K;   // 16-byte aligned: r0 is a multiple of 16 and the base pointer is (checked on the host)
+    {
+      const int n4 = n_fl >> 2;
+      for (int i0 = threadIdx.x; i0 < n4; i0 += 8 * kActorThreads) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = reinterpret_cast<const f32x4*>(src)[min(i0 + kActorThreads * u, n4 - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (i0 + kActorThreads * u < n4) reinterpret_cast<f32x4*>(wl)[i0 + kActorThreads * u] = v[u];
+      }
+      for (int i = (n4 << 2) + threadIdx.x; i < n_fl; i += kActorThreads) wl[i] = src[i];
+    }
+    __syncthreads();
+    const int n_tiles = (rc + 15) >> 4;
+    for (int tile = wave; tile < n_tiles; tile += kActorThreads / 64) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const int lrow = tile * 16 + el;                 // row inside the chunk
+      const float row_ok = lrow < rc ? 1.f : 0.f;
+      const float* wrow = wl + (size_t)min(lrow, rc - 1) * K;
+#pragma unroll 8
+      for (int s = 0; s < n_steps; ++s) {
+        const int k = 4 * s + kq;
+        const float a = wrow[min(k, K - 1)] * (k < K ? row_ok : 0.f);
+        const float b = xin[k * 16 + el];              // rows K .. kpad-1 of xin are zero
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+      }
+      // D: column = env (lane & 15), rows 4 (lane >> 4) + r
+      const int m0 = r0 + tile * 16 + 4 * kq;
+      const int env = env0 + el;
+      uint32_t c[4] = {(uint32_t)m0 | ((uint32_t)LAYER << 24), (uint32_t)env, p.call_lo, p.call_hi ^ 0xAC70u};
+      actor_philox(c, p.seed);
+      if constexpr (LAYER < 4) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = m0 + r;
+          float v = 0.f;
+          if (m < M) {
+            v = fmaxf(acc[r] + bias[m], 0.f);
+            const float u = (float)(c[r] >> 8) * (1.0f / 16777216.0f);   // [0, 1): keep with probability 1 - p
+            v = u >= p.p_drop ? v * p.keep_scale : 0.f;
+          }
+          if (m < p.kpad) xout[m * 16 + el] = v;   // units M .. are written as zero: the next layer's K padding
+        }
+      } else {
+        float ssq = 0.f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const float u1 = ((float)c[2 * h] + 0.5f) * (1.0f / 4294967296.0f), u2 = ((float)c[2 * h + 1] + 0.5f) * (1.0f / 4294967296.0f);
+          const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
+          const float eps[2] = {rad * __builtin_amdgcn_cosf(u2), rad * __builtin_amdgcn_sinf(u2)};
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const int m = m0 + 2 * h + t;
+            if (m < M && env < p.B) {
+              const float mu = acc[2 * h + t] + bias[m];
+              if (p.mean) p.mean[(size_t)env * M + m] = mu;
+              if (p.action) p.action[(size_t)env * M + m] = mu + p.std * eps[t];
+              ssq += eps[t] * eps[t];
+            }
+          }
+        }
+        atomicAdd(&lp_sum[el], ssq);
+      }
+    }
+    __syncthreads();   // the chunk is consumed before the next one (or the next layer's) overwrites wl
+  }
+}
+
+__global__ __launch_bounds__(kActorThreads) void k_actor_act(ActorArgs p) {
+  extern __shared__ float lds_act[];   // xa [kpad][16] | xb [kpad][16] | lp [16] | weight chunk [kActorWFloats]
+  float* xa = lds_act;
+  float* xb = xa + (size_t)p.kpad * 16;
+  float* lp = xb + (size_t)p.kpad * 16;
+  float* wt = lp + 16;
+  const int env0 = blockIdx.x * 16;
+  for (int i = threadIdx.x; i < 2 * p.kpad * 16 + 16; i += kActorThreads) lds_act[i] = 0.f;
+  __syncthreads();
+  for (int i = threadIdx.x; i < p.S * 16; i += kActorThreads) {
+    const int k = i >> 4, e = i & 15, env = min(env0 + e, p.B - 1);
+    xa[i] = p.obs_f16 ? (float)reinterpret_cast<const _Float16*>(p.obs)[(size_t)env * p.S + k]
+                      : reinterpret_cast<const float*>(p.obs)[(size_t)env * p.S + k];
+  }
+  __syncthreads();
+  actor_layer<1>(p, p.w1, p.b1, p.S, p.H, xa, xb, lp, wt, env0);
+  __syncthreads();
+  actor_layer<2>(p, p.w2, p.b2, p.H, p.H, xb, xa, lp, wt, env0);
+  __syncthreads();
+  actor_layer<3>(p, p.w3, p.b3, p.H, p.H, xa, xb, lp, wt, env0);
+  __syncthreads();
+  actor_layer<4>(p, p.wo, p.bo, p.H, p.A, xb, nullptr, lp, wt, env0);
+  __syncthreads();
+  if (threadIdx.x < 16 && env0 + threadIdx.x < p.B && p.log_prob) p.log_prob[env0 + threadIdx.x] = -0.5f * lp[threadIdx.x] - p.logp_const;
+}
+#endif  // AOG_MAIN_TU
+
+// ------------------------------------------------------------------------------------------------
 // K8 (pruned form)  The centred N x N crop of the (qN)^2 inverse transform never needs the (qN)^2 array in memory:
 //   out[i - N/2] = sum_{k < m} S[k] e^{2 pi i k (i - N/2) / m},  m = q N,  i < N.   With k = q a + b:
 //   out = sum_b e^{2 pi i b (i - N/2) / m} F_b[i],   F_b = length-N inverse DFT over a of  (-1)^a S[q a + b].

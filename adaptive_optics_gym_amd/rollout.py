@@ -61,12 +61,61 @@ def sample_action(mean, cov_var: float = 0.5, generator=None):
     return action, log_prob
 
 
-def rollout(env, actor, episodes: int = 1, cov_var: float = 0.5, gatherer=None, generator=None):
+class DeviceActor:
+    """The policy query (``Actor.forward`` + ``get_action``, network.py:48-69) as ONE library launch (``aog_actor_act``): the
+    weights of a torch module built by ``make_actor`` (or any module exposing ``hidden`` = three ``nn.Linear`` and ``out``)
+    are read in place on every call, so a learner may keep updating them.  Dropout masks / Gaussian noise come from the
+    library's Philox streams (seed, call counter), not from torch's generator."""
+
+    def __init__(self, actor, seed: int = 0, dropout_p: float = 0.5):
+        import ctypes as C
+
+        from . import _lib
+
+        self._C, self._lib_mod = C, _lib
+        self.lib = _lib.load()
+        self.actor = actor
+        self.seed = int(seed)
+        self.dropout_p = float(dropout_p)
+        self.calls = 0
+
+    def __call__(self, obs, cov_var: float = 0.5, out=None):
+        """obs [B, S] float16 or float32 on the GPU -> (action [B, A] float32, log_prob [B] float32, mean [B, A])."""
+        import torch
+
+        C, _lib = self._C, self._lib_mod
+        layers = list(self.actor.hidden) + [self.actor.out]
+        for layer in layers:
+            if layer.weight.dtype != torch.float32 or not layer.weight.is_contiguous() or not layer.weight.is_cuda:
+                raise ValueError("DeviceActor needs contiguous float32 CUDA weights")
+        if obs.dtype not in (torch.float16, torch.float32) or not obs.is_contiguous():
+            raise ValueError("obs must be a contiguous float16 or float32 tensor")
+        B, S = obs.shape
+        H, A = layers[0].weight.shape[0], layers[3].weight.shape[0]
+        if layers[0].weight.shape[1] != S:
+            raise ValueError("obs width does not match the actor's first layer")
+        if out is None:
+            action = torch.empty((B, A), dtype=torch.float32, device=obs.device)
+            log_prob = torch.empty((B,), dtype=torch.float32, device=obs.device)
+            mean = torch.empty((B, A), dtype=torch.float32, device=obs.device)
+        else:
+            action, log_prob, mean = out
+        net = _lib.AogActor(B, S, H, A, *[C.c_void_p(t.data_ptr()) for layer in layers for t in (layer.weight, layer.bias)],
+                            self.dropout_p, float(cov_var), self.seed, self.calls)
+        self.calls += 1
+        _lib.check(self.lib.aog_actor_act(C.byref(net), obs.device.index or 0, C.c_void_p(obs.data_ptr()), int(obs.dtype == torch.float16),
+                                          C.c_void_p(mean.data_ptr()), C.c_void_p(action.data_ptr()), C.c_void_p(log_prob.data_ptr()),
+                                          C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)))
+        return action, log_prob, mean
+
+
+def rollout(env, actor, episodes: int = 1, cov_var: float = 0.5, gatherer=None, generator=None, actor_impl: str = "auto", seed: int = 0):
     """Collect ``episodes`` lock-step episodes from ``env`` (a ``BatchedAOEnv``).
 
-    Returns a dict of device tensors shaped ``[T*E, B, ...]`` (obs, act, log_prob, rew, next_obs, done), ``ep_returns``
-    ``[E, B_global]`` (gathered over ranks when ``gatherer`` is distributed) and ``avg_ep_rew`` (the reference's logged
-    scalar)."""
+    ``actor_impl``: "hip" = the fused policy-query kernel (``DeviceActor``), "torch" = the module's own forward +
+    ``sample_action``, "auto" = "hip" for CUDA modules with the ``make_actor`` structure.  Returns a dict of device tensors
+    shaped ``[T*E, B, ...]`` (obs, act, log_prob, rew, next_obs, done), ``ep_returns`` ``[E, B_global]`` (gathered over ranks
+    when ``gatherer`` is distributed) and ``avg_ep_rew`` (the reference's logged scalar)."""
     import torch
 
     from .sharding import EpisodeReturnGatherer
@@ -75,24 +124,53 @@ def rollout(env, actor, episodes: int = 1, cov_var: float = 0.5, gatherer=None, 
     B = env.num_envs
     if gatherer is None:
         gatherer = EpisodeReturnGatherer(B, env.device, False)
-    keys = ("obs", "act", "log_prob", "rew", "next_obs", "done")
-    buf = {k: [] for k in keys}
+    if actor_impl == "auto":
+        structured = hasattr(actor, "hidden") and hasattr(actor, "out") and len(list(actor.hidden)) == 3
+        actor_impl = "hip" if structured and next(actor.parameters()).is_cuda else "torch"
+    dev_actor = DeviceActor(actor, seed=seed) if actor_impl == "hip" else None
+    import inspect
+
+    step_takes_out = "out" in inspect.signature(env.step).parameters
+    n = T * episodes
+    out = None
     ep_returns = []
     with torch.no_grad():
+        i = 0
         for _ in range(episodes):
             obs, _ = env.reset()
             gatherer.start_episode()
+            i0 = i
             for _t in range(T):
-                mean = actor(obs)
-                action, log_prob = sample_action(mean, cov_var, generator)
-                next_obs, rew, done, _, _ = env.step(action)
-                gatherer.add(rew)
-                for k, v in zip(keys, (obs, action, log_prob, rew, next_obs, done)):
-                    buf[k].append(v)
+                if out is None:   # buffers are laid out once the shapes are known: [T*E, B, ...], written in place
+                    S = obs.shape[1]
+                    A = int(list(actor.parameters())[-1].shape[0])   # width of the output layer's bias
+                    dev = obs.device
+                    out = {"obs": torch.empty((n, B, S), dtype=obs.dtype, device=dev), "act": torch.empty((n, B, A), dtype=torch.float32, device=dev),
+                           "log_prob": torch.empty((n, B), dtype=torch.float32, device=dev), "rew": torch.empty((n, B), dtype=torch.float32, device=dev),
+                           "next_obs": torch.empty((n, B, S), dtype=obs.dtype, device=dev), "done": torch.empty((n, B), dtype=torch.bool, device=dev)}
+                    mean_buf = torch.empty((B, A), dtype=torch.float32, device=dev)
+                if dev_actor is not None:
+                    action, _, _ = dev_actor(obs, cov_var, out=(out["act"][i], out["log_prob"][i], mean_buf))
+                else:
+                    action, log_prob = sample_action(actor(obs), cov_var, generator)
+                    out["act"][i].copy_(action)
+                    out["log_prob"][i].copy_(log_prob)
+                if step_takes_out:   # the env writes the transition straight into this step's slices
+                    next_obs = env.step(action, out=(out["next_obs"][i], out["rew"][i], out["done"][i]))[0]
+                else:
+                    next_obs, rew, done, _, _ = env.step(action)
+                    out["rew"][i].copy_(rew)
+                    out["next_obs"][i].copy_(next_obs)
+                    out["done"][i].copy_(done)
+                if _t == 0:
+                    out["obs"][i].copy_(obs)
                 obs = next_obs
+                i += 1
                 # lock-step: done is identical for every env (AO_env.py:147), so no host sync is needed to break
+            if T > 1:
+                out["obs"][i0 + 1:i0 + T].copy_(out["next_obs"][i0:i0 + T - 1])   # obs of step t+1 = next_obs of step t
+            gatherer.add(out["rew"][i0:i0 + T].sum(0))
             ep_returns.append(gatherer.finish_episode().clone())
-    out = {k: torch.stack(v) for k, v in buf.items()}
     out["ep_returns"] = torch.stack(ep_returns)
     out["avg_ep_rew"] = float(out["ep_returns"].mean().item()) / T
     return out

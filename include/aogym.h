@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define AOG_ABI_VERSION 10
+#define AOG_ABI_VERSION 11
 
 typedef struct aog_env aog_env;
 
@@ -224,6 +224,27 @@ int aog_step(aog_env* env, const float* action_dev, float* obs_raw_dev, uint16_t
  * arm with the current screen and mirror, as interleaved (re, im) float32, row-major (y, x), up to a global phase (the
  * library stores screens with their aperture mean removed).  Off the step() path; used for render()/fiber cross-checks. */
 int aog_focal_image(aog_env* env, int env_index, float* field_dev /* [n_focal][n_focal][2] */, void* stream);
+
+/* ---- policy query of the rollout (Actor.forward + Actor.get_action, network.py:17-69; caller algorithm.py:216-296) ----
+ * mean = W_o drop(relu(W_3 drop(relu(W_2 drop(relu(W_1 obs + b_1)) + b_2)) + b_3)) + b_o with nn.Dropout(dropout_p) ACTIVE
+ * (the reference never leaves training mode while acting), action = mean + sqrt(cov_var) eps, eps ~ N(0, I),
+ * log_prob = MultivariateNormal(mean, cov_var I).log_prob(action).  Weights are torch nn.Linear layouts [out][in], float32,
+ * device pointers; they are read on every call (the learner updates them between rollouts).  Dropout masks and eps come from
+ * Philox4x32-10 keyed by (seed, call_index, env, layer, unit): statistically, not bit-wise, torch's streams.
+ * One launch per call; independent of any aog_env handle. */
+typedef struct aog_actor {
+  int32_t batch, state_dim, hidden_dim, act_dim;
+  const float* w1; const float* b1;     /* [hidden][state],  [hidden] */
+  const float* w2; const float* b2;     /* [hidden][hidden], [hidden] */
+  const float* w3; const float* b3;     /* [hidden][hidden], [hidden] */
+  const float* wo; const float* bo;     /* [act][hidden],    [act]    */
+  float dropout_p;                      /* 0.5 in the reference (network.py:39); 0 = evaluation mode */
+  float cov_var;                        /* 0.5 in the reference (algorithm.py:107) */
+  uint64_t seed, call_index;
+} aog_actor;
+/* obs: [batch][state_dim], float16 bits (obs_is_f16 = 1: what aog_step writes) or float32; outputs may be NULL. */
+int aog_actor_act(const aog_actor* net, int device, const void* obs_dev, int obs_is_f16, float* mean_dev /* [batch][act] */,
+                  float* action_dev /* [batch][act] */, float* log_prob_dev /* [batch] */, void* stream);
 
 /* Self-test hook: sin(2 pi u), cos(2 pi u) for n float32 revolutions u_dev with the fused kernels' device code.
  * flavour 0 = polynomial, 1 = v_sin_f32/v_cos_f32 after the exact reduction, 2 = v_sin_f32/v_cos_f32 on raw input. */

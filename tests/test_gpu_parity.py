@@ -10,6 +10,8 @@ import ast
 import glob
 import os
 
+import math
+
 import numpy as np
 import pytest
 
@@ -419,6 +421,63 @@ def test_batched_rollout_on_device():
     assert bool(out["done"][T - 1].all()) and not bool(out["done"][T - 2].any())
     assert -100.0 <= out["avg_ep_rew"] <= 0.0     # Strehl reward = 100 (S - 1)
     env.close()
+
+
+def test_device_actor_matches_torch_module():
+    """R1 policy query (network.py:48-69) as one launch: with dropout off the mean equals the torch module's forward (fp32
+    matrix cores are exact fp32), the action is mean + sqrt(cov) eps with unit-variance eps, log_prob is the
+    MultivariateNormal(mean, cov I) density of the action; with p = 0.5 half of the hidden units are dropped and the
+    survivors doubled."""
+    torch = _torch()
+    from torch.distributions import MultivariateNormal
+    from adaptive_optics_gym_amd.rollout import DeviceActor, make_actor
+
+    torch.manual_seed(3)
+    for S, H, A, B in ((4, 150, 64, 1000), (25, 150, 20, 37), (4, 32, 16, 5)):
+        actor = make_actor(S, A, H, device="cuda:0")
+        with torch.no_grad():
+            actor.out.weight.mul_(100.0)          # make the means O(1) so that errors would show
+        obs32 = torch.rand((B, S), device="cuda") * 3
+        obs16 = obs32.to(torch.float16)
+        dev = DeviceActor(actor, seed=5, dropout_p=0.0)
+        actor.eval()
+        with torch.no_grad():
+            ref16 = actor(obs16)
+            ref32 = actor(obs32)
+        for obs, ref in ((obs16, ref16), (obs32, ref32)):
+            action, log_prob, mean = dev(obs, 0.5)
+            torch.testing.assert_close(mean, ref, rtol=2e-5, atol=2e-6)
+            eps = (action - mean) / math.sqrt(0.5)
+            if B * A > 10000:
+                assert abs(float(eps.mean())) < 0.02 and abs(float(eps.var()) - 1.0) < 0.03
+                assert abs(float((eps ** 4).mean()) - 3.0) < 0.15
+            lp_ref = MultivariateNormal(mean, 0.5 * torch.eye(A, device="cuda")).log_prob(action)
+            torch.testing.assert_close(log_prob, lp_ref, rtol=1e-4, atol=1e-3)
+        a1, _, _ = dev(obs16, 0.5)
+        a2, _, _ = dev(obs16, 0.5)
+        assert not torch.equal(a1, a2)              # a new call draws new noise
+        actor.train()
+    # dropout statistics on the first hidden layer: feed an actor whose later layers are identities is overkill; use the
+    # fraction of exactly-zero means' change instead: with p = 0.5 the mean differs from the p = 0 mean and varies call to call
+    actor = make_actor(4, 64, 150, device="cuda:0")
+    obs = torch.rand((256, 4), device="cuda").to(torch.float16)
+    d5 = DeviceActor(actor, seed=1, dropout_p=0.5)
+    m1 = d5(obs, 0.5)[2]
+    m2 = d5(obs, 0.5)[2]
+    m0 = DeviceActor(actor, seed=1, dropout_p=0.0)(obs, 0.5)[2]
+    assert not torch.equal(m1, m2) and not torch.equal(m1, m0)
+    # E[dropout(x)] = x: averaging many masked means approaches the p = 0 mean of a LINEARISED net only; check layer 1 alone
+    with torch.no_grad():
+        for layer in list(actor.hidden)[1:]:
+            layer.weight.copy_(torch.eye(150, device="cuda")); layer.bias.zero_()
+        actor.out.weight.zero_(); actor.out.bias.zero_()
+        actor.out.weight[:, :64] = torch.eye(64, device="cuda")
+    base = DeviceActor(actor, seed=2, dropout_p=0.0)(obs, 0.5)[2]          # relu(W1 x + b1)[:64]
+    one = DeviceActor(actor, seed=2, dropout_p=0.5)(obs, 0.5)[2]           # three dropout layers in a row: kept w.p. 1/8, scaled x8
+    pos = base > 1e-3
+    kept = (one[pos] != 0).float().mean()
+    assert abs(float(kept) - 0.125) < 0.02
+    torch.testing.assert_close(one[pos][one[pos] != 0], (8.0 * base)[pos][one[pos] != 0], rtol=1e-5, atol=1e-6)
 
 
 @pytest.mark.parametrize("precision", ["fast", "fp64"])
