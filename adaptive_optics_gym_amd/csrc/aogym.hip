@@ -373,7 +373,7 @@ int aog_create(const aog_config* cfg, int device, aog_env** out) {
                   "use AOG_PRECISION_FP64 for this shape");
     }
     e->kernel = cfg->kernel == AOG_KERNEL_AUTO ? AOG_KERNEL_MFMA : cfg->kernel;
-    if (e->kernel == AOG_KERNEL_MFMA && e->A_pad > 64) e->kernel = AOG_KERNEL_VALU;
+    if (e->kernel == AOG_KERNEL_MFMA && e->A_pad > 64 && getenv("AOG_WIDE_VALU")) e->kernel = AOG_KERNEL_VALU;   // developer comparison
     // launch geometry: aim at ~3 (VALU) / ~2 (MFMA) waves per SIMD over 256 CUs
     const int n_groups = e->Bp / 64;
     int P = cfg->pixel_chunks > 0 ? cfg->pixel_chunks : std::max(1, (256 * 4 * 3 + n_groups - 1) / n_groups);

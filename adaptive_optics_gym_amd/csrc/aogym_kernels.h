@@ -403,12 +403,13 @@ struct Plan {
 // 3 = matrix instructions only with no global loads inside the loop, 4 = global loads only, 5 = vector work only (no loads in the
 // loop, no matrix instructions), 6 = full kernel that records a per-wave timeline into `partials` (tools/fused_timeline.py)
 template <int A_PAD, int MRW, int MRS, int SINCOS, int ABL = 0>
-__global__ __launch_bounds__(256, (MRW <= 12 ? 2 : 1)) void k_fused_mfma(const f16x8* __restrict__ modes16, const f32x4* __restrict__ tabs_tile,
+__global__ __launch_bounds__(256, (MRW <= 12 && A_PAD <= 64 ? 2 : 1)) void k_fused_mfma(const f16x8* __restrict__ modes16, const f32x4* __restrict__ tabs_tile,
                                                     const f32x4* __restrict__ psi_tile, const f16x8* __restrict__ act16,
                                                     double* __restrict__ partials, MfmaGeom geo, float ratio) {
   using PL = Plan<A_PAD, MRW, MRS, SINCOS>;
   constexpr int NS = PL::NS, MR = PL::MR, NSTEP = PL::NSTEP, NM = PL::NM, NSLOT = PL::NSLOT;
   constexpr int MAXTB = PL::T.max_tb;
+  constexpr bool kDeep = MRW <= 7 && A_PAD <= 64;   // two-deep screen prefetch + two unrolled stage bodies: only where registers allow
   const long long t_kernel = ABL == 6 ? wall_clock64() : 0;
   extern __shared__ f32x4 lds_tabs[];  // [tile in chunk][g][h][MR]
   const int lane = threadIdx.x & 63;
@@ -547,7 +548,7 @@ __global__ __launch_bounds__(256, (MRW <= 12 ? 2 : 1)) void k_fused_mfma(const f
         }
       } else {
         constexpr int lo = a * MR / PL::N_FL, hi = (a + 1) * MR / PL::N_FL;
-        if (flush) {   // wave-uniform: the fp32 pair sums go to the float64 accumulators every kFlushTiles tiles
+        if (kDeep ? flush : true) {   // wave-uniform: every kFlushTiles tiles (a run-time condition here costs the many-table variants ~300 registers: they flush every tile)
 #pragma unroll
           for (int i = lo; i < hi; ++i) {
             acc[2 * i] += (double)ts[i][0];
@@ -589,10 +590,13 @@ __global__ __launch_bounds__(256, (MRW <= 12 ? 2 : 1)) void k_fused_mfma(const f
       f32x16 d1 = zero16, d2 = zero16;
       if constexpr (ABL == 3 || ABL == 5) {
         p_use = d;
-      } else {
+      } else if constexpr (kDeep) {
         load_modes(mh, ml, t + wp);       // consumed from slot 1 on
         __builtin_amdgcn_sched_barrier(0);
         p_load = load_psi(t + 2 * wp);    // issued AFTER the mode halves: vmcnt retires in order, and the matrix ops wait for those only
+      } else {
+        load_modes(mh, ml, t + wp);
+        if (i > 0) p_use = load_psi(t + wp);   // one tile ahead (tile `first + wp` was requested at kernel entry)
       }
       const f32x4* lt = lds_row(t);
       flush = (i % kFlushTiles) == kFlushTiles - 1;
@@ -620,7 +624,7 @@ __global__ __launch_bounds__(256, (MRW <= 12 ? 2 : 1)) void k_fused_mfma(const f
       d = d1 * kD1Unscale + (p_use + d2 * kD2Unscale);
       if constexpr (ABL == 6) { asm volatile("" ::"v"(d[0])); tdbg[1] += wall_clock64() - tq0; }
     };
-    {
+    if constexpr (kDeep) {
       f32x16 p_alt = zero16;
       int i = 0, t = first;
       for (; i + 2 < n; i += 2, t += 2 * wp) {
@@ -628,6 +632,9 @@ __global__ __launch_bounds__(256, (MRW <= 12 ? 2 : 1)) void k_fused_mfma(const f
         stage(i + 1, t + wp, p_alt, p_next);
       }
       if (i + 1 < n) stage(i, t, p_next, p_alt);
+    } else {
+      // many-table variants (o >= 3) are register-bound: one stage body, the screen one tile ahead in a single register set
+      for (int i = 0, t = first; i + 1 < n; ++i, t += wp) stage(i, t, p_next, p_next);
     }
     if constexpr (ABL == 6) tdbg[2] = wall_clock64();
     flush = true;

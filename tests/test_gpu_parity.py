@@ -115,6 +115,8 @@ def test_golden_fixtures(path, precision, kernel):
     (128, 2, 6, 2, "zernike", "strehl_ratio"),            # BASELINE configs[0] geometry
     (50, 1, 3, 4, "num_actuators", "strehl_ratio"),       # B = 1, odd sizes, A < 8
     (240, 2, 64, 2, "num_actuators", "strehl_ratio"),     # the reference's hard-coded pupil size
+    (64, 3, 100, 2, "num_actuators", "strehl_ratio"),     # 64 < act_dim <= 128: the 128-mode matrix-core variant
+    (64, 2, 20, 3, "zernike", "smf_ssim"),                # o = 3: the 12-table variant
 ])
 def test_live_oracle_parity(N, B, A, o, act_type, rew, precision, kernel):
     torch = _torch()
