@@ -43,7 +43,8 @@ def build(force: bool = False, verbose: bool = True, fast: bool = False) -> str:
     extra = ["-DAOG_FAST_BUILD"] if fast else []
     jobs = [([hipcc, *FLAGS, *extra, "-c", os.path.join(CSRC, "aogym.hip"), "-o", os.path.join(OBJ, "aogym.o")])]
     for a in APADS:
-        jobs.append([hipcc, *FLAGS, *extra, f"-DAOG_INST_APAD={a}", "-c", os.path.join(CSRC, "fused_inst.hip"), "-o",
+        # -fno-slp-vectorize: the fused kernels must not get their scalar FMAs re-packed into v_pk_fma_f32 (trap)
+        jobs.append([hipcc, *FLAGS, "-fno-slp-vectorize", *extra, f"-DAOG_INST_APAD={a}", "-c", os.path.join(CSRC, "fused_inst.hip"), "-o",
                      os.path.join(OBJ, f"fused_apad{a}.o")])
 
     def run(cmd):

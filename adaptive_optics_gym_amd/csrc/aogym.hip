@@ -386,7 +386,8 @@ int aog_create(const aog_config* cfg, int device, aog_env** out) {
     // P pixel chunks (proportional split of the tiles), 2 workgroups per CU when the batch allows; the table stage of a
     // chunk must fit 60 KiB of LDS
     int Pm = cfg->pixel_chunks > 0 ? cfg->pixel_chunks : std::max(1, (256 * 2) / wg_y);
-    const int max_tpc = std::max(1, (int)(60 * 1024 / (8 * (e->MRW + 1) * 16)));
+    int max_tpc = std::max(1, (int)(60 * 1024 / (8 * (e->MRW + 1) * 16)));
+    if (e->MRW >= 20) max_tpc = std::min(max_tpc, aog::kF32AccTiles * wp);   // fp32-only accumulation: bounded terms per lane
     Pm = std::max(Pm, (e->n_ptiles + max_tpc - 1) / max_tpc);
     Pm = std::min(Pm, e->n_ptiles);
     e->mfma_chunks_x = Pm;

@@ -334,6 +334,7 @@ __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_in
 // fp32 partial sums of the table reduction are folded into the float64 accumulators every kFlushTiles tiles (16 pixels per lane
 // each): the conversions + float64 adds are half-rate vector work, 16 of ~115 issue cycles per (pixel, env) if done every tile
 constexpr int kFlushTiles = 4;
+constexpr int kF32AccTiles = 13;   // longest chunk (tiles per wave) of the variants that accumulate in fp32 only
 constexpr int kSkewNops = 150;   // x 16 cycles: start-up skew of the second workgroup of a CU (about half a stage)
 
 template <int A_PAD, int MRW, int MRS, int SINCOS>
@@ -459,10 +460,14 @@ __global__ __launch_bounds__(256, (MRW <= 12 && A_PAD <= 64 ? 2 : 1)) void k_fus
     return d;
   };
   f16x8 mh[NSTEP], ml[NSTEP];
-  load_modes(mh, ml, first);
-  f32x16 p_first = load_psi(first);
-  f32x16 p_next = load_psi(first + wp);   // the screen stream comes from HBM: kept TWO tiles ahead (the mode halves, shared by every
-                                          // env tile, are L2 hits and stay one tile ahead)
+  f32x16 p_first, p_next;
+  const bool hoist = geo.max_tiles >= 0;   // (negative: developer switch AOG_NO_HOIST)
+  if (hoist) {
+    load_modes(mh, ml, first);
+    p_first = load_psi(first);
+    p_next = load_psi(first + wp);   // the screen stream comes from HBM: kept TWO tiles ahead (the mode halves, shared by every
+                                     // env tile, are L2 hits and stay one tile ahead)
+  }
   __builtin_amdgcn_sched_barrier(0);
   // stage this chunk's tables (contiguous in global memory) into LDS, 8 loads in flight per thread
   {
@@ -479,23 +484,34 @@ __global__ __launch_bounds__(256, (MRW <= 12 && A_PAD <= 64 ? 2 : 1)) void k_fus
   }
   __syncthreads();
   if (etile >= geo.n_etiles) return;
+  if (!hoist) {
+    load_modes(mh, ml, first);
+    p_first = load_psi(first);
+    p_next = load_psi(first + wp);
+  }
   // Workgroups j and j + 32 of an XCD share a CU (two passes of the dispatcher over its 32 CUs) and would run in lock step: both
   // waves of every SIMD issuing their 12 loads, then both doing vector work.  Half a stage of skew lets one wave's load issue
-  // overlap the other's arithmetic.  The delay is a counted s_nop loop on purpose: with s_sleep here (loads of the first tiles
-  // still in flight) 16-lane pieces of those loads came back wrong, run to run — measured, not understood; never sleep with
-  // vector loads outstanding.
-  if constexpr (ABL == 0 || ABL == 6) {
+  // overlap the other's arithmetic (a counted s_nop loop; s_sleep works as well).  NOTE: once the two waves of a SIMD run out of
+  // phase, packed fp32 FMAs with a broadcast operand (v_pk_fma_f32 ... op_sel) in the table reduction returned wrong LOW halves
+  // in lanes 16-31, run to run; that is why the reduction below uses scalar FMAs and the file is built with -fno-slp-vectorize.
+  if constexpr (ABL == 0 || ABL >= 6) {
     if ((j & 32) != 0 && kSkewNops > 0) {
       for (int q = 0; q < kSkewNops; ++q) asm volatile("s_nop 15");
     }
   }
 
-  double acc[NS];
+  // Many-table variants keep NO float64 running sums (58 of them would be 116 registers and cost the second wave per SIMD):
+  // their fp32 pair sums run over the whole chunk, which the host keeps at <= kF32AccTiles tiles (<= 208 terms per lane;
+  // error budget in DESIGN.md), and are widened once at the end.
+  constexpr bool kF32Acc = MRW >= 20;
+  double acc[kF32Acc ? 1 : NS];
 #pragma unroll
-  for (int i = 0; i < NS; ++i) acc[i] = 0.0;
-  f32x2 ts[MR];   // (sum cos * g, sum sin * g) of table m: one v_pk_fma_f32 per (pixel, table) feeds both halves
+  for (int i = 0; i < (kF32Acc ? 1 : NS); ++i) acc[i] = 0.0;
+  // fp32 sums (cos * g at 2m, sin * g at 2m + 1).  Scalar FMAs on purpose: the packed form (v_pk_fma_f32 with a broadcast table
+  // value) produced wrong low halves in lanes 16-31 whenever the two waves of a SIMD ran out of phase.
+  float ts[NS];
 #pragma unroll
-  for (int i = 0; i < MR; ++i) ts[i] = f32x2{0.f, 0.f};
+  for (int i = 0; i < NS; ++i) ts[i] = 0.f;
 
   // This wave's tiles: t0 + w_p + i*wp, i < n.  Stage i (all inside one wave):
   //   issue the loads of tile i+1 (mode halves) and i+2 (screen), run slot 0 of tile i's vector work while they land, then the
@@ -544,16 +560,20 @@ __global__ __launch_bounds__(256, (MRW <= 12 && A_PAD <= 64 ? 2 : 1)) void k_fus
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const f32x2 e = m < MRW ? ew[par][r] : es[par][r];
-          ts[m] = __builtin_elementwise_fma(e, f32x2{gv[r], gv[r]}, ts[m]);
+          ts[2 * m] = fmaf(e[0], gv[r], ts[2 * m]);
+          ts[2 * m + 1] = fmaf(e[1], gv[r], ts[2 * m + 1]);
         }
       } else {
         constexpr int lo = a * MR / PL::N_FL, hi = (a + 1) * MR / PL::N_FL;
-        if (kDeep ? flush : true) {   // wave-uniform: every kFlushTiles tiles (a run-time condition here costs the many-table variants ~300 registers: they flush every tile)
+        if constexpr (kF32Acc) {
+          // nothing: the pair sums are widened after the last tile
+        } else if (kDeep ? flush : true) {   // wave-uniform: every kFlushTiles tiles (a run-time condition here costs the many-table variants ~300 registers: they flush every tile)
 #pragma unroll
           for (int i = lo; i < hi; ++i) {
-            acc[2 * i] += (double)ts[i][0];
-            acc[2 * i + 1] += (double)ts[i][1];
-            ts[i] = f32x2{0.f, 0.f};
+            acc[2 * i] += (double)ts[2 * i];
+            acc[2 * i + 1] += (double)ts[2 * i + 1];
+            ts[2 * i] = 0.f;
+            ts[2 * i + 1] = 0.f;
           }
         }
       }
@@ -607,7 +627,7 @@ __global__ __launch_bounds__(256, (MRW <= 12 && A_PAD <= 64 ? 2 : 1)) void k_fus
         fetch_rows(IC<1>{}, lt);
         run_slot(IC<0>{}, lt);
       } else {
-        acc[0] += (double)d[0];
+        acc[0] += (double)d[0];   // (ablation builds only)
       }
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (ABL == 6) { const long long tq = wall_clock64(); tdbg[0] += tq - tq0; tq0 = tq; }
@@ -623,6 +643,13 @@ __global__ __launch_bounds__(256, (MRW <= 12 && A_PAD <= 64 ? 2 : 1)) void k_fus
       });
       d = d1 * kD1Unscale + (p_use + d2 * kD2Unscale);
       if constexpr (ABL == 6) { asm volatile("" ::"v"(d[0])); tdbg[1] += wall_clock64() - tq0; }
+      if constexpr (ABL == 7) {   // self-check: the screen values just consumed against a fresh load of the same addresses
+        const f32x16 chk = load_psi(t + wp);
+        int bad = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) bad += (chk[q] != p_use[q]) ? 1 : 0;
+        if (bad) printf("[fused chk] psi mismatch wg %d wave %d lane %d tile %d: %d of 16\n", (int)blockIdx.x, (int)(threadIdx.x >> 6), lane, t + wp, bad);
+      }
     };
     if constexpr (kDeep) {
       f32x16 p_alt = zero16;
@@ -651,7 +678,10 @@ __global__ __launch_bounds__(256, (MRW <= 12 && A_PAD <= 64 ? 2 : 1)) void k_fus
   double* out = partials + (size_t)chunk * NS * geo.Bp + (size_t)etile * 32 + (lane & 31);
 #pragma unroll
   for (int i = 0; i < NS; ++i) {
-    const double v = acc[i] + __shfl_down(acc[i], 32, 64);
+    double a;
+    if constexpr (kF32Acc) a = (double)ts[i];
+    else a = acc[i];
+    const double v = a + __shfl_down(a, 32, 64);
     if (h == 0) out[(size_t)i * geo.Bp] = v;
   }
 }

@@ -31,7 +31,9 @@ void launch_mfma(aog_env* e, hipStream_t s) {
   g.max_tiles = e->mfma_tpc;
   dim3 grid(round_up(g.P, 8) * g.wg_y);
   const float ratio = (float)(e->cfg.wavelength_wfs / e->cfg.wavelength_sci);
-  const size_t lds = (size_t)e->mfma_tpc * 8 * (MRW + 1) * 16;
+  size_t lds = (size_t)e->mfma_tpc * 8 * (MRW + 1) * 16;
+  if (const char* pad = getenv("AOG_LDS_PAD_KB")) lds = std::max(lds, (size_t)atoi(pad) * 1024);   // developer aid: force one workgroup per CU
+  g.max_tiles = getenv("AOG_NO_HOIST") ? -e->mfma_tpc : e->mfma_tpc;
   if constexpr (A_PAD == 64 && MRW == 7 && SC == 2) {
     if (e->ablate == 1) {
       hipLaunchKernelGGL((aog::k_fused_mfma<A_PAD, MRW, 1, SC, 1>), grid, dim3(256), lds, s,
@@ -52,6 +54,14 @@ void launch_mfma(aog_env* e, hipStream_t s) {
     AOG_ABL_CASE(5)
     AOG_ABL_CASE(6)
 #undef AOG_ABL_CASE
+  }
+  if constexpr (SC == 2 && (MRW == 28 || MRW == 7)) {
+    if (e->ablate == 7) {   // self-checking build (prints on a mismatch)
+      hipLaunchKernelGGL((aog::k_fused_mfma<A_PAD, MRW, 1, SC, 7>), grid, dim3(256), lds, s,
+                         reinterpret_cast<const aog::f16x8*>(e->modes16), reinterpret_cast<const aog::f32x4*>(e->tabs_tile),
+                         reinterpret_cast<const aog::f32x4*>(e->psi_tile), reinterpret_cast<const aog::f16x8*>(e->act16), e->partials, g, ratio);
+      return;
+    }
   }
   hipLaunchKernelGGL((aog::k_fused_mfma<A_PAD, MRW, 1, SC>), grid, dim3(256), lds, s,
                      reinterpret_cast<const aog::f16x8*>(e->modes16), reinterpret_cast<const aog::f32x4*>(e->tabs_tile),
