@@ -17,7 +17,8 @@ DEPS = [os.path.join(CSRC, f) for f in ("aogym.hip", "fused_inst.hip", "aogym_ke
        [os.path.join(HERE, "..", "include", "aogym.h")]
 OUT = os.path.join(HERE, "libaogym.so")
 APADS = (16, 32, 64, 128)
-FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wall"]
+# -fno-slp-vectorize: no kernel gets scalar fp32 pairs re-packed into v_pk_* behind its back (packed-FMA trap)
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wall", "-fno-slp-vectorize"]
 
 
 def hipcc_path() -> str:
@@ -43,8 +44,7 @@ def build(force: bool = False, verbose: bool = True, fast: bool = False) -> str:
     extra = ["-DAOG_FAST_BUILD"] if fast else []
     jobs = [([hipcc, *FLAGS, *extra, "-c", os.path.join(CSRC, "aogym.hip"), "-o", os.path.join(OBJ, "aogym.o")])]
     for a in APADS:
-        # -fno-slp-vectorize: the fused kernels must not get their scalar FMAs re-packed into v_pk_fma_f32 (trap)
-        jobs.append([hipcc, *FLAGS, "-fno-slp-vectorize", *extra, f"-DAOG_INST_APAD={a}", "-c", os.path.join(CSRC, "fused_inst.hip"), "-o",
+        jobs.append([hipcc, *FLAGS, *extra, f"-DAOG_INST_APAD={a}", "-c", os.path.join(CSRC, "fused_inst.hip"), "-o",
                      os.path.join(OBJ, f"fused_apad{a}.o")])
 
     def run(cmd):
