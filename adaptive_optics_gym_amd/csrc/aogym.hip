@@ -705,9 +705,12 @@ int aog_generate_screens(aog_env* e, int first, int count, int oversampling, dou
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int N = e->cfg.n_pupil, m = N * oversampling;
   if ((m & 1) != 0) return fail(AOG_ERR_UNSUPPORTED, "aog_generate_screens: odd FFT size");
-  // pruned synthesis (no (qN)^2 array): power-of-two N in [64, 512] and power-of-two oversampling
-  const bool pow2 = (N & (N - 1)) == 0 && (oversampling & (oversampling - 1)) == 0;
-  if (pow2 && N >= 64 && N <= 512 && !getenv("AOG_SCREENS_FULLFFT")) {
+  // pruned synthesis (no (qN)^2 array): N = 64 R or 60 R with R in {1, 2, 4, 8} (64 .. 512; 60, 120, 240, 480) and power-of-two
+  // oversampling
+  const int LW = N % 64 == 0 ? 64 : (N % 60 == 0 ? 60 : 0);
+  const int Rr = LW ? N / LW : 0;
+  const bool pow2 = (oversampling & (oversampling - 1)) == 0 && (Rr == 1 || Rr == 2 || Rr == 4 || Rr == 8);
+  if (pow2 && !getenv("AOG_SCREENS_FULLFFT")) {
     const size_t per_env = (size_t)m * N * 2;   // floats of T
     int batch = (int)std::max<size_t>(1, std::min<size_t>((size_t)e->B, ((size_t)2 << 30) / (per_env * sizeof(float))));
     if (e->syn_m != m) {   // (a different oversampling later on allocates afresh; the old workspace is released with the handle)
@@ -736,9 +739,11 @@ int aog_generate_screens(aog_env* e, int first, int count, int oversampling, dou
     a.amp_scale = (float)amp_scale;
     a.crop_scale = (float)(std::sqrt(cn_squared) / ((double)m * m * pixel_pitch * pixel_pitch));
     const size_t lds = (size_t)4 * 64 * 65 * sizeof(float);
-    const int R = N / 64;
-    auto rows = R == 1 ? aog::k_screen_rows<1> : R == 2 ? aog::k_screen_rows<2> : R == 4 ? aog::k_screen_rows<4> : aog::k_screen_rows<8>;
-    auto cols = R == 1 ? aog::k_screen_cols<1> : R == 2 ? aog::k_screen_cols<2> : R == 4 ? aog::k_screen_cols<4> : aog::k_screen_cols<8>;
+    const int R = Rr;
+    auto rows = LW == 64 ? (R == 1 ? aog::k_screen_rows<1, 64> : R == 2 ? aog::k_screen_rows<2, 64> : R == 4 ? aog::k_screen_rows<4, 64> : aog::k_screen_rows<8, 64>)
+                         : (R == 1 ? aog::k_screen_rows<1, 60> : R == 2 ? aog::k_screen_rows<2, 60> : R == 4 ? aog::k_screen_rows<4, 60> : aog::k_screen_rows<8, 60>);
+    auto cols = LW == 64 ? (R == 1 ? aog::k_screen_cols<1, 64> : R == 2 ? aog::k_screen_cols<2, 64> : R == 4 ? aog::k_screen_cols<4, 64> : aog::k_screen_cols<8, 64>)
+                         : (R == 1 ? aog::k_screen_cols<1, 60> : R == 2 ? aog::k_screen_cols<2, 60> : R == 4 ? aog::k_screen_cols<4, 60> : aog::k_screen_cols<8, 60>);
     if (!e->syn_attr_set) {
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(rows), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(cols), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

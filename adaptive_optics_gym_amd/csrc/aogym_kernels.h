@@ -2039,6 +2039,59 @@ __device__ __forceinline__ void dft_reg(cf32 (&x)[NP]) {
   });
 }
 
+// 60-point variant (pupils of 60, 120, 240 (the reference's size), 480 pixels): mixed radix 2 x 2 x 3 x 5, recursive decimation in
+// time over the smallest prime factor, every index compile-time; output in natural order.
+struct Tw60 { float c[60][2]; };
+__device__ constexpr Tw60 kTw60 = {{{1.000000000e+00f, 0.000000000e+00f}, {9.945218954e-01f, 1.045284633e-01f}, {9.781476007e-01f, 2.079116908e-01f}, {9.510565163e-01f, 3.090169944e-01f}, {9.135454576e-01f, 4.067366431e-01f}, {8.660254038e-01f, 5.000000000e-01f}, {8.090169944e-01f, 5.877852523e-01f}, {7.431448255e-01f, 6.691306064e-01f}, {6.691306064e-01f, 7.431448255e-01f}, {5.877852523e-01f, 8.090169944e-01f}, {5.000000000e-01f, 8.660254038e-01f}, {4.067366431e-01f, 9.135454576e-01f}, {3.090169944e-01f, 9.510565163e-01f}, {2.079116908e-01f, 9.781476007e-01f}, {1.045284633e-01f, 9.945218954e-01f}, {2.832769449e-16f, 1.000000000e+00f}, {-1.045284633e-01f, 9.945218954e-01f}, {-2.079116908e-01f, 9.781476007e-01f}, {-3.090169944e-01f, 9.510565163e-01f}, {-4.067366431e-01f, 9.135454576e-01f}, {-5.000000000e-01f, 8.660254038e-01f}, {-5.877852523e-01f, 8.090169944e-01f}, {-6.691306064e-01f, 7.431448255e-01f}, {-7.431448255e-01f, 6.691306064e-01f}, {-8.090169944e-01f, 5.877852523e-01f}, {-8.660254038e-01f, 5.000000000e-01f}, {-9.135454576e-01f, 4.067366431e-01f}, {-9.510565163e-01f, 3.090169944e-01f}, {-9.781476007e-01f, 2.079116908e-01f}, {-9.945218954e-01f, 1.045284633e-01f}, {-1.000000000e+00f, 5.665538898e-16f}, {-9.945218954e-01f, -1.045284633e-01f}, {-9.781476007e-01f, -2.079116908e-01f}, {-9.510565163e-01f, -3.090169944e-01f}, {-9.135454576e-01f, -4.067366431e-01f}, {-8.660254038e-01f, -5.000000000e-01f}, {-8.090169944e-01f, -5.877852523e-01f}, {-7.431448255e-01f, -6.691306064e-01f}, {-6.691306064e-01f, -7.431448255e-01f}, {-5.877852523e-01f, -8.090169944e-01f}, {-5.000000000e-01f, -8.660254038e-01f}, {-4.067366431e-01f, -9.135454576e-01f}, {-3.090169944e-01f, -9.510565163e-01f}, {-2.079116908e-01f, -9.781476007e-01f}, {-1.045284633e-01f, -9.945218954e-01f}, {-1.836970199e-16f, -1.000000000e+00f}, {1.045284633e-01f, -9.945218954e-01f}, {2.079116908e-01f, -9.781476007e-01f}, {3.090169944e-01f, -9.510565163e-01f}, {4.067366431e-01f, -9.135454576e-01f}, {5.000000000e-01f, -8.660254038e-01f}, {5.877852523e-01f, -8.090169944e-01f}, {6.691306064e-01f, -7.431448255e-01f}, {7.431448255e-01f, -6.691306064e-01f}, {8.090169944e-01f, -5.877852523e-01f}, {8.660254038e-01f, -5.000000000e-01f}, {9.135454576e-01f, -4.067366431e-01f}, {9.510565163e-01f, -3.090169944e-01f}, {9.781476007e-01f, -2.079116908e-01f}, {9.945218954e-01f, -1.045284633e-01f}}};
+template <int N> struct smallest_factor { static constexpr int v = (N % 2 == 0) ? 2 : (N % 3 == 0) ? 3 : (N % 5 == 0) ? 5 : N; };
+// in: element j of this sub-problem is src[OFF + STRIDE * j]; out: dst[0..N) natural order
+template <int N, int NTOP, int OFF, int STRIDE, class C, class TWF>
+__device__ __forceinline__ void dft_rec(const C* src, C* dst, TWF&& tw) {
+  if constexpr (N == 1) {
+    dst[0] = src[OFF];
+  } else {
+    constexpr int P = smallest_factor<N>::v, M = N / P;
+    C sub[P][M];
+    static_for<P>([&](auto sc) {
+      constexpr int s = decltype(sc)::v;
+      dft_rec<M, NTOP, OFF + STRIDE * s, STRIDE * P>(src, sub[s], tw);
+    });
+    static_for<M>([&](auto kc) {
+      constexpr int k = decltype(kc)::v;
+      C t[P];
+      static_for<P>([&](auto sc) {
+        constexpr int s = decltype(sc)::v;
+        constexpr int e = (s * k * (NTOP / N)) % NTOP;          // W_N^{s k}
+        t[s] = e == 0 ? sub[s][k] : cmul(sub[s][k], tw(e));
+      });
+      static_for<P>([&](auto jc) {
+        constexpr int j = decltype(jc)::v;
+        C acc = t[0];
+        static_for<P - 1>([&](auto sc) {
+          constexpr int s = decltype(sc)::v + 1;
+          constexpr int e = ((s * j) % P) * (NTOP / P);           // W_P^{s j}
+          acc = cadd(acc, e == 0 ? t[s] : cmul(t[s], tw(e)));
+        });
+        dst[k + M * j] = acc;
+      });
+    });
+  }
+}
+
+template <int LW>
+__device__ __forceinline__ void dft_lanes(cf32 (&z)[64]) {   // inverse DFT of z[0..LW) in place, natural order out
+  if constexpr (LW == 64) {
+    dft_reg<64>(z);
+    cf32 t[64];
+    static_for<64>([&](auto ic) { t[decltype(ic)::v] = z[bitrev_c(decltype(ic)::v, 6)]; });
+    static_for<64>([&](auto ic) { z[decltype(ic)::v] = t[decltype(ic)::v]; });
+  } else {
+    cf32 t[LW];
+    dft_rec<LW, LW, 0, 1>(z, t, [](int e) { return cf32{kTw60.c[e][0], kTw60.c[e][1]}; });
+    static_for<LW>([&](auto ic) { z[decltype(ic)::v] = t[decltype(ic)::v]; });
+  }
+}
+
 struct ScreenSynthArgs {
   float2* T;                 // [env in batch][m][N] complex64
   float* out;                // [env in batch][N][N]
@@ -2050,12 +2103,12 @@ struct ScreenSynthArgs {
 
 // the shared transform: `load(bb_global, r)` supplies sample (a = lane + 64 r, b = bb_global) already multiplied by (-1)^a;
 // on return acc[p] (p < R) holds out[(p + R * lane) - N/2 ... i.e. output index i = p + R * lane of the centred crop.
-template <int R, class Load>
+template <int R, int LW, class Load>
 __device__ __forceinline__ void pruned_line(Load&& load, int q, int N, float* __restrict__ lbuf, cf32 (&acc)[R]) {
   // lbuf: this wave's private [64][65] float plane; real and imaginary parts cross it one after the other (half the LDS of a
   // complex plane: two workgroups fit a CU)
   constexpr int BCmax = 64 / R;
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63;   // lanes LW .. 63 idle in the per-sample phases (LW = 60 for N = 60 R)
   const int m = q * N;
   const int BC = min(q, BCmax);
   auto lds_fence = [] {
@@ -2088,27 +2141,28 @@ __device__ __forceinline__ void pruned_line(Load&& load, int q, int N, float* __
 #pragma unroll
         for (int p = 0; p < R; ++p) {
           const cf32 y = cmul(x[bitrev_c(p, log2_c(R))], wl[p]);
-          lbuf[(p * BC + bb) * 65 + lane] = y.x;
+          if (LW == 64 || lane < LW) lbuf[(p * BC + bb) * 65 + lane] = y.x;
           z[bb * R + p].y = y.y;
         }
       }
     });
     lds_fence();
 #pragma unroll
-    for (int t = 0; t < 64; ++t) z[t].x = row[t];
+    for (int t = 0; t < LW; ++t) z[t].x = row[t];
     lds_fence();
     static_for<BCmax>([&](auto bc) {
       constexpr int bb = decltype(bc)::v;
       if (bb < BC) {
 #pragma unroll
-        for (int p = 0; p < R; ++p) lbuf[(p * BC + bb) * 65 + lane] = z[bb * R + p].y;
+        for (int p = 0; p < R; ++p)
+          if (LW == 64 || lane < LW) lbuf[(p * BC + bb) * 65 + lane] = z[bb * R + p].y;
       }
     });
     lds_fence();
 #pragma unroll
-    for (int t = 0; t < 64; ++t) z[t].y = row[t];
-    // 2) every lane s < R * BC owns a 64-point sequence
-    dft_reg<64>(z);
+    for (int t = 0; t < LW; ++t) z[t].y = row[t];
+    // 2) every lane s < R * BC owns an LW-point sequence
+    dft_lanes<LW>(z);
     // 3) b-twiddles e^{2 pi i b (i - N/2) / m}, i = p + R i2, by recurrence over i2 (exact restart every 16 steps)
     const int p_of = lane / BC, b_of = b0 + (lane - p_of * BC);
     cf32 tw, step;
@@ -2119,10 +2173,10 @@ __device__ __forceinline__ void pruned_line(Load&& load, int q, int N, float* __
       __sincosf(6.2831853071795865f * (float)b_of * ((float)R / (float)m), &sn, &cs);
       step = cf32{cs, sn};
     }
-    static_for<64>([&](auto tc) {
+    static_for<LW>([&](auto tc) {
       constexpr int i2 = decltype(tc)::v;
-      z[bitrev_c(i2, 6)] = cmul(z[bitrev_c(i2, 6)], tw);
-      if constexpr ((i2 & 15) == 15 && i2 != 63) {
+      z[i2] = cmul(z[i2], tw);
+      if constexpr ((i2 & 15) == 15 && i2 != LW - 1) {
         float sn, cs;
         __sincosf(6.2831853071795865f * (float)b_of * ((float)(p_of + R * (i2 + 1) - N / 2) / (float)m), &sn, &cs);
         tw = cf32{cs, sn};
@@ -2132,9 +2186,9 @@ __device__ __forceinline__ void pruned_line(Load&& load, int q, int N, float* __
     });
     // 4) second transpose (real plane, then imaginary): lane j sums over the b's of this group for its R outputs i = p + R j
     lds_fence();
-    static_for<64>([&](auto tc) {
+    static_for<LW>([&](auto tc) {
       constexpr int i2 = decltype(tc)::v;
-      if (active) lbuf[lane * 65 + i2] = z[bitrev_c(i2, 6)].x;
+      if (active) lbuf[lane * 65 + i2] = z[i2].x;
     });
     lds_fence();
 #pragma unroll
@@ -2144,9 +2198,9 @@ __device__ __forceinline__ void pruned_line(Load&& load, int q, int N, float* __
       acc[p].x = sum;
     }
     lds_fence();
-    static_for<64>([&](auto tc) {
+    static_for<LW>([&](auto tc) {
       constexpr int i2 = decltype(tc)::v;
-      if (active) lbuf[lane * 65 + i2] = z[bitrev_c(i2, 6)].y;
+      if (active) lbuf[lane * 65 + i2] = z[i2].y;
     });
     lds_fence();
 #pragma unroll
@@ -2160,7 +2214,7 @@ __device__ __forceinline__ void pruned_line(Load&& load, int q, int N, float* __
 }
 
 // Pass A: grid (m / 4, envs in batch), 4 waves, one spectrum line v per wave.  LDS 4 x 64 x 65 x 4 B.
-template <int R>
+template <int R, int LW>
 __global__ __launch_bounds__(256) void k_screen_rows(ScreenSynthArgs p) {
   extern __shared__ float lds_syn[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -2169,11 +2223,11 @@ __global__ __launch_bounds__(256) void k_screen_rows(ScreenSynthArgs p) {
   const int b = blockIdx.y;
   if (v >= m) return;
   const float fv = p.du * (float)(v < m / 2 ? v : v - m);
-  const float sign = (lane & 1) ? -1.f : 1.f;   // (-1)^a, a = lane + 64 r
+  const float sign = (lane & 1) ? -1.f : 1.f;   // (-1)^a, a = lane + LW r (LW is even)
   cf32 pending[R];   // second sample of the Philox pair drawn for (a, b even): consumed as (a, b + 1)
   auto load = [&](int bg, int r, auto oddc) -> cf32 {
     // samples come in Philox pairs (u even, u + 1): b even draws, b odd uses the second half
-    const int a = lane + 64 * r;
+    const int a = min(lane, LW - 1) + LW * r;   // (idle lanes compute a duplicate that is never stored)
     const int u = q * a + bg;
     if constexpr (decltype(oddc)::v == 1) return pending[r];   // (only reached with q > 1: q = 1 has the single b = 0)
     const size_t idx = (size_t)v * m + (u & ~1);
@@ -2205,14 +2259,16 @@ __global__ __launch_bounds__(256) void k_screen_rows(ScreenSynthArgs p) {
     return o[0];
   };
   cf32 acc[R];
-  pruned_line<R>(load, q, N, lds_syn + (size_t)wave * 64 * 65, acc);
+  pruned_line<R, LW>(load, q, N, lds_syn + (size_t)wave * 64 * 65, acc);
   float2* dst = p.T + ((size_t)b * m + v) * N + (size_t)R * lane;
+  if (lane < LW) {
 #pragma unroll
-  for (int pp = 0; pp < R; ++pp) dst[pp] = make_float2(acc[pp].x, acc[pp].y);
+    for (int pp = 0; pp < R; ++pp) dst[pp] = make_float2(acc[pp].x, acc[pp].y);
+  }
 }
 
 // Pass B: grid (N / 4, envs in batch), one column ix per wave; reads T[v][ix] (the 4 waves of a workgroup share its cache lines).
-template <int R>
+template <int R, int LW>
 __global__ __launch_bounds__(256, 2) void k_screen_cols(ScreenSynthArgs p) {
   extern __shared__ float lds_syn[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -2223,15 +2279,17 @@ __global__ __launch_bounds__(256, 2) void k_screen_cols(ScreenSynthArgs p) {
   const float sign = (lane & 1) ? -1.f : 1.f;
   const float2* src = p.T + (size_t)b * m * N + ix;
   auto load = [&](int bg, int r, auto) -> cf32 {
-    const int vv = q * (lane + 64 * r) + bg;
+    const int vv = q * (min(lane, LW - 1) + LW * r) + bg;
     const float2 t = src[(size_t)vv * N];
     return cf32{sign * t.x, sign * t.y};
   };
   cf32 acc[R];
-  pruned_line<R>(load, q, N, lds_syn + (size_t)wave * 64 * 65, acc);
+  pruned_line<R, LW>(load, q, N, lds_syn + (size_t)wave * 64 * 65, acc);
   float* dst = p.out + (size_t)b * N * N + ix;
+  if (lane < LW) {
 #pragma unroll
-  for (int pp = 0; pp < R; ++pp) dst[(size_t)(pp + R * lane) * N] = acc[pp].x * p.crop_scale;
+    for (int pp = 0; pp < R; ++pp) dst[(size_t)(pp + R * lane) * N] = acc[pp].x * p.crop_scale;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------

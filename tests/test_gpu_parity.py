@@ -701,11 +701,12 @@ def test_device_screen_synthesis_statistics():
     env.close()
 
 
-@pytest.mark.parametrize("N,q", [(64, 8), (128, 4), (256, 16), (512, 2)])
+@pytest.mark.parametrize("N,q", [(64, 8), (128, 4), (256, 16), (512, 2), (60, 8), (120, 4), (240, 16), (480, 2)])
 def test_pruned_screen_synthesis_matches_full_transform(monkeypatch, N, q):
-    """K8, power-of-two pupils: the pruned two-pass synthesis (Philox lines -> length-N transforms in registers/LDS, never the
+    """K8, pupils of 64 R or 60 R pixels (R = 1, 2, 4, 8; 240 is the reference's size): the pruned two-pass synthesis (Philox lines -> length-N transforms in registers/LDS, never the
     (qN)^2 array) gives the same screens as spectrum fill + hipFFT + centred crop on the same Philox stream; only fp32 rounding
-    (and the float amplitude law) differs.  Covers 1, 2, 4 and 8 points per lane and one or two b-groups per line."""
+    (and the float amplitude law) differs.  Covers 1, 2, 4 and 8 points per lane, one or two b-groups per line, and both the
+    radix-2 64-point and the mixed-radix (2 x 2 x 3 x 5) 60-point in-register transform."""
     torch = _torch()
     from adaptive_optics_gym_amd import BatchedAOEnv
 

@@ -11,6 +11,6 @@ def run(N, q, full, B=3):
     ps = np.stack([env.phase_screen(i).cpu().numpy() for i in range(B)])
     env.close()
     return ps
-for N, q in ((64, 4), (128, 4), (256, 2), (64, 16), (256, 16)):
+for N, q in ((60, 8), (120, 4), (240, 16), (480, 2), (256, 16), (64, 4)):
     a = run(N, q, True); b = run(N, q, False)
     print(N, q, "rms full %.4e  max|diff|/rms %.3e" % (a.std(), np.abs(a - b).max() / a.std()), flush=True)
