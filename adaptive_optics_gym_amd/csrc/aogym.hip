@@ -7,6 +7,7 @@
 #include <hipfft/hipfft.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -150,6 +151,7 @@ int launch_epilogue(aog_env* e, bool is_step, float* obs_raw, uint16_t* obs, flo
   p.has_thr = e->cfg.has_rew_threshold;
   p.max_steps = e->cfg.max_steps;
   p.is_step = is_step ? 1 : 0;
+  p.partials_f32 = (e->tab_mfma && e->MRW > 8 && e->cfg.precision == AOG_PRECISION_FAST) ? 1 : 0;
   p.thr = e->cfg.rew_threshold;
   p.ssim_peak = e->cfg.ssim_ref_peak;
   p.ssim_alpha = e->cfg.ssim_alpha;
@@ -374,6 +376,10 @@ int aog_create(const aog_config* cfg, int device, aog_env** out) {
     }
     e->kernel = cfg->kernel == AOG_KERNEL_AUTO ? AOG_KERNEL_MFMA : cfg->kernel;
     if (e->kernel == AOG_KERNEL_MFMA && e->A_pad > 64 && getenv("AOG_WIDE_VALU")) e->kernel = AOG_KERNEL_VALU;   // developer comparison
+    // table reduction on the matrix cores: default for the 12/20/28-table variants (o >= 3), opt-in (AOG_TABLES_MFMA=1) / opt-out
+    // (AOG_TABLES_MFMA=0) otherwise
+    e->tab_mfma = e->kernel == AOG_KERNEL_MFMA && e->MRW >= 12;
+    if (const char* tm = getenv("AOG_TABLES_MFMA")) e->tab_mfma = e->kernel == AOG_KERNEL_MFMA && atoi(tm) != 0;
     // launch geometry: aim at ~3 (VALU) / ~2 (MFMA) waves per SIMD over 256 CUs
     const int n_groups = e->Bp / 64;
     int P = cfg->pixel_chunks > 0 ? cfg->pixel_chunks : std::max(1, (256 * 4 * 3 + n_groups - 1) / n_groups);
@@ -388,6 +394,7 @@ int aog_create(const aog_config* cfg, int device, aog_env** out) {
     int Pm = cfg->pixel_chunks > 0 ? cfg->pixel_chunks : std::max(1, (256 * 2) / wg_y);
     int max_tpc = std::max(1, (int)(60 * 1024 / (8 * (e->MRW + 1) * 16)));
     if (e->MRW >= 20) max_tpc = std::min(max_tpc, aog::kF32AccTiles * wp);   // fp32-only accumulation: bounded terms per lane
+    if (e->tab_mfma) max_tpc = e->MRW > 8 ? aog::kTabF32Tiles * wp : 4096;   // no table stage in LDS; fp32-only variants: bounded chunks
     Pm = std::max(Pm, (e->n_ptiles + max_tpc - 1) / max_tpc);
     Pm = std::min(Pm, e->n_ptiles);
     e->mfma_chunks_x = Pm;
@@ -442,6 +449,8 @@ int aog_create(const aog_config* cfg, int device, aog_env** out) {
     TRY_ALLOC(dev_alloc(e, &e->modes16, (size_t)e->n_ap_pad * e->A_pad * 2));
     TRY_ALLOC(dev_alloc(e, &e->tabs_f32, (size_t)e->n_ap_pad * TROW));
     TRY_ALLOC(dev_alloc(e, &e->tabs_tile, (size_t)e->n_ap_pad * (e->MRW + e->MRS)));
+    TRY_ALLOC(dev_alloc(e, &e->tab16, (size_t)e->n_ptiles * 2 * 2 * 64 * 8));
+    TRY_ALLOC(dev_alloc(e, &e->sci_tile, (size_t)e->n_ptiles * 32));
     TRY_ALLOC(dev_alloc(e, &e->psi_rev, (size_t)e->n_quads * e->Bp * 4));
     TRY_ALLOC(dev_alloc(e, &e->psi_tile, (size_t)e->n_etiles * e->n_ptiles * 1024));
   } else {
@@ -538,6 +547,31 @@ int aog_upload_tables(aog_env* e, const aog_tables* t) {
         tt[((((size_t)pt * 4 + g) * 2 + h) * MR + m) * 4 + r] = v;
       }
     HIP_TRY(hipMemcpy(e->modes_f32, mf.data(), sizeof(float) * mf.size(), hipMemcpyHostToDevice));
+    {
+      // table-MFMA form: A operand of step s, lane (kg, m), element el <-> pixel i = (el & 3) + 16 s + 8 (el >> 2) + 4 kg of the tile
+      std::vector<_Float16> t16((size_t)e->n_ptiles * 2 * 2 * 64 * 8, (_Float16)0.f);
+      std::vector<float> st((size_t)e->n_ptiles * 32, 0.f);
+      for (int pt = 0; pt < e->n_ptiles; ++pt)
+        for (int sidx = 0; sidx < 2; ++sidx)
+          for (int kg = 0; kg < 2; ++kg)
+            for (int el = 0; el < 8; ++el) {
+              const int i = (el & 3) + 16 * sidx + 8 * (el >> 2) + 4 * kg;
+              const int p = pt * 32 + i;
+              if (p >= n_ap) continue;
+              for (int m = 0; m < e->MRW_used && m < 32; ++m) {
+                const float v = (float)t->wfs_tables[(size_t)m * n_ap + p];
+                const _Float16 hi = (_Float16)v;
+                const _Float16 lo = (_Float16)(v - (float)hi);
+                const size_t base = ((((size_t)pt * 2 + sidx) * 2) * 64 + (kg * 32 + m)) * 8 + el;
+                t16[base] = hi;
+                t16[base + (size_t)64 * 8] = lo;
+              }
+              // science table: register a = 8 s + el of half-wave h = kg
+              if (e->MRS_used > 0) st[((size_t)pt * 2 + kg) * 16 + 8 * sidx + el] = (float)t->sci_tables[p];
+            }
+      HIP_TRY(hipMemcpy(e->tab16, t16.data(), sizeof(_Float16) * t16.size(), hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(e->sci_tile, st.data(), sizeof(float) * st.size(), hipMemcpyHostToDevice));
+    }
     HIP_TRY(hipMemcpy(e->modes16, m16.data(), sizeof(_Float16) * m16.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->tabs_f32, tf.data(), sizeof(float) * tf.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->tabs_tile, tt.data(), sizeof(float) * tt.size(), hipMemcpyHostToDevice));
@@ -1151,12 +1185,12 @@ int aog_actor_act(const aog_actor* n, int device, const void* obs_dev, int obs_i
   a.call_hi = (uint32_t)(n->call_index >> 32);
   const size_t lds = ((size_t)2 * a.kpad * 16 + 16 + (size_t)aog::kActorWFloats) * sizeof(float);
   if (lds > 64 * 1024) {
-    static bool attr_set = false;   // one process-wide attribute: the largest request so far
-    static size_t attr_bytes = 0;
-    if (!attr_set || lds > attr_bytes) {
+    // the attribute is per device: remember the largest request made on each (one process normally drives one GPU)
+    static std::atomic<size_t> attr_bytes[64];
+    const int slot = device >= 0 && device < 64 ? device : 0;
+    if (lds > attr_bytes[slot].load(std::memory_order_relaxed)) {
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(aog::k_actor_act), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr_set = true;
-      attr_bytes = lds;
+      attr_bytes[slot].store(lds, std::memory_order_relaxed);
     }
   }
   hipLaunchKernelGGL(aog::k_actor_act, dim3((n->batch + 15) / 16), dim3(aog::kActorThreads), lds, static_cast<hipStream_t>(stream), a);

@@ -31,6 +31,9 @@ struct aog_env {
   _Float16* modes16 = nullptr;   // [n_ptiles][A_pad/16][hi|lo][64][8]
   float* tabs_f32 = nullptr;     // [n_ap_pad][TROW]
   float* tabs_tile = nullptr;    // [n_ptiles][4][2][MRW+MRS][4]
+  _Float16* tab16 = nullptr;     // table-MFMA form: [n_ptiles][step 2][hi|lo][lane 64][8] A operands of the wfs tables
+  float* sci_tile = nullptr;     // [n_ptiles][h 2][16] science table in accumulator order
+  bool tab_mfma = false;         // table reduction on the matrix cores (k_fused_tab)
   double* gram = nullptr;        // [A][A]
   double* wfs_coef = nullptr;    // [n_out][MRW_used][2]
   double* sci_coef = nullptr;    // [MRS_used][2]

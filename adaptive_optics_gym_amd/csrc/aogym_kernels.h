@@ -334,6 +334,7 @@ __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_in
 // fp32 partial sums of the table reduction are folded into the float64 accumulators every kFlushTiles tiles (16 pixels per lane
 // each): the conversions + float64 adds are half-rate vector work, 16 of ~115 issue cycles per (pixel, env) if done every tile
 constexpr int kFlushTiles = 4;
+constexpr int kTabF32Tiles = 13;   // same for the table-MFMA form (32 terms per tile and accumulator element)
 constexpr int kF32AccTiles = 13;   // longest chunk (tiles per wave) of the variants that accumulate in fp32 only
 constexpr int kSkewNops = 150;   // x 16 cycles: start-up skew of the second workgroup of a CU (about half a stage)
 
@@ -687,6 +688,220 @@ __global__ __launch_bounds__(256, (MRW <= 12 && A_PAD <= 64 ? 2 : 1)) void k_fus
   }
 }
 
+// ---- K3b'  fused pupil pass with BOTH contractions on the f16 matrix cores ("table-MFMA" form) ---------------------------------
+// Same phase stage as k_fused_mfma.  The table reduction  Z_m(env) = sum_p G_m(p) (cos, sin)(u_p,env)  is a second MFMA:
+//   A = table rows (m < 32) x 16 pixels, f16 hi + lo (unscaled: v_mfma keeps f16 subnormals, measured), pre-arranged on the host
+//       in the pixel order in which the phase accumulator hands its 16 values per lane to the B operand (tab16);
+//   B = cos / sin of this lane's 8 pixels of the step, f16 hi + lo;  Gh Eh + Gh El + Gl Eh accumulate into ONE fp32 accumulator.
+// Per (pixel, env) the vector unit only does the 4 sin/cos, the hi/lo split (6 ops) and the two science-table FMAs, instead of
+// 2 (MRW + 1) FMAs; the matrix pipe (idle 85 % of the time in k_fused_mfma) takes 12 more instructions per tile.
+// Sums: tables m < MRW in the 32x32 accumulators (lane (env, h) holds rows (a & 3) + 8 (a >> 2) + 4 h); the 8-table variant
+// folds its (few) live rows into float64 every kFlushTiles tiles, the others run fp32 over a chunk of bounded length.
+template <int MRW>
+struct TabGeom {
+  static constexpr int kLiveRegs = MRW <= 8 ? 4 : (MRW <= 16 ? 8 : (MRW <= 24 ? 12 : 16));   // accumulator registers a < kLiveRegs hold real tables
+  static constexpr bool kF64 = MRW <= 8;
+};
+template <int A_PAD, int MRW>
+__global__ __launch_bounds__(256, 2) void k_fused_tab(const f16x8* __restrict__ modes16, const f16x8* __restrict__ tab16,
+                                                      const f32x4* __restrict__ sci_tile, const f32x4* __restrict__ psi_tile,
+                                                      const f16x8* __restrict__ act16, double* __restrict__ partials, MfmaGeom geo, float ratio) {
+  constexpr int NSTEP = A_PAD / 16, NM = 3 * NSTEP, NS = 2 * (MRW + 1);
+  constexpr int LIVE = TabGeom<MRW>::kLiveRegs;
+  constexpr bool F64 = TabGeom<MRW>::kF64;
+  extern __shared__ f32x4 lds_sci[];   // [tile in chunk][h][4] float4 = the science table in accumulator order
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int L = blockIdx.x, j = L >> 3;
+  const int c = (j / geo.wg_y) * 8 + (L & 7);
+  if (c >= geo.P) return;
+  const int we = geo.we, wp = 4 / we;
+  const int w_e = wave % we, w_p = wave / we;
+  const int etile = (j % geo.wg_y) * we + w_e;
+  const int t0 = (int)(((long long)c * geo.n_ptiles) / geo.P);
+  const int t1 = (int)(((long long)(c + 1) * geo.n_ptiles) / geo.P);
+  const int h = lane >> 5;
+  const int etile_c = min(etile, geo.n_etiles - 1);
+  const int first = t0 + w_p;
+  const int n = first < t1 ? (t1 - first + wp - 1) / wp : 0;
+  const int last = n > 0 ? first + (n - 1) * wp : min(t0, geo.n_ptiles - 1);
+  f16x8 bh[NSTEP], bl[NSTEP];
+  {
+    const f16x8* asrc = act16 + ((size_t)etile_c * NSTEP * 2) * 64 + lane;
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+      bh[s] = asrc[(2 * s) * 64];
+      bl[s] = asrc[(2 * s + 1) * 64];
+    }
+  }
+  const size_t psi_base = (size_t)etile_c * geo.n_ptiles;
+  auto load_modes = [&](f16x8 (&mh)[NSTEP], f16x8 (&ml)[NSTEP], int t) {
+    const f16x8* ms = modes16 + ((size_t)min(t, last) * NSTEP * 2) * 64 + lane;
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+      mh[s] = ms[(2 * s) * 64];
+      ml[s] = ms[(2 * s + 1) * 64];
+    }
+  };
+  auto load_psi = [&](int t) {
+    const f32x4* ps = psi_tile + ((psi_base + min(t, last)) * 4) * 64 + lane;
+    f32x16 d;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 v = ps[g * 64];
+      d[4 * g + 0] = v[0]; d[4 * g + 1] = v[1]; d[4 * g + 2] = v[2]; d[4 * g + 3] = v[3];
+    }
+    return d;
+  };
+  auto load_tab = [&](f16x8 (&ta)[4], int t) {   // [step][hi|lo]
+    const f16x8* ts = tab16 + ((size_t)min(t, last) * 4) * 64 + lane;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ta[q] = ts[q * 64];
+  };
+  f16x8 mh[NSTEP], ml[NSTEP], ta[4], tb[4];
+  load_modes(mh, ml, first);
+  f32x16 p_first = load_psi(first);
+  load_tab(ta, first);
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    const int n4 = (t1 - t0) * 8;
+    const f32x4* src = sci_tile + (size_t)t0 * 8;
+    for (int i = threadIdx.x; i < n4; i += 256) lds_sci[i] = src[i];
+  }
+  __syncthreads();
+  if (etile >= geo.n_etiles) return;
+  if ((j & 32) != 0 && kSkewNops > 0) {
+    for (int q = 0; q < kSkewNops; ++q) asm volatile("s_nop 15");
+  }
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  f32x16 Dc = zero16, Ds = zero16;          // table sums (cos, sin), rows by register
+  float sc_c = 0.f, sc_s = 0.f;             // science-table sums of this lane's pixels
+  double acc_t[F64 ? 2 * LIVE : 1];
+  double acc_sc = 0.0, acc_ss = 0.0;
+#pragma unroll
+  for (int i = 0; i < (F64 ? 2 * LIVE : 1); ++i) acc_t[i] = 0.0;
+  if (n > 0) {
+    auto mfma_q = [&](auto qc, f32x16& d1, f32x16& d2) {
+      constexpr int q = decltype(qc)::v, s = q / 3, w = q % 3;
+      if constexpr (w == 0) d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[s], bh[s], d1, 0, 0, 0);
+      else if constexpr (w == 1) d2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[s], bl[s], d2, 0, 0, 0);
+      else d2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ml[s], bh[s], d2, 0, 0, 0);
+    };
+    f32x16 d;
+    {
+      f32x16 d1 = zero16, d2 = zero16;
+      static_for<NM>([&](auto qc) { mfma_q(qc, d1, d2); });
+      d = d1 * kD1Unscale + (p_first + d2 * kD2Unscale);
+    }
+    // vector work + table MFMAs of the tile in `d` (tables in ta), with the THETA matrix ops of the next tile (if any) dealt between
+    auto reduce_tile = [&](int t, auto with_next, f32x16& d1, f32x16& d2) {
+      constexpr bool NEXT = decltype(with_next)::v != 0;
+      const f32x4* gs = lds_sci + (size_t)(t - t0) * 8 + h * 4;
+      static_for<2>([&](auto sc) {
+        constexpr int s = decltype(sc)::v;
+        f16x8 ch, cl, sh, sl;
+        const f32x4 g0 = gs[2 * s], g1 = gs[2 * s + 1];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float u = d[8 * s + e];
+          const float cw = __builtin_amdgcn_cosf(u), sw = __builtin_amdgcn_sinf(u);
+          const float us = u * ratio;
+          const float cs = __builtin_amdgcn_cosf(us), ss = __builtin_amdgcn_sinf(us);
+          const float g = e < 4 ? g0[e & 3] : g1[e & 3];
+          sc_c = fmaf(cs, g, sc_c);
+          sc_s = fmaf(ss, g, sc_s);
+          const _Float16 chh = (_Float16)cw, shh = (_Float16)sw;
+          ch[e] = chh;
+          sh[e] = shh;
+          cl[e] = (_Float16)(cw - (float)chh);
+          sl[e] = (_Float16)(sw - (float)shh);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // 6 table MFMAs of this step; ALL phase MFMAs of the next tile go behind step 0, so that they run under step 1's vector
+        // work and d(next) is ready when the stage ends
+        constexpr int LO = 0, HI = s == 0 ? NM : 0, CNT = HI - LO;
+        constexpr int C1 = LO + (CNT + 2) / 3, C2 = LO + (2 * CNT + 2) / 3;
+        auto theta = [&](auto lo, auto hi) {
+          if constexpr (NEXT && decltype(hi)::v > decltype(lo)::v)
+            static_for<decltype(hi)::v - decltype(lo)::v>([&](auto qc) { mfma_q(IC<decltype(lo)::v + decltype(qc)::v>{}, d1, d2); });
+        };
+        Dc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ta[2 * s], ch, Dc, 0, 0, 0);
+        theta(IC<LO>{}, IC<C1>{});
+        Ds = __builtin_amdgcn_mfma_f32_32x32x16_f16(ta[2 * s], sh, Ds, 0, 0, 0);
+        Dc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ta[2 * s], cl, Dc, 0, 0, 0);
+        theta(IC<C1>{}, IC<C2>{});
+        Ds = __builtin_amdgcn_mfma_f32_32x32x16_f16(ta[2 * s], sl, Ds, 0, 0, 0);
+        Dc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ta[2 * s + 1], ch, Dc, 0, 0, 0);
+        theta(IC<C2>{}, IC<HI>{});
+        Ds = __builtin_amdgcn_mfma_f32_32x32x16_f16(ta[2 * s + 1], sh, Ds, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    };
+    auto flush = [&] {
+      acc_sc += (double)sc_c; acc_ss += (double)sc_s;
+      sc_c = 0.f; sc_s = 0.f;
+      if constexpr (F64) {
+        static_for<LIVE>([&](auto ac) {
+          constexpr int a = decltype(ac)::v;
+          acc_t[2 * a] += (double)Dc[a];
+          acc_t[2 * a + 1] += (double)Ds[a];
+          Dc[a] = 0.f;
+          Ds[a] = 0.f;
+        });
+      }
+    };
+    for (int i = 0, t = first; i + 1 < n; ++i, t += wp) {
+      f32x16 d1 = zero16, d2 = zero16;
+      load_modes(mh, ml, t + wp);
+      const f32x16 p = load_psi(t + wp);
+      load_tab(tb, t + wp);
+      __builtin_amdgcn_sched_barrier(0);
+      reduce_tile(t, IC<1>{}, d1, d2);
+      d = d1 * kD1Unscale + (p + d2 * kD2Unscale);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) ta[q] = tb[q];
+      if ((i % kFlushTiles) == kFlushTiles - 1) flush();
+    }
+    {
+      f32x16 d1 = zero16, d2 = zero16;
+      reduce_tile(last, IC<0>{}, d1, d2);
+    }
+    flush();
+  }
+  const int chunk = c * wp + w_p;
+  if constexpr (F64) {
+    double* out = partials + (size_t)chunk * NS * geo.Bp + (size_t)etile * 32 + (lane & 31);
+    static_for<LIVE>([&](auto ac) {
+      constexpr int a = decltype(ac)::v;
+      const int m = (a & 3) + 8 * (a >> 2) + 4 * h;
+      if (m < MRW) {
+        out[(size_t)(2 * m) * geo.Bp] = acc_t[2 * a];
+        out[(size_t)(2 * m + 1) * geo.Bp] = acc_t[2 * a + 1];
+      }
+    });
+    const double vc = acc_sc + __shfl_down(acc_sc, 32, 64), vs = acc_ss + __shfl_down(acc_ss, 32, 64);
+    if (h == 0) {
+      out[(size_t)(2 * MRW) * geo.Bp] = vc;
+      out[(size_t)(2 * MRW + 1) * geo.Bp] = vs;
+    }
+  } else {
+    // the sums of these variants are fp32 anyway: the slabs are written (and read by the epilogue) as float, half the traffic
+    float* out = reinterpret_cast<float*>(partials) + (size_t)chunk * NS * geo.Bp + (size_t)etile * 32 + (lane & 31);
+    static_for<LIVE>([&](auto ac) {
+      constexpr int a = decltype(ac)::v;
+      const int m = (a & 3) + 8 * (a >> 2) + 4 * h;
+      if (m < MRW) {
+        out[(size_t)(2 * m) * geo.Bp] = Dc[a];
+        out[(size_t)(2 * m + 1) * geo.Bp] = Ds[a];
+      }
+    });
+    const double vc = acc_sc + __shfl_down(acc_sc, 32, 64), vs = acc_ss + __shfl_down(acc_ss, 32, 64);
+    if (h == 0) {
+      out[(size_t)(2 * MRW) * geo.Bp] = (float)vc;
+      out[(size_t)(2 * MRW + 1) * geo.Bp] = (float)vs;
+    }
+  }
+}
+
 // Phase-only form of the contraction: u = psi + Mt a for every (pixel, env), written back in the psi_tile layout.  Used by the
 // Shack-Hartmann chain, whose mirror (deformable_mirror_shack) carries its own actuators.  One wave per (env tile, pixel tile).
 template <int A_PAD>
@@ -780,6 +995,7 @@ struct EpilogueArgs {
   float* strehl;
   int32_t* t_render;
   int B, Bp, n_chunks, MRW, MRS, MRW_used, MRS_used, n_obs, n_fiber, reward_type, has_thr, max_steps, is_step;
+  int partials_f32;   // slabs hold float (table-MFMA variants with fp32-only sums) instead of double
   double thr, ssim_peak, ssim_alpha;
 };
 
@@ -836,14 +1052,23 @@ __global__ __launch_bounds__(1024) void k_epilogue(EpilogueArgs p) {
   for (int i = threadIdx.x; i < n_out * p.MRW_used * 2; i += blockDim.x) cfs[i] = p.wfs_coef[i];
   for (int i = threadIdx.x; i < p.MRS_used * 2; i += blockDim.x) cfsci[i] = p.sci_coef[i];
   for (int s = q; s < NS; s += 16) {
-    const double* src = p.partials + (size_t)s * p.Bp + env;
     double a[4] = {0, 0, 0, 0};
     int c = cq;
-    for (; c + 3 * kEpiGroups < p.n_chunks; c += 4 * kEpiGroups) {
+    if (p.partials_f32) {
+      const float* src = reinterpret_cast<const float*>(p.partials) + (size_t)s * p.Bp + env;
+      for (; c + 3 * kEpiGroups < p.n_chunks; c += 4 * kEpiGroups) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) a[u] += src[(size_t)(c + kEpiGroups * u) * cstride];
+        for (int u = 0; u < 4; ++u) a[u] += (double)src[(size_t)(c + kEpiGroups * u) * cstride];
+      }
+      for (; c < p.n_chunks; c += kEpiGroups) a[0] += (double)src[(size_t)c * cstride];
+    } else {
+      const double* src = p.partials + (size_t)s * p.Bp + env;
+      for (; c + 3 * kEpiGroups < p.n_chunks; c += 4 * kEpiGroups) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] += src[(size_t)(c + kEpiGroups * u) * cstride];
+      }
+      for (; c < p.n_chunks; c += kEpiGroups) a[0] += src[(size_t)c * cstride];
     }
-    for (; c < p.n_chunks; c += kEpiGroups) a[0] += src[(size_t)c * cstride];
     part[((size_t)cq * NS + s) * kEpiEnvs + e] = (a[0] + a[1]) + (a[2] + a[3]);
   }
   __syncthreads();

@@ -31,6 +31,13 @@ void launch_mfma(aog_env* e, hipStream_t s) {
   g.max_tiles = e->mfma_tpc;
   dim3 grid(round_up(g.P, 8) * g.wg_y);
   const float ratio = (float)(e->cfg.wavelength_wfs / e->cfg.wavelength_sci);
+  if (e->tab_mfma) {
+    const size_t lds_t = (size_t)e->mfma_tpc * 8 * 16;
+    hipLaunchKernelGGL((aog::k_fused_tab<A_PAD, MRW>), grid, dim3(256), lds_t, s, reinterpret_cast<const aog::f16x8*>(e->modes16),
+                       reinterpret_cast<const aog::f16x8*>(e->tab16), reinterpret_cast<const aog::f32x4*>(e->sci_tile),
+                       reinterpret_cast<const aog::f32x4*>(e->psi_tile), reinterpret_cast<const aog::f16x8*>(e->act16), e->partials, g, ratio);
+    return;
+  }
   size_t lds = (size_t)e->mfma_tpc * 8 * (MRW + 1) * 16;
   if (const char* pad = getenv("AOG_LDS_PAD_KB")) lds = std::max(lds, (size_t)atoi(pad) * 1024);   // developer aid: force one workgroup per CU
   g.max_tiles = getenv("AOG_NO_HOIST") ? -e->mfma_tpc : e->mfma_tpc;

@@ -215,11 +215,12 @@ def test_full_size_properties_config2():
     ref.close()
 
 
-@pytest.mark.parametrize("N,A,o,rew", [(256, 64, 5, "smf_ssim"), (512, 20, 5, "smf_ssim"), (256, 100, 4, "strehl_ratio")])
+@pytest.mark.parametrize("N,A,o,rew", [(256, 64, 5, "smf_ssim"), (512, 20, 5, "smf_ssim"), (256, 100, 4, "strehl_ratio"), (256, 64, 3, "smf_ssim"),
+                                      (240, 64, 5, "smf_ssim")])
 def test_full_size_many_table_variants_vs_float64_kernel(N, A, o, rew):
-    """The 20/28-table variants (o = 4, 5: BASELINE configs[2] and [4] shapes) accumulate their table sums in fp32 over a whole
-    chunk (<= 13 tiles, 208 terms per lane) and widen once; at full pupil sizes they still meet the observation tolerance
-    against the float64 device kernel, on strong von Karman screens."""
+    """The 12/20/28-table variants (o = 3, 4, 5: BASELINE configs[2] and [4] shapes) run their table reduction on the matrix
+    cores with fp32 accumulation over a whole chunk (<= 13 tiles, 416 terms per accumulator element) and float slabs; at full
+    pupil sizes they still meet the observation tolerance against the float64 device kernel, on strong von Karman screens."""
     torch = _torch()
     from adaptive_optics_gym_amd import BatchedAOEnv
     from adaptive_optics_gym_amd.atmosphere_host import cn_squared_from_fried_parameter, screens_torch
