@@ -141,6 +141,15 @@ int launch_epilogue(aog_env* e, bool is_step, float* obs_raw, uint16_t* obs, flo
   p.Bp = e->Bp;
   const bool ref = e->cfg.precision == AOG_PRECISION_FP64;
   p.n_chunks = ref ? 1 : e->n_chunks;
+  if (e->tab_mfma && e->MRW > 8 && e->cfg.precision == AOG_PRECISION_FAST) {
+    // many short float chunks: fold them first with a fully coalesced pass, the epilogue then reads one float64 slab
+    const int NSr = 2 * (e->MRW + e->MRS);
+    hipLaunchKernelGGL(aog::k_reduce_slabs, dim3(e->Bp / 64, (NSr + 3) / 4), dim3(256), 0, s, reinterpret_cast<const float*>(e->partials),
+                       e->slab_reduced, e->n_chunks, NSr, e->Bp);
+    p.partials = e->slab_reduced;
+    p.n_chunks = 1;
+    p.partials_f32 = 0;
+  }
   p.MRW = ref ? e->MRW_used : e->MRW;
   p.MRS = ref ? e->MRS_used : e->MRS;
   p.MRW_used = e->MRW_used;
@@ -151,7 +160,7 @@ int launch_epilogue(aog_env* e, bool is_step, float* obs_raw, uint16_t* obs, flo
   p.has_thr = e->cfg.has_rew_threshold;
   p.max_steps = e->cfg.max_steps;
   p.is_step = is_step ? 1 : 0;
-  p.partials_f32 = (e->tab_mfma && e->MRW > 8 && e->cfg.precision == AOG_PRECISION_FAST) ? 1 : 0;
+  p.partials_f32 = 0;   // (float slabs are folded by k_reduce_slabs above; the epilogue's own float path is kept for reference)
   p.thr = e->cfg.rew_threshold;
   p.ssim_peak = e->cfg.ssim_ref_peak;
   p.ssim_alpha = e->cfg.ssim_alpha;
@@ -422,6 +431,7 @@ int aog_create(const aog_config* cfg, int device, aog_env** out) {
   TRY_ALLOC(dev_alloc(e, &e->t_render, e->B));
   TRY_ALLOC(dev_alloc(e, &e->dev_status, 16));
   TRY_ALLOC(dev_alloc(e, &e->partials, e->partial_elems));
+  TRY_ALLOC(dev_alloc(e, &e->slab_reduced, (size_t)2 * 64 * e->Bp));   // [NS <= 58][Bp] float64 (k_reduce_slabs)
   if (cfg->atm_dynamic) {
     const size_t N2 = (size_t)cfg->n_pupil * cfg->n_pupil;
     TRY_ALLOC(dev_alloc(e, &e->psi_master, (size_t)e->B * N2));

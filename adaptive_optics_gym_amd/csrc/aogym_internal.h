@@ -119,6 +119,7 @@ struct aog_env {
   int next_noise_max_ext = 0;
   unsigned long long rng_seed = 1234;
   double* partials = nullptr;
+  double* slab_reduced = nullptr;   // single float64 slab [NS][Bp] after k_reduce_slabs
   size_t partial_elems = 0;
   // profiling of the fused kernel
   bool profile = false;

@@ -1021,6 +1021,26 @@ __device__ inline double ssim_1d_delta_ref(const double* x, int stride, int n, d
   return sum / cnt;
 }
 
+// Pre-reduction of float slabs (table-MFMA variants write many short chunks): out[s][env] = sum_c part[c][s][env], one thread per
+// (s, env), envs along the lanes (256-B rows), eight independent loads in flight.  The epilogue then sees a single float64 slab.
+#ifdef AOG_MAIN_TU
+__global__ __launch_bounds__(256) void k_reduce_slabs(const float* __restrict__ part, double* __restrict__ out, int n_chunks, int NS, int Bp) {
+  const int env = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int s = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (env >= Bp || s >= NS) return;
+  const size_t cstride = (size_t)NS * Bp;
+  const float* src = part + (size_t)s * Bp + env;
+  double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int c = 0;
+  for (; c + 7 < n_chunks; c += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] += (double)src[(size_t)(c + u) * cstride];
+  }
+  for (; c < n_chunks; ++c) a[0] += (double)src[(size_t)c * cstride];
+  out[(size_t)s * Bp + env] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+}
+#endif  // AOG_MAIN_TU
+
 // block = 4 envs x 16 sum slots x 16 chunk groups (1024 threads, grid = ceil(Bp / 4): 256 workgroups at B = 1024, one per CU):
 // thread (e, q, cq) adds sums s = q, q + 16, ... over chunks cq, cq + 16, ... (independent loads in flight); the chunk groups meet
 // in LDS; then one thread per (env, output) forms |coef . sums|^2, and one thread per env finishes reward / done / power.
