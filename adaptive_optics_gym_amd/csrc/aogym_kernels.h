@@ -757,7 +757,7 @@ __global__ __launch_bounds__(256, 2) void k_fused_tab(const f16x8* __restrict__ 
 #pragma unroll
     for (int q = 0; q < 4; ++q) ta[q] = ts[q * 64];
   };
-  f16x8 mh[NSTEP], ml[NSTEP], ta[4], tb[4];
+  f16x8 mh[NSTEP], ml[NSTEP], ta[4];
   load_modes(mh, ml, first);
   f32x16 p_first = load_psi(first);
   load_tab(ta, first);
@@ -792,49 +792,42 @@ __global__ __launch_bounds__(256, 2) void k_fused_tab(const f16x8* __restrict__ 
       static_for<NM>([&](auto qc) { mfma_q(qc, d1, d2); });
       d = d1 * kD1Unscale + (p_first + d2 * kD2Unscale);
     }
-    // vector work + table MFMAs of the tile in `d` (tables in ta), with the THETA matrix ops of the next tile (if any) dealt between
-    auto reduce_tile = [&](int t, auto with_next, f32x16& d1, f32x16& d2) {
-      constexpr bool NEXT = decltype(with_next)::v != 0;
-      const f32x4* gs = lds_sci + (size_t)(t - t0) * 8 + h * 4;
-      static_for<2>([&](auto sc) {
-        constexpr int s = decltype(sc)::v;
-        f16x8 ch, cl, sh, sl;
-        const f32x4 g0 = gs[2 * s], g1 = gs[2 * s + 1];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float u = d[8 * s + e];
-          const float cw = __builtin_amdgcn_cosf(u), sw = __builtin_amdgcn_sinf(u);
-          const float us = u * ratio;
-          const float cs = __builtin_amdgcn_cosf(us), ss = __builtin_amdgcn_sinf(us);
-          const float g = e < 4 ? g0[e & 3] : g1[e & 3];
-          sc_c = fmaf(cs, g, sc_c);
-          sc_s = fmaf(ss, g, sc_s);
-          const _Float16 chh = (_Float16)cw, shh = (_Float16)sw;
-          ch[e] = chh;
-          sh[e] = shh;
-          cl[e] = (_Float16)(cw - (float)chh);
-          sl[e] = (_Float16)(sw - (float)shh);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // 6 table MFMAs of this step; ALL phase MFMAs of the next tile go behind step 0, so that they run under step 1's vector
-        // work and d(next) is ready when the stage ends
-        constexpr int LO = 0, HI = s == 0 ? NM : 0, CNT = HI - LO;
-        constexpr int C1 = LO + (CNT + 2) / 3, C2 = LO + (2 * CNT + 2) / 3;
-        auto theta = [&](auto lo, auto hi) {
-          if constexpr (NEXT && decltype(hi)::v > decltype(lo)::v)
-            static_for<decltype(hi)::v - decltype(lo)::v>([&](auto qc) { mfma_q(IC<decltype(lo)::v + decltype(qc)::v>{}, d1, d2); });
-        };
-        Dc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ta[2 * s], ch, Dc, 0, 0, 0);
-        theta(IC<LO>{}, IC<C1>{});
-        Ds = __builtin_amdgcn_mfma_f32_32x32x16_f16(ta[2 * s], sh, Ds, 0, 0, 0);
-        Dc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ta[2 * s], cl, Dc, 0, 0, 0);
-        theta(IC<C1>{}, IC<C2>{});
-        Ds = __builtin_amdgcn_mfma_f32_32x32x16_f16(ta[2 * s], sl, Ds, 0, 0, 0);
-        Dc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ta[2 * s + 1], ch, Dc, 0, 0, 0);
-        theta(IC<C2>{}, IC<HI>{});
-        Ds = __builtin_amdgcn_mfma_f32_32x32x16_f16(ta[2 * s + 1], sh, Ds, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      });
+    // Registers are refilled just in time: the mode halves and the step-0 table operands of the NEXT stage are requested right
+    // after the matrix ops that read the current ones have been issued (middle of the stage), the step-1 table operands and the
+    // screen of the tile after next at the end of the stage — every load has most of a stage to land, with no second register set.
+    f32x16 pA = load_psi(first + wp), pB = zero16;
+    __builtin_amdgcn_sched_barrier(0);
+    load_modes(mh, ml, first + wp);
+    // Matrix instructions are dealt BETWEEN the pixels of a vector step (one wave issues in order: a block of 18 MFMAs would keep
+    // it from issuing vector work for ~600 cycles, and both waves of a SIMD tend to be in the same phase).  The queue of a stage:
+    //   during step 0 of tile t : the 12 phase MFMAs of tile t + wp  and  the 6 step-1 table MFMAs of tile t - wp (operands kept)
+    //   during step 1 of tile t : the 6 step-0 table MFMAs of tile t
+    f16x8 c0, l0, s0, m0;   // step-0 B operands of the current tile (cos hi, cos lo, sin hi, sin lo)
+    f16x8 c1, l1, s1, m1;   // step-1 B operands, consumed during the NEXT stage's step 0
+    auto tab_one = [&](auto kc, const f16x8& tah, const f16x8& tal, const f16x8& ch, const f16x8& cl, const f16x8& sh, const f16x8& sl) {
+      constexpr int k = decltype(kc)::v;   // 0..5
+      if constexpr (k == 0) Dc = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, ch, Dc, 0, 0, 0);
+      else if constexpr (k == 1) Ds = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, sh, Ds, 0, 0, 0);
+      else if constexpr (k == 2) Dc = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, cl, Dc, 0, 0, 0);
+      else if constexpr (k == 3) Ds = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, sl, Ds, 0, 0, 0);
+      else if constexpr (k == 4) Dc = __builtin_amdgcn_mfma_f32_32x32x16_f16(tal, ch, Dc, 0, 0, 0);
+      else Ds = __builtin_amdgcn_mfma_f32_32x32x16_f16(tal, sh, Ds, 0, 0, 0);
+    };
+    // one pixel e of step s: sin/cos, science sums, hi/lo split into element e of the four B operands
+    auto vec_pixel = [&](auto sc, auto ec, const f32x4& g0, const f32x4& g1, f16x8& ch, f16x8& cl, f16x8& sh, f16x8& sl) {
+      constexpr int s = decltype(sc)::v, e = decltype(ec)::v;
+      const float u = d[8 * s + e];
+      const float cw = __builtin_amdgcn_cosf(u), sw = __builtin_amdgcn_sinf(u);
+      const float us = u * ratio;
+      const float cs = __builtin_amdgcn_cosf(us), ss = __builtin_amdgcn_sinf(us);
+      const float g = e < 4 ? g0[e & 3] : g1[e & 3];
+      sc_c = fmaf(cs, g, sc_c);
+      sc_s = fmaf(ss, g, sc_s);
+      const _Float16 chh = (_Float16)cw, shh = (_Float16)sw;
+      ch[e] = chh;
+      sh[e] = shh;
+      cl[e] = (_Float16)(cw - (float)chh);
+      sl[e] = (_Float16)(sw - (float)shh);
     };
     auto flush = [&] {
       acc_sc += (double)sc_c; acc_ss += (double)sc_s;
@@ -849,22 +842,72 @@ __global__ __launch_bounds__(256, 2) void k_fused_tab(const f16x8* __restrict__ 
         });
       }
     };
-    for (int i = 0, t = first; i + 1 < n; ++i, t += wp) {
+    // stage: vector work of tile t; PREV: tile t - wp still owes its step-1 table MFMAs; NEXT: tile t + wp gets its phase
+    auto stage = [&](auto prevc, auto nextc, int i, int t, f32x16& p_use, f32x16& p_load) {
+      constexpr bool PREV = decltype(prevc)::v != 0, NEXT = decltype(nextc)::v != 0;
+      constexpr int NQ0 = (NEXT ? NM : 0) + (PREV ? 6 : 0);   // matrix ops dealt over the 8 pixels of step 0
       f32x16 d1 = zero16, d2 = zero16;
-      load_modes(mh, ml, t + wp);
-      const f32x16 p = load_psi(t + wp);
-      load_tab(tb, t + wp);
+      const f32x4* gs = lds_sci + (size_t)(t - t0) * 8 + h * 4;
+      {
+        const f32x4 g0 = gs[0], g1 = gs[1];
+        static_for<8>([&](auto ec) {
+          constexpr int e = decltype(ec)::v;
+          vec_pixel(IC<0>{}, ec, g0, g1, c0, l0, s0, m0);
+          constexpr int qa = NQ0 * e / 8, qb = NQ0 * (e + 1) / 8;
+          static_for<qb - qa>([&](auto kc) {
+            constexpr int q = qa + decltype(kc)::v;
+            if constexpr (PREV && q < 6) tab_one(IC<q>{}, ta[2], ta[3], c1, l1, s1, m1);
+            else mfma_q(IC<q - (PREV ? 6 : 0)>{}, d1, d2);
+          });
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      }
+      if constexpr (NEXT) {   // the operands those matrix ops read are free again: request the next stage's
+        load_modes(mh, ml, t + 2 * wp);
+      }
+      {
+        const f16x8* ts = tab16 + ((size_t)t * 4) * 64 + lane;   // this tile's step-1 table operands (consumed next stage)
+        ta[2] = ts[128];
+        ta[3] = ts[192];
+      }
       __builtin_amdgcn_sched_barrier(0);
-      reduce_tile(t, IC<1>{}, d1, d2);
-      d = d1 * kD1Unscale + (p + d2 * kD2Unscale);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) ta[q] = tb[q];
+      {
+        const f32x4 g0 = gs[2], g1 = gs[3];
+        static_for<8>([&](auto ec) {
+          constexpr int e = decltype(ec)::v;
+          vec_pixel(IC<1>{}, ec, g0, g1, c1, l1, s1, m1);
+          constexpr int qa = 6 * e / 8, qb = 6 * (e + 1) / 8;
+          static_for<qb - qa>([&](auto kc) { tab_one(IC<qa + decltype(kc)::v>{}, ta[0], ta[1], c0, l0, s0, m0); });
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      }
+      if constexpr (NEXT) {
+        d = d1 * kD1Unscale + (p_use + d2 * kD2Unscale);
+        const f16x8* ts = tab16 + ((size_t)min(t + wp, last) * 4) * 64 + lane;   // next tile's step-0 table operands
+        ta[0] = ts[0];
+        ta[1] = ts[64];
+        p_load = load_psi(t + 2 * wp);
+      }
       if ((i % kFlushTiles) == kFlushTiles - 1) flush();
+    };
+    if (n == 1) {
+      stage(IC<0>{}, IC<0>{}, 0, first, pA, pB);
+    } else {
+      stage(IC<0>{}, IC<1>{}, 0, first, pA, pB);
+      int i = 1, t = first + wp;
+      for (; i + 2 < n; i += 2, t += 2 * wp) {
+        stage(IC<1>{}, IC<1>{}, i, t, pB, pA);
+        stage(IC<1>{}, IC<1>{}, i + 1, t + wp, pA, pB);
+      }
+      if (i + 1 < n) {
+        stage(IC<1>{}, IC<1>{}, i, t, pB, pA);
+        stage(IC<1>{}, IC<0>{}, i + 1, t + wp, pA, pB);
+      } else {
+        stage(IC<1>{}, IC<0>{}, i, t, pB, pA);
+      }
     }
-    {
-      f32x16 d1 = zero16, d2 = zero16;
-      reduce_tile(last, IC<0>{}, d1, d2);
-    }
+    // the last tile's step-1 table MFMAs
+    static_for<6>([&](auto kc) { tab_one(kc, ta[2], ta[3], c1, l1, s1, m1); });
     flush();
   }
   const int chunk = c * wp + w_p;
