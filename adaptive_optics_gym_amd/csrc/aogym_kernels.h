@@ -752,8 +752,11 @@ __global__ __launch_bounds__(256, 2) void k_fused_tab(const f16x8* __restrict__ 
     }
     return d;
   };
+  // Table rows m >= MRW are zero: the lanes that would fetch them all read ONE zero entry (row 31 of the first half) instead, so a
+  // variant with few tables pulls 2-3 cache lines per operand through L1 instead of 8 (the kernel is bound by that fill rate).
+  const int tlane = (lane & 31) <= MRW ? lane : 31;
   auto load_tab = [&](f16x8 (&ta)[4], int t) {   // [step][hi|lo]
-    const f16x8* ts = tab16 + ((size_t)min(t, last) * 4) * 64 + lane;
+    const f16x8* ts = tab16 + ((size_t)min(t, last) * 4) * 64 + tlane;
 #pragma unroll
     for (int q = 0; q < 4; ++q) ta[q] = ts[q * 64];
   };
@@ -866,7 +869,7 @@ __global__ __launch_bounds__(256, 2) void k_fused_tab(const f16x8* __restrict__ 
         load_modes(mh, ml, t + 2 * wp);
       }
       {
-        const f16x8* ts = tab16 + ((size_t)t * 4) * 64 + lane;   // this tile's step-1 table operands (consumed next stage)
+        const f16x8* ts = tab16 + ((size_t)t * 4) * 64 + tlane;   // this tile's step-1 table operands (consumed next stage)
         ta[2] = ts[128];
         ta[3] = ts[192];
       }
@@ -883,7 +886,7 @@ __global__ __launch_bounds__(256, 2) void k_fused_tab(const f16x8* __restrict__ 
       }
       if constexpr (NEXT) {
         d = d1 * kD1Unscale + (p_use + d2 * kD2Unscale);
-        const f16x8* ts = tab16 + ((size_t)min(t + wp, last) * 4) * 64 + lane;   // next tile's step-0 table operands
+        const f16x8* ts = tab16 + ((size_t)min(t + wp, last) * 4) * 64 + tlane;   // next tile's step-0 table operands
         ta[0] = ts[0];
         ta[1] = ts[64];
         p_load = load_psi(t + 2 * wp);
