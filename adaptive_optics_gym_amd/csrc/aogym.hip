@@ -385,9 +385,8 @@ int aog_create(const aog_config* cfg, int device, aog_env** out) {
     }
     e->kernel = cfg->kernel == AOG_KERNEL_AUTO ? AOG_KERNEL_MFMA : cfg->kernel;
     if (e->kernel == AOG_KERNEL_MFMA && e->A_pad > 64 && getenv("AOG_WIDE_VALU")) e->kernel = AOG_KERNEL_VALU;   // developer comparison
-    // table reduction on the matrix cores: default for the 12/20/28-table variants (o >= 3), opt-in (AOG_TABLES_MFMA=1) / opt-out
-    // (AOG_TABLES_MFMA=0) otherwise
-    e->tab_mfma = e->kernel == AOG_KERNEL_MFMA && e->MRW >= 12;
+    // table reduction on the matrix cores: the default; AOG_TABLES_MFMA=0 selects the vector-unit form (k_fused_mfma)
+    e->tab_mfma = e->kernel == AOG_KERNEL_MFMA;
     if (const char* tm = getenv("AOG_TABLES_MFMA")) e->tab_mfma = e->kernel == AOG_KERNEL_MFMA && atoi(tm) != 0;
     // launch geometry: aim at ~3 (VALU) / ~2 (MFMA) waves per SIMD over 256 CUs
     const int n_groups = e->Bp / 64;

@@ -733,6 +733,17 @@ __global__ __launch_bounds__(256, 2) void k_fused_tab(const f16x8* __restrict__ 
       bl[s] = asrc[(2 * s + 1) * 64];
     }
   }
+  // The float64-flush variant (few tables) and the 128-mode variants are out of registers: their actuator operands live in LDS (this wave's own 2 NSTEP KB,
+  // behind the science rows) and are read back right before each phase MFMA.
+  constexpr bool BLDS = F64 || A_PAD > 64;
+  f16x8* lds_b = reinterpret_cast<f16x8*>(lds_sci + (size_t)geo.max_tiles * 8) + (size_t)wave * NSTEP * 2 * 64 + lane;
+  if constexpr (BLDS) {
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+      lds_b[(2 * s) * 64] = bh[s];
+      lds_b[(2 * s + 1) * 64] = bl[s];
+    }
+  }
   const size_t psi_base = (size_t)etile_c * geo.n_ptiles;
   auto load_modes = [&](f16x8 (&mh)[NSTEP], f16x8 (&ml)[NSTEP], int t) {
     const f16x8* ms = modes16 + ((size_t)min(t, last) * NSTEP * 2) * 64 + lane;
@@ -785,9 +796,17 @@ __global__ __launch_bounds__(256, 2) void k_fused_tab(const f16x8* __restrict__ 
   if (n > 0) {
     auto mfma_q = [&](auto qc, f32x16& d1, f32x16& d2) {
       constexpr int q = decltype(qc)::v, s = q / 3, w = q % 3;
-      if constexpr (w == 0) d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[s], bh[s], d1, 0, 0, 0);
-      else if constexpr (w == 1) d2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[s], bl[s], d2, 0, 0, 0);
-      else d2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ml[s], bh[s], d2, 0, 0, 0);
+      f16x8 xh, xl;
+      if constexpr (BLDS) {
+        if constexpr (w != 1) xh = lds_b[(2 * s) * 64];
+        if constexpr (w == 1) xl = lds_b[(2 * s + 1) * 64];
+      } else {
+        xh = bh[s];
+        xl = bl[s];
+      }
+      if constexpr (w == 0) d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[s], xh, d1, 0, 0, 0);
+      else if constexpr (w == 1) d2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[s], xl, d2, 0, 0, 0);
+      else d2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ml[s], xh, d2, 0, 0, 0);
     };
     f32x16 d;
     {
@@ -798,7 +817,8 @@ __global__ __launch_bounds__(256, 2) void k_fused_tab(const f16x8* __restrict__ 
     // Registers are refilled just in time: the mode halves and the step-0 table operands of the NEXT stage are requested right
     // after the matrix ops that read the current ones have been issued (middle of the stage), the step-1 table operands and the
     // screen of the tile after next at the end of the stage — every load has most of a stage to land, with no second register set.
-    f32x16 pA = load_psi(first + wp), pB = zero16;
+    f32x16 pA = F64 ? zero16 : load_psi(first + wp), pB_store = zero16;
+    f32x16& pB = F64 ? pA : pB_store;   // single screen register set in the float64-flush variant
     __builtin_amdgcn_sched_barrier(0);
     load_modes(mh, ml, first + wp);
     // Matrix instructions are dealt BETWEEN the pixels of a vector step (one wave issues in order: a block of 18 MFMAs would keep
@@ -850,6 +870,7 @@ __global__ __launch_bounds__(256, 2) void k_fused_tab(const f16x8* __restrict__ 
       constexpr bool PREV = decltype(prevc)::v != 0, NEXT = decltype(nextc)::v != 0;
       constexpr int NQ0 = (NEXT ? NM : 0) + (PREV ? 6 : 0);   // matrix ops dealt over the 8 pixels of step 0
       f32x16 d1 = zero16, d2 = zero16;
+      if constexpr (F64 && NEXT) p_use = load_psi(t + wp);   // (this variant keeps one screen register set: one tile ahead)
       const f32x4* gs = lds_sci + (size_t)(t - t0) * 8 + h * 4;
       {
         const f32x4 g0 = gs[0], g1 = gs[1];
@@ -889,7 +910,7 @@ __global__ __launch_bounds__(256, 2) void k_fused_tab(const f16x8* __restrict__ 
         const f16x8* ts = tab16 + ((size_t)min(t + wp, last) * 4) * 64 + tlane;   // next tile's step-0 table operands
         ta[0] = ts[0];
         ta[1] = ts[64];
-        p_load = load_psi(t + 2 * wp);
+        if constexpr (!F64) p_load = load_psi(t + 2 * wp);
       }
       if ((i % kFlushTiles) == kFlushTiles - 1) flush();
     };

@@ -32,7 +32,11 @@ void launch_mfma(aog_env* e, hipStream_t s) {
   dim3 grid(round_up(g.P, 8) * g.wg_y);
   const float ratio = (float)(e->cfg.wavelength_wfs / e->cfg.wavelength_sci);
   if (e->tab_mfma) {
-    const size_t lds_t = (size_t)e->mfma_tpc * 8 * 16;
+    const size_t lds_t = (size_t)e->mfma_tpc * 8 * 16 + ((MRW <= 8 || A_PAD > 64) ? (size_t)4 * (A_PAD / 16) * 2 * 64 * 16 : 0);   // science rows (+ actuator operands)
+    if (lds_t > 64 * 1024 && !e->tab_attr_set) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(aog::k_fused_tab<A_PAD, MRW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t);
+      e->tab_attr_set = true;
+    }
     hipLaunchKernelGGL((aog::k_fused_tab<A_PAD, MRW>), grid, dim3(256), lds_t, s, reinterpret_cast<const aog::f16x8*>(e->modes16),
                        reinterpret_cast<const aog::f16x8*>(e->tab16), reinterpret_cast<const aog::f32x4*>(e->sci_tile),
                        reinterpret_cast<const aog::f32x4*>(e->psi_tile), reinterpret_cast<const aog::f16x8*>(e->act16), e->partials, g, ratio);

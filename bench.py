@@ -206,7 +206,7 @@ def main():
                        "obs_dim": w["obs_dim"], "kernel": {1: "valu", 2: "mfma"}.get(env.info.kernel, "ref"),
                        "parallelism": f"envs sharded over {world} GPU(s), no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_fused_mfma",
+                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_fused_mfma" if os.environ.get("AOG_TABLES_MFMA") == "0" else "k_fused_tab",
                          "kernel_ms": kernel_ms, "launches_timed": launches, "bytes_per_env_step": bytes_step,
                          "note": "algorithmic bytes (SURVEY.md 8d: 282,913 B per env-step) x 1024 envs per launch / mean "
                                  "HIP-event duration of the fused kernel; traffic = PMC (2*FETCH_SIZE + WRITE_SIZE) KiB per "
