@@ -214,9 +214,9 @@ def main():
             "roofline_fp32": {"bound": "valu", "achieved": ach_tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": ach_tf / FP32_PEAK_TFLOPS, "flops_per_env_step": flops_step,
                               "note": "SURVEY.md 8d algorithmic flops priced at the fp32 vector/MFMA peak; the surface "
-                                      "contraction (2*A*n_ap of them) actually runs as 3 f16 MFMAs per 16 modes, so this "
-                                      "fraction overstates fp32 pipe use — the kernel is bound by its sincos/accumulate "
-                                      "vector work, then by HBM"},
+                                      "contraction (2*A*n_ap of them) and the table sums actually run as split-f16 MFMAs, so "
+                                      "this fraction overstates fp32 pipe use — the kernel is bound by the per-CU L2-served fill "
+                                      "rate of its operands and its sin/cos work, then by HBM"},
         }
         if not args.no_parity:
             result["parity"] = strehl_check(env, screens, torch)
