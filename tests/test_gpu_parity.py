@@ -496,7 +496,7 @@ def test_device_actor_matches_torch_module():
     from adaptive_optics_gym_amd.rollout import DeviceActor, make_actor
 
     torch.manual_seed(3)
-    for S, H, A, B in ((4, 150, 64, 1000), (25, 150, 20, 37), (4, 32, 16, 5)):
+    for S, H, A, B in ((4, 150, 64, 1000), (25, 150, 20, 37), (4, 32, 16, 5), (9, 400, 6, 33)):   # last: weight matrix staged in several chunks
         actor = make_actor(S, A, H, device="cuda:0")
         with torch.no_grad():
             actor.out.weight.mul_(100.0)          # make the means O(1) so that errors would show
