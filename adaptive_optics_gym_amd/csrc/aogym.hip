@@ -880,6 +880,9 @@ int aog_upload_sh(aog_env* e, const aog_sh_tables* t) {
   if ((rc = dev_alloc(e, &e->sh_act16, (size_t)e->n_etiles * e->A_pad * 32 * 2)) != AOG_OK) return rc;
   if ((rc = dev_alloc(e, &e->sh_phase, (size_t)e->n_etiles * e->n_ptiles * 1024)) != AOG_OK) return rc;
   if ((rc = dev_alloc(e, &e->sh_pad, (size_t)e->B * N2 * 4 * 2, false)) != AOG_OK) return rc;
+  // zero-padded INPUT of the forward transform: only aperture pixels are ever written (k_sh_field), the padding stays zero because
+  // the forward FFT runs out of place into sh_pad — no memset per call
+  if ((rc = dev_alloc(e, &e->sh_in, (size_t)e->B * N2 * 4 * 2, true)) != AOG_OK) return rc;
   if ((rc = dev_alloc(e, &e->sh_image, (size_t)e->B * N2, false)) != AOG_OK) return rc;
   if ((rc = dev_alloc(e, &e->sh_noisy, (size_t)e->B * N2, false)) != AOG_OK) return rc;
   hipfftHandle plan;
@@ -904,7 +907,6 @@ int aog_sh_image(aog_env* e, double* image_dev, void* stream) {
   const size_t per = (size_t)4 * N * N;
   hipfftHandle plan = (hipfftHandle)(uintptr_t)e->sh_plan;
   if (hipfftSetStream(plan, s) != HIPFFT_SUCCESS) return fail(AOG_ERR_HIP, "hipfftSetStream failed");
-  HIP_TRY(hipMemsetAsync(e->sh_pad, 0, sizeof(double) * 2 * per * e->B, s));
   {
     const int n = e->B * e->A_pad;
     hipLaunchKernelGGL(aog::k_sh_act16, dim3((n + 255) / 256), dim3(256), 0, s, e->sh_act, e->sh_act16, e->B, e->A, e->A_pad,
@@ -912,10 +914,11 @@ int aog_sh_image(aog_env* e, double* image_dev, void* stream) {
     aog_host::launch_sh_phase(e, s);
   }
   hipLaunchKernelGGL(aog::k_sh_field, dim3((e->n_ap + 255) / 256, e->B), dim3(256), 0, s, e->sh_phase, e->ap_index,
-                     reinterpret_cast<const double2*>(e->sh_mla), reinterpret_cast<double2*>(e->sh_pad), e->n_ap, e->n_ptiles, N, e->sh_amp);
+                     reinterpret_cast<const double2*>(e->sh_mla), reinterpret_cast<double2*>(e->sh_in), e->n_ap, e->n_ptiles, N, e->sh_amp);
   HIP_TRY(hipGetLastError());
   hipfftDoubleComplex* buf = reinterpret_cast<hipfftDoubleComplex*>(e->sh_pad);
-  if (hipfftExecZ2Z(plan, buf, buf, HIPFFT_FORWARD) != HIPFFT_SUCCESS) return fail(AOG_ERR_HIP, "hipfftExecZ2Z forward failed");
+  if (hipfftExecZ2Z(plan, reinterpret_cast<hipfftDoubleComplex*>(e->sh_in), buf, HIPFFT_FORWARD) != HIPFFT_SUCCESS)
+    return fail(AOG_ERR_HIP, "hipfftExecZ2Z forward failed");
   hipLaunchKernelGGL(aog::k_sh_transfer, dim3((unsigned)((per + 255) / 256), e->B), dim3(256), 0, s, reinterpret_cast<double2*>(e->sh_pad),
                      reinterpret_cast<const double2*>(e->sh_tf), per);
   if (hipfftExecZ2Z(plan, buf, buf, HIPFFT_BACKWARD) != HIPFFT_SUCCESS) return fail(AOG_ERR_HIP, "hipfftExecZ2Z backward failed");

@@ -54,6 +54,7 @@ struct aog_env {
   _Float16* sh_act16 = nullptr;   // same, B-operand layout
   float* sh_phase = nullptr;      // psi_tile layout: wfs phase (rev) through the shack mirror
   double* sh_pad = nullptr;       // [B][2N][2N] complex work buffer
+  double* sh_in = nullptr;       // [B][2N][2N] complex128: zero-padded forward input (padding never written)
   double* sh_image = nullptr;     // [B][N*N]
   double* sh_noisy = nullptr;     // [B][N*N]
   void* sh_plan = nullptr;        // hipfftHandle (Z2Z, batch B)
