@@ -754,7 +754,8 @@ int aog_generate_screens(aog_env* e, int first, int count, int oversampling, dou
   const int Rr = LW ? N / LW : 0;
   const bool pow2 = (oversampling & (oversampling - 1)) == 0 && (Rr == 1 || Rr == 2 || Rr == 4 || Rr == 8);
   if (pow2 && !getenv("AOG_SCREENS_FULLFFT")) {
-    const size_t per_env = (size_t)m * N * 2;   // floats of T
+    const int lines = m / 2 + 1;                 // half-plane synthesis: spectrum lines 0 .. m/2 (k_screen_rows)
+    const size_t per_env = (size_t)lines * N * 2;   // floats of T
     int batch = (int)std::max<size_t>(1, std::min<size_t>((size_t)e->B, ((size_t)2 << 30) / (per_env * sizeof(float))));
     if (e->syn_m != m) {   // (a different oversampling later on allocates afresh; the old workspace is released with the handle)
       int rc;
@@ -781,7 +782,7 @@ int aog_generate_screens(aog_env* e, int first, int count, int oversampling, dou
     a.u0sq = (float)(u0 * u0);
     a.amp_scale = (float)amp_scale;
     a.crop_scale = (float)(std::sqrt(cn_squared) / ((double)m * m * pixel_pitch * pixel_pitch));
-    const size_t lds = (size_t)4 * 64 * 65 * sizeof(float);
+    const size_t lds = (size_t)4 * 64 * 65 * sizeof(float), lds_cols = (size_t)aog::kColsWaves * 64 * 65 * sizeof(float);
     const int R = Rr;
     auto rows = LW == 64 ? (R == 1 ? aog::k_screen_rows<1, 64> : R == 2 ? aog::k_screen_rows<2, 64> : R == 4 ? aog::k_screen_rows<4, 64> : aog::k_screen_rows<8, 64>)
                          : (R == 1 ? aog::k_screen_rows<1, 60> : R == 2 ? aog::k_screen_rows<2, 60> : R == 4 ? aog::k_screen_rows<4, 60> : aog::k_screen_rows<8, 60>);
@@ -789,14 +790,16 @@ int aog_generate_screens(aog_env* e, int first, int count, int oversampling, dou
                          : (R == 1 ? aog::k_screen_cols<1, 60> : R == 2 ? aog::k_screen_cols<2, 60> : R == 4 ? aog::k_screen_cols<4, 60> : aog::k_screen_cols<8, 60>);
     if (!e->syn_attr_set) {
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(rows), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(cols), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(cols), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cols));
       e->syn_attr_set = true;
     }
-    for (int done = 0; done < count; done += e->syn_batch) {
-      const int nb = std::min(e->syn_batch, count - done);
+    const int n_launch = (count + e->syn_batch - 1) / e->syn_batch;
+    const int per_launch = (count + n_launch - 1) / n_launch;   // even shares (no short tail launch)
+    for (int done = 0; done < count; done += per_launch) {
+      const int nb = std::min(per_launch, count - done);
       a.first_env = first + done;
-      hipLaunchKernelGGL(rows, dim3((m + 3) / 4, nb), dim3(256), lds, s, a);
-      hipLaunchKernelGGL(cols, dim3((N + 3) / 4, nb), dim3(256), lds, s, a);
+      hipLaunchKernelGGL(rows, dim3((lines + 3) / 4, nb), dim3(256), lds, s, a);
+      hipLaunchKernelGGL(cols, dim3((N + aog::kColsWaves - 1) / aog::kColsWaves, nb), dim3(64 * aog::kColsWaves), lds_cols, s, a);
       HIP_TRY(hipGetLastError());
       int rc = set_screens<float>(e, e->syn_out, first + done, nb, s);
       if (rc != AOG_OK) return rc;

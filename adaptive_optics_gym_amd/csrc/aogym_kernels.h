@@ -2134,6 +2134,13 @@ __global__ void k_spectrum_fill(float2* __restrict__ spec, int m, int first_env,
   const size_t per_env = (size_t)m * m / 2;
   const int b = blockIdx.y;
   if (pair >= per_env) return;
+  // Half-plane form (see k_screen_rows): lines v > m/2 stay zero, lines 0 < v < m/2 carry sqrt(2) x the amplitude
+  const int v_line = (int)((2 * pair) / m);   // m is even: both samples of a pair sit on one line
+  if (2 * v_line > m) {
+    reinterpret_cast<float4*>(spec + (size_t)b * m * m)[pair] = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
+  const float line_scale = (v_line == 0 || 2 * v_line == m) ? 1.f : 1.41421356237f;
   uint32_t c[4] = {(uint32_t)pair, (uint32_t)(pair >> 32) ^ (generation * 0x9E3779B9u), (uint32_t)(first_env + b), 0x5C4EE7u};
   uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
@@ -2150,7 +2157,7 @@ __global__ void k_spectrum_fill(float2* __restrict__ spec, int m, int first_env,
     const double fu = du * (double)(u < m / 2 ? u : u - m), fv = du * (double)(v < m / 2 ? v : v - m);
     const double f2 = fu * fu + fv * fv;
     // 0.0229 r0^(-5/3) ((f^2 + u0^2)/(2 pi)^2)^(-11/6) (2 pi)^2 / du^2, zero at the origin; amp_scale holds the constants
-    const float a = f2 < 1e-18 ? 0.f : (float)(amp_scale * pow(f2 + u0sq, -11.0 / 12.0));
+    const float a = f2 < 1e-18 ? 0.f : line_scale * (float)(amp_scale * pow(f2 + u0sq, -11.0 / 12.0));
     const float u1 = ((float)c[2 * h] + 0.5f) * (1.0f / 4294967296.0f);
     const float u2 = ((float)c[2 * h + 1] + 0.5f) * (1.0f / 4294967296.0f);
     const float r = a * sqrtf(-2.0f * __logf(u1));
@@ -2405,7 +2412,7 @@ __device__ __forceinline__ void dft_lanes(cf32 (&z)[64]) {   // inverse DFT of z
 }
 
 struct ScreenSynthArgs {
-  float2* T;                 // [env in batch][m][N] complex64
+  float2* T;                 // [env in batch][m/2 + 1][N] complex64
   float* out;                // [env in batch][N][N]
   int N, q, first_env;
   unsigned long long seed;
@@ -2525,7 +2532,12 @@ __device__ __forceinline__ void pruned_line(Load&& load, int q, int N, float* __
   }
 }
 
-// Pass A: grid (m / 4, envs in batch), 4 waves, one spectrum line v per wave.  LDS 4 x 64 x 65 x 4 B.
+// Pass A: grid ((m/2 + 1) / 4, envs in batch), 4 waves, one spectrum line v per wave.  LDS 4 x 64 x 65 x 4 B.
+// Only the lines 0 <= v <= m/2 are drawn.  The screen is the REAL part of the transform of independent complex normals a(k) g_k, and
+// a(k) = a(-k): the pair (k, -k) contributes a(k) [(g_k.re + g_-k.re) cos - (g_k.im - g_-k.im) sin], in which the two bracketed
+// sums are independent N(0, 2) — the same law as sqrt(2) a(k) g_k alone.  So lines 0 < v < m/2 carry sqrt(2) a and stand for their
+// conjugate lines m - v as well; lines 0 and m/2 pair within themselves and are drawn in full as before.  Half the Philox draws,
+// half the row transforms, same distribution of the screens (not the same sample stream as the full-plane form).
 template <int R, int LW>
 __global__ __launch_bounds__(256) void k_screen_rows(ScreenSynthArgs p) {
   extern __shared__ float lds_syn[];
@@ -2533,9 +2545,11 @@ __global__ __launch_bounds__(256) void k_screen_rows(ScreenSynthArgs p) {
   const int N = p.N, q = p.q, m = q * N;
   const int v = blockIdx.x * 4 + wave;
   const int b = blockIdx.y;
-  if (v >= m) return;
-  const float fv = p.du * (float)(v < m / 2 ? v : v - m);
-  const float sign = (lane & 1) ? -1.f : 1.f;   // (-1)^a, a = lane + LW r (LW is even)
+  const int lines = m / 2 + 1;
+  if (v >= lines) return;
+  const float fv = p.du * (float)v;
+  // (-1)^a, a = lane + LW r (LW is even), times the half-plane weight of this line
+  const float sign = ((lane & 1) ? -1.f : 1.f) * ((v == 0 || 2 * v == m) ? 1.f : 1.41421356237f);
   cf32 pending[R];   // second sample of the Philox pair drawn for (a, b even): consumed as (a, b + 1)
   auto load = [&](int bg, int r, auto oddc) -> cf32 {
     // samples come in Philox pairs (u even, u + 1): b even draws, b odd uses the second half
@@ -2572,26 +2586,30 @@ __global__ __launch_bounds__(256) void k_screen_rows(ScreenSynthArgs p) {
   };
   cf32 acc[R];
   pruned_line<R, LW>(load, q, N, lds_syn + (size_t)wave * 64 * 65, acc);
-  float2* dst = p.T + ((size_t)b * m + v) * N + (size_t)R * lane;
+  float2* dst = p.T + ((size_t)b * lines + v) * N + (size_t)R * lane;
   if (lane < LW) {
 #pragma unroll
     for (int pp = 0; pp < R; ++pp) dst[pp] = make_float2(acc[pp].x, acc[pp].y);
   }
 }
 
-// Pass B: grid (N / 4, envs in batch), one column ix per wave; reads T[v][ix] (the 4 waves of a workgroup share its cache lines).
+// Pass B: grid (N / 8, envs in batch), one column ix per wave; reads T[v][ix]: the 8 waves of a workgroup take 8 adjacent columns,
+// 64 B of every line of T (T does not fit the L2: with 4 columns per workgroup half of every fetched sector was unused).
+constexpr int kColsWaves = 8;
 template <int R, int LW>
-__global__ __launch_bounds__(256, 2) void k_screen_cols(ScreenSynthArgs p) {
+__global__ __launch_bounds__(64 * kColsWaves) void k_screen_cols(ScreenSynthArgs p) {
   extern __shared__ float lds_syn[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int N = p.N, q = p.q, m = q * N;
-  const int ix = blockIdx.x * 4 + wave;
+  const int ix = blockIdx.x * kColsWaves + wave;
   const int b = blockIdx.y;
   if (ix >= N) return;
   const float sign = (lane & 1) ? -1.f : 1.f;
-  const float2* src = p.T + (size_t)b * m * N + ix;
+  const int lines = m / 2 + 1;
+  const float2* src = p.T + (size_t)b * lines * N + ix;
   auto load = [&](int bg, int r, auto) -> cf32 {
     const int vv = q * (min(lane, LW - 1) + LW * r) + bg;
+    if (vv >= lines) return cf32{0.f, 0.f};   // the conjugate half plane is folded into the lines below m/2 (see k_screen_rows)
     const float2 t = src[(size_t)vv * N];
     return cf32{sign * t.x, sign * t.y};
   };
