@@ -2532,14 +2532,16 @@ __device__ __forceinline__ void pruned_line(Load&& load, int q, int N, float* __
   }
 }
 
-// Pass A: grid ((m/2 + 1) / 4, envs in batch), 4 waves, one spectrum line v per wave.  LDS 4 x 64 x 65 x 4 B.
+// Pass A: grid ((m/2 + 1) / 4, envs in batch), 4 waves, one spectrum line v per wave.  LDS 4 x 64 x 65 x 4 B.  Two workgroups per CU
+// (launch bound: 256 registers; left free the compiler takes 313 and one wave per SIMD runs 15 % slower than two with ~50 spills
+// outside the hot code).
 // Only the lines 0 <= v <= m/2 are drawn.  The screen is the REAL part of the transform of independent complex normals a(k) g_k, and
 // a(k) = a(-k): the pair (k, -k) contributes a(k) [(g_k.re + g_-k.re) cos - (g_k.im - g_-k.im) sin], in which the two bracketed
 // sums are independent N(0, 2) — the same law as sqrt(2) a(k) g_k alone.  So lines 0 < v < m/2 carry sqrt(2) a and stand for their
 // conjugate lines m - v as well; lines 0 and m/2 pair within themselves and are drawn in full as before.  Half the Philox draws,
 // half the row transforms, same distribution of the screens (not the same sample stream as the full-plane form).
 template <int R, int LW>
-__global__ __launch_bounds__(256) void k_screen_rows(ScreenSynthArgs p) {
+__global__ __launch_bounds__(256, 2) void k_screen_rows(ScreenSynthArgs p) {
   extern __shared__ float lds_syn[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int N = p.N, q = p.q, m = q * N;

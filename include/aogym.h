@@ -152,7 +152,10 @@ int aog_get_screens_f64(aog_env* env, double* psi_dev, void* stream);
 /* layer.reset() / layer construction (AO_env.py:77, :370): synthesise new von Karman screens for envs [first, first+count) ON THE
  * DEVICE and install them — hcipy's FiniteAtmosphericLayer + SpectralNoiseFactoryFFT: complex normals on the (oversampling N)^2
  * FFT grid times sqrt(PSD (2 pi)^2 / du^2), inverse FFT (hipFFT/rocFFT), real part of the central N x N crop / delta^2 * sqrt(Cn^2).
- * Normals come from the handle's Philox stream (aog_set_rng_seed); statistically equivalent to hcipy, not draw-for-draw. */
+ * Normals come from the handle's Philox stream (aog_set_rng_seed); statistically equivalent to hcipy, not draw-for-draw: only the
+ * half plane of spectrum lines 0..m/2 is drawn (a conjugate pair of independent complex normals with equal amplitudes contributes
+ * to the REAL part exactly like one normal of sqrt(2) x the amplitude), and pupils of 64 R / 60 R pixels never materialise the
+ * oversampled array (pruned two-pass transform). */
 int aog_generate_screens(aog_env* env, int first, int count, int oversampling, double cn_squared, double outer_scale,
                          double pixel_pitch, void* stream);
 
