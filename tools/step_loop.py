@@ -50,6 +50,7 @@ while done < args.steps:
     blocks.append((time.perf_counter() - tb) / nb)
     done += nb
 dt = time.perf_counter() - t0
+print('blocks (us/step, in order): ' + ' '.join(f'{b*1e6:.0f}' for b in blocks))
 blocks.sort()
 print(f"per-step wall over blocks of <=50: min {blocks[0]*1e6:.1f} us  median {blocks[len(blocks)//2]*1e6:.1f} us  max {blocks[-1]*1e6:.1f} us")
 ms, n = env.profile_read()
