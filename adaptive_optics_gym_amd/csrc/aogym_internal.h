@@ -125,6 +125,8 @@ struct aog_env {
   size_t partial_elems = 0;
   // profiling of the fused kernel
   bool profile = false;
+  int profile_every = 1;         // time every n-th launch of the fused kernel (aog_profile_enable(env, n))
+  unsigned profile_phase = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   size_t events_used = 0;
   std::vector<void*> allocs;

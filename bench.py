@@ -32,6 +32,7 @@ WORKLOAD = dict(batch_per_gpu=1024, n_pupil=256, act_dim=64, obs_dim=2, atm_type
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
+PROFILE_EVERY = 8          # HIP events around one block of 32 launches of the fused kernel in 8 inside the timed region
 
 
 def algorithmic_per_step(n_pupil, act_dim, obs_dim, batch, n_ap):
@@ -172,7 +173,7 @@ def main():
 
     run(args.warmup)
     fence()
-    env.profile(True)
+    env.profile(True, every=PROFILE_EVERY)
     t0 = time.perf_counter()
     run(args.steps)
     fence()
@@ -208,8 +209,11 @@ def main():
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_fused_mfma" if os.environ.get("AOG_TABLES_MFMA") == "0" else "k_fused_tab",
                          "kernel_ms": kernel_ms, "launches_timed": launches, "bytes_per_env_step": bytes_step,
+                         "timed_every": PROFILE_EVERY,
                          "note": "algorithmic bytes (SURVEY.md 8d: 282,913 B per env-step) x 1024 envs per launch / mean "
-                                 "HIP-event duration of the fused kernel; traffic = PMC (2*FETCH_SIZE + WRITE_SIZE) KiB per "
+                                 "HIP-event duration of the fused kernel over the timed region (one block of 32 launches in 8 carries "
+                                 "the two event records: they hold the stream ~6 us, which would otherwise be in every step); "
+                                 "traffic = PMC (2*FETCH_SIZE + WRITE_SIZE) KiB per "
                                  "launch from profiles/traffic_latest.json; 6.29 TB/s is the measured copy ceiling"},
             "roofline_fp32": {"bound": "valu", "achieved": ach_tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": ach_tf / FP32_PEAK_TFLOPS, "flops_per_env_step": flops_step,
