@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libaogym.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 AOG_REWARD = {"strehl_ratio": 0, "smf_ssim": 1}
 AOG_PRECISION = {"fast": 0, "fp64": 1}
@@ -82,6 +82,7 @@ SYMBOLS = {
     "aog_get_phase_screen": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "aog_actor_act": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "aog_device_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "aog_set_return_accumulator": (C.c_int, [C.c_void_p, C.c_void_p]),
     "aog_debug_read_partials": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "aog_get_actuators": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "aog_set_actuators": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

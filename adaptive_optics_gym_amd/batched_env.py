@@ -453,6 +453,18 @@ class BatchedAOEnv:
             for e, st in enumerate(state["rng"]):
                 self._env_rng(e).set_state(st)
 
+    def accumulate_returns(self, returns=None):
+        """Have every ``step`` add its rewards into ``returns`` ([B] float32 contiguous device tensor; the caller zeroes it at
+        episode start) inside the step's last kernel — the episode-return sum of the rollout without a launch of its own.
+        ``None`` detaches.  The tensor must stay alive while attached (a reference is kept here)."""
+        torch = self._torch
+        if returns is not None:
+            ok = returns.dtype == torch.float32 and tuple(returns.shape) == (self.num_envs,) and returns.is_contiguous() and returns.is_cuda
+            if not ok:
+                raise ValueError("accumulate_returns: expected a contiguous float32 [num_envs] tensor on the env's device")
+        self._returns_ref = returns
+        _lib.check(self.lib.aog_set_return_accumulator(self._handle, C.c_void_p(returns.data_ptr() if returns is not None else None)))
+
     def device_status(self):
         """Synchronise and return the library's sticky device status word (0 = fine)."""
         v = C.c_int32()

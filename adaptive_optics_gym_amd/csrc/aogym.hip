@@ -164,6 +164,7 @@ int launch_epilogue(aog_env* e, bool is_step, float* obs_raw, uint16_t* obs, flo
   p.has_thr = e->cfg.has_rew_threshold;
   p.max_steps = e->cfg.max_steps;
   p.is_step = is_step ? 1 : 0;
+  p.ret_acc = is_step ? e->ret_acc : nullptr;
   p.partials_f32 = 0;   // (float slabs are folded by k_reduce_slabs above; the epilogue's own float path is kept for reference)
   p.thr = e->cfg.rew_threshold;
   p.ssim_peak = e->cfg.ssim_ref_peak;
@@ -1074,6 +1075,12 @@ int aog_debug_read_partials(aog_env* e, void* dst_host, size_t nbytes) {
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(dst_host, e->partials, nbytes, hipMemcpyDeviceToHost));
+  return AOG_OK;
+}
+
+int aog_set_return_accumulator(aog_env* e, float* returns_dev) {
+  if (!e) return fail(AOG_ERR_INVALID, "aog_set_return_accumulator: null handle");
+  e->ret_acc = returns_dev;
   return AOG_OK;
 }
 

@@ -124,6 +124,7 @@ struct aog_env {
   double* slab_reduced = nullptr;   // single float64 slab [NS][Bp] after k_reduce_slabs
   size_t partial_elems = 0;
   // profiling of the fused kernel
+  float* ret_acc = nullptr;      // caller-owned episode-return accumulator (aog_set_return_accumulator)
   bool profile = false;
   int profile_every = 1;         // time every n-th launch of the fused kernel (aog_profile_enable(env, n))
   unsigned profile_phase = 0;

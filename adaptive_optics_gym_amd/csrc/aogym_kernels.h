@@ -1061,6 +1061,7 @@ struct EpilogueArgs {
   float* power;
   float* strehl;
   int32_t* t_render;
+  float* ret_acc;   // nullable: episode-return accumulator [B] (aog_set_return_accumulator)
   int B, Bp, n_chunks, MRW, MRS, MRW_used, MRS_used, n_obs, n_fiber, reward_type, has_thr, max_steps, is_step;
   int partials_f32;   // slabs hold float (table-MFMA variants with fp32-only sums) instead of double
   double thr, ssim_peak, ssim_alpha;
@@ -1212,6 +1213,7 @@ __global__ __launch_bounds__(1024) void k_epilogue(EpilogueArgs p) {
   const int tr = p.t_render[env] + 1;
   p.t_render[env] = tr;
   if (p.reward) p.reward[env] = (float)reward;
+  if (p.ret_acc) p.ret_acc[env] += (float)reward;
   if (p.done) p.done[env] = (tr == p.max_steps) ? 1 : 0;
   if (p.power) p.power[env] = (float)power;
   if (p.strehl) p.strehl[env] = (float)strehl;

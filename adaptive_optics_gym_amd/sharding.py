@@ -43,11 +43,25 @@ class EpisodeReturnGatherer:
             self.world = dist.get_world_size(group)
             self._out = torch.empty(self.world * self.local_envs, dtype=torch.float32, device=device)
 
+        self._attached = None
+
+    def attach(self, env):
+        """Let ``env`` (a ``BatchedAOEnv``) add each step's rewards into ``self.returns`` inside its own last kernel; ``add`` then
+        has nothing left to do."""
+        env.accumulate_returns(self.returns)
+        self._attached = env
+
+    def detach(self):
+        if self._attached is not None:
+            self._attached.accumulate_returns(None)
+            self._attached = None
+
     def start_episode(self):
         self.returns.zero_()
 
     def add(self, reward):
-        self.returns += reward
+        if self._attached is None:
+            self.returns += reward
 
     def finish_episode(self):
         """Returns the [world * local_envs] tensor of episode returns ordered by global env id."""

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define AOG_ABI_VERSION 11
+#define AOG_ABI_VERSION 12
 
 typedef struct aog_env aog_env;
 
@@ -200,6 +200,12 @@ int aog_get_phase_screen(aog_env* env, int env_index, float* phase_dev, void* st
 /* Developer aid: copies the first nbytes of the fused kernel's partial-sum buffer to host memory (synchronises).  With the
  * AOG_ABLATE=6 diagnostic build of the fused kernel that buffer holds per-wave timeline records instead of sums. */
 int aog_debug_read_partials(aog_env* env, void* dst_host, size_t nbytes);
+
+/* Episode-return accumulation of the rollout (algorithm.py:509-510 sums the rewards of an episode on the host): when
+ * returns_dev ([B] float32, caller-owned, device) is set, every aog_step also does returns_dev[env] += reward[env] (float32, the
+ * same arithmetic as the caller's own `returns += reward`) in its last kernel.  NULL detaches.  The caller zeroes the buffer at
+ * episode start and reads it (all-gathers it across ranks) at episode end. */
+int aog_set_return_accumulator(aog_env* env, float* returns_dev);
 
 /* Synchronises the device and returns the handle's sticky device-side status word: 0 = fine, 1 = a bounded inter-workgroup wait
  * timed out (results of that step are invalid). */

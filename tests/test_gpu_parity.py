@@ -486,6 +486,39 @@ def test_batched_rollout_on_device():
     env.close()
 
 
+def test_episode_returns_accumulate_inside_the_step():
+    """aog_set_return_accumulator: the epilogue adds each step's reward into the caller's [B] float32 buffer with the caller's own
+    arithmetic (returns += reward), resets add nothing, detaching stops it; the sharded gatherer uses it through attach()."""
+    torch = _torch()
+    from adaptive_optics_gym_amd import BatchedAOEnv
+    from adaptive_optics_gym_amd.sharding import EpisodeReturnGatherer
+
+    N, B, A = 64, 70, 16      # 70 envs: a ragged last env tile
+    env = BatchedAOEnv(B, "cuda:0", num_pupil_pixels=N, screens=smooth_screens(B, N, 21), act_dim=A, obs_dim=2,
+                       timesteps_per_episode=4, verbose=False)
+    gather = EpisodeReturnGatherer(B, torch.device("cuda:0"), False)
+    gather.attach(env)
+    env.reset()
+    gather.start_episode()
+    manual = torch.zeros(B, dtype=torch.float32, device="cuda")
+    for t in range(4):
+        _, rew, done, _, _ = env.step(torch.from_numpy(actions_for(B, A, 30 + t)).cuda())
+        gather.add(rew)                      # no-op while attached
+        manual += rew
+    assert bool(done.all())
+    ret = gather.finish_episode()
+    assert torch.equal(ret, manual) and float(manual.abs().max()) > 0
+    env.reset()                              # the reset's observation pass must not touch the sums
+    assert torch.equal(gather.returns, manual)
+    gather.detach()
+    env.step(torch.from_numpy(actions_for(B, A, 40)).cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(gather.returns, manual)
+    with pytest.raises(ValueError):
+        env.accumulate_returns(torch.zeros(B + 1, dtype=torch.float32, device="cuda"))
+    env.close()
+
+
 def test_device_actor_matches_torch_module():
     """R1 policy query (network.py:48-69) as one launch: with dropout off the mean equals the torch module's forward (fp32
     matrix cores are exact fp32), the action is mean + sqrt(cov) eps with unit-variance eps, log_prob is the

@@ -1,5 +1,8 @@
-import os, sys, time, json
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+"""Where the time of bench.py's timed region goes beyond the three per-step kernels (developer tool): per-segment wall time of the
+same loop with (a) event timing of every launch, (b) none, (c) one block of 32 in 8, each with the episode returns summed by torch
+(`returns += reward`, one more launch per step) or inside the epilogue (`EpisodeReturnGatherer.attach`)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 from adaptive_optics_gym_amd import BatchedAOEnv
@@ -15,22 +18,19 @@ env = BatchedAOEnv(B, device, atm_type=w["atm_type"], atm_fried=w["atm_fried"], 
 T = w["timesteps_per_episode"]
 actions = torch.randn((T, B, w["act_dim"]), device=device) * 0.7071
 gather = EpisodeReturnGatherer(B, device, False)
-def run(n, marks=None):
+def run(n):
     t = 0; env.reset(); gather.start_episode()
     for i in range(n):
         _, rew, _, _, _ = env.step(actions[t]); gather.add(rew); t += 1
-        if marks is not None and i in marks:
-            torch.cuda.synchronize(); marks[i] = time.perf_counter()
         if t == T:
             gather.finish_episode(); env.reset(); gather.start_episode(); t = 0
-for mode in ("profile_on_before_timed", "profile_off", "profile_on_during_warmup"):
-    if mode == "profile_on_during_warmup": env.profile(True)
-    run(30); torch.cuda.synchronize()
-    if mode == "profile_on_before_timed": env.profile(True)
-    marks = {9: 0, 29: 0, 59: 0, 119: 0, 299: 0}
-    t0 = time.perf_counter(); run(300, marks); torch.cuda.synchronize(); t1 = time.perf_counter()
-    ks = sorted(marks); prev_t, prev_k = t0, -1; seg = []
-    for k in ks:
-        seg.append(f"steps {prev_k+1}-{k}: {(marks[k]-prev_t)/(k-prev_k)*1e6:.1f} us/step"); prev_t, prev_k = marks[k], k
-    print(mode, f"total {(t1-t0)*1e3:.2f} ms |", " | ".join(seg), flush=True)
-    env.profile_read(); env.profile(False)
+for attach in (False, True, False, True):
+    gather.attach(env) if attach else gather.detach()
+    for every in (1, 0, 8):
+        run(30); torch.cuda.synchronize()
+        if every: env.profile(True, every=every)
+        res = []
+        for n in (300, 1500):
+            t0 = time.perf_counter(); run(n); torch.cuda.synchronize(); res.append((time.perf_counter() - t0) / n * 1e6)
+        if every: env.profile_read(); env.profile(False)
+        print(f"returns in {'epilogue' if attach else 'torch   '} | events every {every}: {res[0]:.1f} us/step over 300, {res[1]:.1f} over 1500", flush=True)
