@@ -1154,6 +1154,13 @@ __global__ __launch_bounds__(1024) void k_epilogue(EpilogueArgs p) {
   double* pw = U + (size_t)NS * kEpiEnvs;                         // [n_out + 1][4]: powers of the outputs, then Strehl
   double* cfs = pw + (size_t)(n_out + 1) * kEpiEnvs;              // [n_out][MRW_used][2] then [MRS_used][2]
   double* cfsci = cfs + (size_t)n_out * p.MRW_used * 2;
+  // the per-env state the last phase updates is requested now (it would otherwise be one more memory round trip at the very end)
+  int tr_prev = 0;
+  float ret_prev = 0.f;
+  if (threadIdx.x < kEpiEnvs && env < p.B && p.is_step) {
+    tr_prev = p.t_render[env];
+    if (p.ret_acc) ret_prev = p.ret_acc[env];
+  }
   // the small coefficient matrices go to LDS once (the output threads would otherwise chase them through L2 serially)
   for (int i = threadIdx.x; i < n_out * p.MRW_used * 2; i += blockDim.x) cfs[i] = p.wfs_coef[i];
   for (int i = threadIdx.x; i < p.MRS_used * 2; i += blockDim.x) cfsci[i] = p.sci_coef[i];
@@ -1228,10 +1235,10 @@ __global__ __launch_bounds__(1024) void k_epilogue(EpilogueArgs p) {
     reward = p.ssim_alpha * power + (1.0 - p.ssim_alpha) * ssim;
   }
   if (p.has_thr && reward < p.thr) reward = -1.0;
-  const int tr = p.t_render[env] + 1;
+  const int tr = tr_prev + 1;
   p.t_render[env] = tr;
   if (p.reward) p.reward[env] = (float)reward;
-  if (p.ret_acc) p.ret_acc[env] += (float)reward;
+  if (p.ret_acc) p.ret_acc[env] = ret_prev + (float)reward;
   if (p.done) p.done[env] = (tr == p.max_steps) ? 1 : 0;
   if (p.power) p.power[env] = (float)power;
   if (p.strehl) p.strehl[env] = (float)strehl;
