@@ -332,6 +332,7 @@ __device__ __host__ inline void split_f16(float x, _Float16& hi, _Float16& lo) {
 //   sees 1/8 of the mode matrix.  Chunk c owns pixel tiles [c*n_ptiles/P, (c+1)*n_ptiles/P).
 struct MfmaGeom {
   int n_ptiles, n_etiles, Bp, P, wg_y, we, max_tiles;
+  int skew;   // start-up skew of every second workgroup, x 16 cycles (kSkewNops unless the developer override AOG_SKEW_NOPS is set)
 };
 
 // ---- compile-time interleave plan -------------------------------------------------------------------------------
@@ -801,8 +802,8 @@ __global__ __launch_bounds__(256, 2) void k_fused_tab(const f16x8* __restrict__ 
   }
   __syncthreads();
   if (etile >= geo.n_etiles) return;
-  if ((j & 32) != 0 && kSkewNops > 0) {
-    for (int q = 0; q < kSkewNops; ++q) asm volatile("s_nop 15");
+  if ((j & 32) != 0) {
+    for (int q = 0; q < geo.skew; ++q) asm volatile("s_nop 15");
   }
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   f32x16 Dc = zero16, Ds = zero16;          // table sums (cos, sin), rows by register

@@ -29,6 +29,8 @@ void launch_mfma(aog_env* e, hipStream_t s) {
   g.we = e->mfma_we;
   g.wg_y = (e->n_etiles + e->mfma_we - 1) / e->mfma_we;
   g.max_tiles = e->mfma_tpc;
+  static const int skew = getenv("AOG_SKEW_NOPS") ? atoi(getenv("AOG_SKEW_NOPS")) : aog::kSkewNops;
+  g.skew = skew;
   dim3 grid(round_up(g.P, 8) * g.wg_y);
   const float ratio = (float)(e->cfg.wavelength_wfs / e->cfg.wavelength_sci);
   if (e->tab_mfma) {
