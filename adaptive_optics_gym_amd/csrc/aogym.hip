@@ -393,6 +393,7 @@ int aog_create(const aog_config* cfg, int device, aog_env** out) {
     // table reduction on the matrix cores: the default; AOG_TABLES_MFMA=0 selects the vector-unit form (k_fused_mfma)
     e->tab_mfma = e->kernel == AOG_KERNEL_MFMA;
     if (const char* tm = getenv("AOG_TABLES_MFMA")) e->tab_mfma = e->kernel == AOG_KERNEL_MFMA && atoi(tm) != 0;
+    if (const char* t16 = getenv("AOG_FUSED_T16")) e->fused_t16 = atoi(t16) != 0;   // developer variant, see k_fused_t16
     // launch geometry: aim at ~3 (VALU) / ~2 (MFMA) waves per SIMD over 256 CUs
     const int n_groups = e->Bp / 64;
     int P = cfg->pixel_chunks > 0 ? cfg->pixel_chunks : std::max(1, (256 * 4 * 3 + n_groups - 1) / n_groups);

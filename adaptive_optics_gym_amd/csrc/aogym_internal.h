@@ -34,6 +34,7 @@ struct aog_env {
   _Float16* tab16 = nullptr;     // table-MFMA form: [n_ptiles][step 2][hi|lo][lane 64][8] A operands of the wfs tables
   float* sci_tile = nullptr;     // [n_ptiles][h 2][16] science table in accumulator order
   bool tab_mfma = false;         // table reduction on the matrix cores (k_fused_tab)
+  bool fused_t16 = false;        // opt-in (AOG_FUSED_T16=1 at aog_create): 16 x 16 x 16 tile variant k_fused_t16 (<= 8 tables)
   bool tab_attr_set = false;
   double* gram = nullptr;        // [A][A]
   double* wfs_coef = nullptr;    // [n_out][MRW_used][2]

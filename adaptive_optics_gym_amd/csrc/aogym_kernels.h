@@ -988,6 +988,156 @@ __global__ __launch_bounds__(256, 2) void k_fused_tab(const f16x8* __restrict__ 
   }
 }
 
+// ---- K3b''  the same two contractions on 16 x 16 x 16 matrix tiles: four waves per SIMD instead of two ---------------------------
+// k_fused_tab holds 232 registers (32 x 32 accumulators), two waves per SIMD, and on this hardware the vector unit's issue rate
+// scales with the number of resident waves (tools/microbench/valu_rates.hip: one instruction per 6 / 3 / 1.5 cycles with 1 / 2 / 4
+// waves per SIMD).  Here a wave owns a 16-pixel x 16-env sub-tile: 4-register accumulators, two-register operands, < 128 registers.
+// It reads the SAME operand arrays as k_fused_tab (host layouts are for the 32 x 32 x 16 instruction): a lane of the 16 x 16 x 16
+// operand (row or column = lane & 15, k = 4 (lane >> 4) + j) finds its four halves as one 8-byte piece of a 16-byte entry:
+//   mode / actuator operands : entry lane 32 (kg >> 1) + R0 + row,  halves 4 (kg & 1) ..     (k = 8 kgrp + e)
+//   table operands           : entry lane 32 (kg & 1) + m,          halves 4 (kg >> 1) ..    (pixel = 16 s + 8 (e >> 2) + 4 kgrp + (e & 3))
+//   screen / science rows    : float4 of group g = 2 s + (q >> 1), half h = q & 1, column C0 + c   (rows 8 g + 4 h + r = R0 + 4 q + r)
+// and the phase accumulator's layout (column = env, rows 4 q + r) IS the B-operand layout of the table product (k = pixel 4 q + j).
+// Workgroup = pixel chunk x two env tiles; wave w: env tile 2 eg + (w >> 1), env half C0 = 16 (w & 1); every wave walks all the
+// tiles of the chunk, both pixel halves.  Slabs as k_fused_tab's float64 variant: partials[chunk][s][env].
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+template <int A_PAD, int MRW>
+__global__ __launch_bounds__(256, 4) void k_fused_t16(const _Float16* __restrict__ modes16, const _Float16* __restrict__ tab16,
+                                                      const f32x4* __restrict__ sci_tile, const f32x4* __restrict__ psi_tile,
+                                                      const _Float16* __restrict__ act16, double* __restrict__ partials, MfmaGeom geo, float ratio) {
+  static_assert(MRW <= 8, "two table row groups of four");
+  constexpr int NSTEP = A_PAD / 16, NS = 2 * (MRW + 1);
+  extern __shared__ f32x4 lds_sci16[];   // [tile in chunk][h][4] float4
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int L = blockIdx.x, j = L >> 3;
+  const int c = (j / geo.wg_y) * 8 + (L & 7);
+  if (c >= geo.P) return;
+  const int etile = (j % geo.wg_y) * 2 + (wave >> 1);
+  const int etile_c = min(etile, geo.n_etiles - 1);
+  const int C0 = 16 * (wave & 1);
+  const int t0 = (int)(((long long)c * geo.n_ptiles) / geo.P);
+  const int t1 = (int)(((long long)(c + 1) * geo.n_ptiles) / geo.P);
+  const int col = lane & 15, q = lane >> 4;
+  {
+    const int n4 = (t1 - t0) * 8;
+    const f32x4* src = sci_tile + (size_t)t0 * 8;
+    for (int i = threadIdx.x; i < n4; i += 256) lds_sci16[i] = src[i];
+  }
+  // actuator operands of this wave's 16 envs: constant for the whole kernel
+  f16x4 bh[NSTEP], bl[NSTEP];
+  {
+    const _Float16* asrc = act16 + ((size_t)etile_c * NSTEP * 2) * 64 * 8 + (size_t)(32 * (q >> 1) + C0 + col) * 8 + 4 * (q & 1);
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+      bh[s] = *reinterpret_cast<const f16x4*>(asrc + (size_t)(2 * s) * 64 * 8);
+      bl[s] = *reinterpret_cast<const f16x4*>(asrc + (size_t)(2 * s + 1) * 64 * 8);
+    }
+  }
+  __syncthreads();
+  if (etile >= geo.n_etiles) return;
+  const int n_sub = 2 * (t1 - t0);
+  // per-lane pieces of the addresses
+  const int mode_lane = (32 * (q >> 1) + col) * 8 + 4 * (q & 1);       // + R0 * 8
+  const int tlane = (col <= MRW ? 32 * (q & 1) + col : 31) * 8 + 4 * (q >> 1);   // rows >= MRW are zero: one shared zero entry (row 31 of the first half)
+  const size_t psi_lane = (size_t)(q & 1) * 32 + C0 + col;
+  auto load_modes = [&](f16x4 (&mh)[NSTEP], f16x4 (&ml)[NSTEP], int i) {
+    const int t = t0 + (i >> 1), R0 = 16 * (i & 1);
+    const _Float16* ms = modes16 + ((size_t)t * NSTEP * 2) * 64 * 8 + R0 * 8 + mode_lane;
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+      mh[s] = *reinterpret_cast<const f16x4*>(ms + (size_t)(2 * s) * 64 * 8);
+      ml[s] = *reinterpret_cast<const f16x4*>(ms + (size_t)(2 * s + 1) * 64 * 8);
+    }
+  };
+  auto load_tab = [&](f16x4& th, f16x4& tl, int i) {
+    const int t = t0 + (i >> 1), sh = i & 1;
+    const _Float16* ts = tab16 + ((size_t)(t * 2 + sh) * 2) * 64 * 8 + tlane;
+    th = *reinterpret_cast<const f16x4*>(ts);
+    tl = *reinterpret_cast<const f16x4*>(ts + 64 * 8);
+  };
+  auto load_psi = [&](int i) {
+    const int t = t0 + (i >> 1), sh = i & 1;
+    return psi_tile[(((size_t)etile * geo.n_ptiles + t) * 4 + 2 * sh + (q >> 1)) * 64 + psi_lane];
+  };
+  f16x4 mh[NSTEP], ml[NSTEP], th, tl;
+  f32x4 psi;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 Dc = zero4, Ds = zero4;
+  float sc_c = 0.f, sc_s = 0.f;
+  double acc_c[4] = {0, 0, 0, 0}, acc_s[4] = {0, 0, 0, 0}, acc_sc = 0, acc_ss = 0;
+  auto flush = [&] {
+    acc_sc += (double)sc_c; acc_ss += (double)sc_s;
+    sc_c = 0.f; sc_s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      acc_c[r] += (double)Dc[r];
+      acc_s[r] += (double)Ds[r];
+    }
+    Dc = zero4;
+    Ds = zero4;
+  };
+  if (n_sub > 0) {
+    load_modes(mh, ml, 0);
+    load_tab(th, tl, 0);
+    psi = load_psi(0);
+  }
+  for (int i = 0; i < n_sub; ++i) {
+    const int inext = min(i + 1, n_sub - 1);
+    f32x4 d1 = zero4, d2 = zero4;
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+      d1 = __builtin_amdgcn_mfma_f32_16x16x16f16(mh[s], bh[s], d1, 0, 0, 0);
+      d2 = __builtin_amdgcn_mfma_f32_16x16x16f16(mh[s], bl[s], d2, 0, 0, 0);
+      d2 = __builtin_amdgcn_mfma_f32_16x16x16f16(ml[s], bh[s], d2, 0, 0, 0);
+    }
+    const f32x4 g = lds_sci16[(i >> 1) * 8 + (q & 1) * 4 + 2 * (i & 1) + (q >> 1)];
+    load_modes(mh, ml, inext);   // the operands those matrix ops read are free again
+    f32x4 u;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) u[r] = d1[r] * kD1Unscale + (psi[r] + d2[r] * kD2Unscale);
+    psi = load_psi(inext);
+    f16x4 ch, cl, sh, sl;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float cw = __builtin_amdgcn_cosf(u[r]), sw = __builtin_amdgcn_sinf(u[r]);
+      const float us = u[r] * ratio;
+      const float cs = __builtin_amdgcn_cosf(us), ss = __builtin_amdgcn_sinf(us);
+      sc_c = fmaf(cs, g[r], sc_c);
+      sc_s = fmaf(ss, g[r], sc_s);
+      const _Float16 chh = (_Float16)cw, shh = (_Float16)sw;
+      ch[r] = chh;
+      sh[r] = shh;
+      cl[r] = (_Float16)(cw - (float)chh);
+      sl[r] = (_Float16)(sw - (float)shh);
+    }
+    Dc = __builtin_amdgcn_mfma_f32_16x16x16f16(th, ch, Dc, 0, 0, 0);
+    Ds = __builtin_amdgcn_mfma_f32_16x16x16f16(th, sh, Ds, 0, 0, 0);
+    Dc = __builtin_amdgcn_mfma_f32_16x16x16f16(th, cl, Dc, 0, 0, 0);
+    Ds = __builtin_amdgcn_mfma_f32_16x16x16f16(th, sl, Ds, 0, 0, 0);
+    Dc = __builtin_amdgcn_mfma_f32_16x16x16f16(tl, ch, Dc, 0, 0, 0);
+    Ds = __builtin_amdgcn_mfma_f32_16x16x16f16(tl, sh, Ds, 0, 0, 0);
+    load_tab(th, tl, inext);
+    if ((i & 7) == 7) flush();   // 128 terms per fp32 accumulator element between folds into float64
+  }
+  flush();
+  double* out = partials + (size_t)c * NS * geo.Bp + (size_t)etile * 32 + C0 + col;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int m = 4 * q + r;
+    if (m < MRW) {
+      out[(size_t)(2 * m) * geo.Bp] = acc_c[r];
+      out[(size_t)(2 * m + 1) * geo.Bp] = acc_s[r];
+    }
+  }
+  double vc = acc_sc, vs = acc_ss;
+  vc += __shfl_xor(vc, 16, 64); vs += __shfl_xor(vs, 16, 64);
+  vc += __shfl_xor(vc, 32, 64); vs += __shfl_xor(vs, 32, 64);
+  if (q == 0) {
+    out[(size_t)(2 * MRW) * geo.Bp] = vc;
+    out[(size_t)(2 * MRW + 1) * geo.Bp] = vs;
+  }
+}
+
 // Phase-only form of the contraction: u = psi + Mt a for every (pixel, env), written back in the psi_tile layout.  Used by the
 // Shack-Hartmann chain, whose mirror (deformable_mirror_shack) carries its own actuators.  One wave per (env tile, pixel tile).
 template <int A_PAD>

@@ -33,6 +33,17 @@ void launch_mfma(aog_env* e, hipStream_t s) {
   g.skew = skew;
   dim3 grid(round_up(g.P, 8) * g.wg_y);
   const float ratio = (float)(e->cfg.wavelength_wfs / e->cfg.wavelength_sci);
+  if constexpr (MRW <= 8) {
+    if (e->tab_mfma && e->fused_t16 && e->mfma_we == 4) {   // (we == 4: one slab per pixel chunk, as this kernel writes them)
+      aog::MfmaGeom g16 = g;
+      g16.wg_y = (e->n_etiles + 1) / 2;
+      const size_t lds16 = (size_t)e->mfma_tpc * 8 * 16;
+      hipLaunchKernelGGL((aog::k_fused_t16<A_PAD, MRW>), dim3(round_up(g16.P, 8) * g16.wg_y), dim3(256), lds16, s, reinterpret_cast<const _Float16*>(e->modes16),
+                         reinterpret_cast<const _Float16*>(e->tab16), reinterpret_cast<const aog::f32x4*>(e->sci_tile),
+                         reinterpret_cast<const aog::f32x4*>(e->psi_tile), reinterpret_cast<const _Float16*>(e->act16), e->partials, g16, ratio);
+      return;
+    }
+  }
   if (e->tab_mfma) {
     const size_t lds_t = (size_t)e->mfma_tpc * 8 * 16 + ((MRW <= 8 || A_PAD > 64) ? (size_t)4 * (A_PAD / 16) * 2 * 64 * 16 : 0);   // science rows (+ actuator operands)
     if (lds_t > 64 * 1024 && !e->tab_attr_set) {

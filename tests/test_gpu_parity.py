@@ -249,6 +249,35 @@ def test_full_size_many_table_variants_vs_float64_kernel(N, A, o, rew):
     ref.close(); env.close()
 
 
+def test_sixteen_wide_tile_variant_vs_float64_kernel(monkeypatch):
+    """k_fused_t16 (opt-in, AOG_FUSED_T16=1): the same contractions on 16 x 16 x 16 matrix tiles at four waves per SIMD, reading
+    k_fused_tab's operand arrays through a different lane map.  130 envs = 5 env tiles: the last workgroup's second tile is padding."""
+    torch = _torch()
+    from adaptive_optics_gym_amd import BatchedAOEnv
+    from adaptive_optics_gym_amd.atmosphere_host import cn_squared_from_fried_parameter, screens_torch
+
+    N, B, A, o = 128, 130, 64, 2
+    dev = torch.device("cuda:0")
+    g = torch.Generator(dev).manual_seed(78)
+    scr = screens_torch(B, N, 0.5 / N, cn_squared_from_fried_parameter(0.15, 2.2e-6), 10.0, dev, g, oversampling=4)
+    a = torch.randn((B, A), device=dev, generator=g) * 0.7071
+    kw = dict(act_dim=A, obs_dim=o, rew_type="strehl_ratio", act_type="num_actuators", atm_fried=0.15, timesteps_per_episode=3,
+              num_pupil_pixels=N, verbose=False)
+    ref = BatchedAOEnv(B, dev, screens=scr, precision="fp64", **kw)
+    tab = BatchedAOEnv(B, dev, screens=scr, kernel="mfma", **kw)
+    monkeypatch.setenv("AOG_FUSED_T16", "1")
+    env = BatchedAOEnv(B, dev, screens=scr, kernel="mfma", **kw)
+    ref.reset(); tab.reset(); env.reset()
+    _, _, _, _, r_info = ref.step(a)
+    _, _, _, _, t_info = tab.step(a)
+    _, _, _, _, info = env.step(a)
+    _assert_obs_close(info["obs_raw"].cpu().numpy(), r_info["obs_raw"].cpu().numpy())
+    assert torch.max(torch.abs(info["strehl"].double() / r_info["strehl"].double() - 1)) < RTOL
+    assert torch.max(torch.abs(info["power"].double() / r_info["power"].double() - 1)) < RTOL
+    assert not torch.equal(info["obs_raw"], t_info["obs_raw"])     # (a different kernel did run: other summation order)
+    ref.close(); tab.close(); env.close()
+
+
 @pytest.mark.parametrize("o", [2, 5])
 def test_fast_kernel_is_repeatable_at_full_size(o):
     """Identical launches give identical bits (B = 1024, N = 256: two workgroups per CU, skewed start).  Regression test for a
