@@ -999,27 +999,47 @@ __global__ __launch_bounds__(256, 2) void k_fused_tab(const f16x8* __restrict__ 
 //   screen / science rows    : float4 of group g = 2 s + (q >> 1), half h = q & 1, column C0 + c   (rows 8 g + 4 h + r = R0 + 4 q + r)
 // and the phase accumulator's layout (column = env, rows 4 q + r) IS the B-operand layout of the table product (k = pixel 4 q + j).
 // Workgroup = pixel chunk x two env tiles; wave w: env tile 2 eg + (w >> 1), env half C0 = 16 (w & 1); every wave walks all the
-// tiles of the chunk, both pixel halves.  Slabs as k_fused_tab's float64 variant: partials[chunk][s][env].
+// tiles of the chunk, both pixel halves.  The mode tile (8 KB per 32 pixels at 64 modes) is fetched ONCE per workgroup — global ->
+// registers while the previous tile is worked on, -> LDS, one barrier per tile — and the four waves read their operands from LDS:
+// with per-wave global loads the smaller tiles doubled the bytes through the L1 (64 B/clk) and the variant ran at 75 us.
+// Slabs as k_fused_tab's float64 variant: partials[chunk][s][env].
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 template <int A_PAD, int MRW>
-__global__ __launch_bounds__(256, 4) void k_fused_t16(const _Float16* __restrict__ modes16, const _Float16* __restrict__ tab16,
+__global__ __launch_bounds__(256, 3) void k_fused_t16(const _Float16* __restrict__ modes16, const _Float16* __restrict__ tab16,
                                                       const f32x4* __restrict__ sci_tile, const f32x4* __restrict__ psi_tile,
                                                       const _Float16* __restrict__ act16, double* __restrict__ partials, MfmaGeom geo, float ratio) {
   static_assert(MRW <= 8, "two table row groups of four");
   constexpr int NSTEP = A_PAD / 16, NS = 2 * (MRW + 1);
-  extern __shared__ f32x4 lds_sci16[];   // [tile in chunk][h][4] float4
+  constexpr int MODE_ENTRIES = NSTEP * 2 * 64;   // 16-byte entries of one 32-pixel mode tile (hi and lo halves)
+  extern __shared__ f32x4 lds_sci16[];   // science rows [tile in chunk][h][4] float4 | two mode-tile buffers [MODE_ENTRIES] x 16 B
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int L = blockIdx.x, j = L >> 3;
   const int c = (j / geo.wg_y) * 8 + (L & 7);
   if (c >= geo.P) return;
   const int etile = (j % geo.wg_y) * 2 + (wave >> 1);
-  const int etile_c = min(etile, geo.n_etiles - 1);
+  const int etile_c = min(etile, geo.n_etiles - 1);   // a padding tile computes on a copy of the last one and stores nothing
   const int C0 = 16 * (wave & 1);
   const int t0 = (int)(((long long)c * geo.n_ptiles) / geo.P);
   const int t1 = (int)(((long long)(c + 1) * geo.n_ptiles) / geo.P);
+  const int nt = t1 - t0;
   const int col = lane & 15, q = lane >> 4;
+  f16x8* lds_modes = reinterpret_cast<f16x8*>(lds_sci16 + (size_t)geo.max_tiles * 8);
+  // the mode tile of the chunk's first pixel tile goes to buffer 0 together with the science rows
+  constexpr int MPT = (MODE_ENTRIES + 255) / 256;   // 16-byte pieces of a mode tile per thread
+  auto fetch_modes = [&](f16x8 (&r)[MPT], int t) {
+    const f16x8* src = reinterpret_cast<const f16x8*>(modes16) + (size_t)min(t, t1 - 1) * MODE_ENTRIES;
+#pragma unroll
+    for (int u = 0; u < MPT; ++u) r[u] = src[min((int)threadIdx.x + 256 * u, MODE_ENTRIES - 1)];
+  };
+  auto stash_modes = [&](const f16x8 (&r)[MPT], int buf) {
+#pragma unroll
+    for (int u = 0; u < MPT; ++u)
+      if ((int)threadIdx.x + 256 * u < MODE_ENTRIES) lds_modes[(size_t)buf * MODE_ENTRIES + threadIdx.x + 256 * u] = r[u];
+  };
+  f16x8 mstage[MPT];
+  fetch_modes(mstage, t0);
   {
-    const int n4 = (t1 - t0) * 8;
+    const int n4 = nt * 8;
     const f32x4* src = sci_tile + (size_t)t0 * 8;
     for (int i = threadIdx.x; i < n4; i += 256) lds_sci16[i] = src[i];
   }
@@ -1033,22 +1053,12 @@ __global__ __launch_bounds__(256, 4) void k_fused_t16(const _Float16* __restrict
       bl[s] = *reinterpret_cast<const f16x4*>(asrc + (size_t)(2 * s + 1) * 64 * 8);
     }
   }
+  stash_modes(mstage, 0);
   __syncthreads();
-  if (etile >= geo.n_etiles) return;
-  const int n_sub = 2 * (t1 - t0);
   // per-lane pieces of the addresses
-  const int mode_lane = (32 * (q >> 1) + col) * 8 + 4 * (q & 1);       // + R0 * 8
+  const int mode_lane = (32 * (q >> 1) + col) * 8 + 4 * (q & 1);       // halves inside a mode tile; + R0 * 8
   const int tlane = (col <= MRW ? 32 * (q & 1) + col : 31) * 8 + 4 * (q >> 1);   // rows >= MRW are zero: one shared zero entry (row 31 of the first half)
   const size_t psi_lane = (size_t)(q & 1) * 32 + C0 + col;
-  auto load_modes = [&](f16x4 (&mh)[NSTEP], f16x4 (&ml)[NSTEP], int i) {
-    const int t = t0 + (i >> 1), R0 = 16 * (i & 1);
-    const _Float16* ms = modes16 + ((size_t)t * NSTEP * 2) * 64 * 8 + R0 * 8 + mode_lane;
-#pragma unroll
-    for (int s = 0; s < NSTEP; ++s) {
-      mh[s] = *reinterpret_cast<const f16x4*>(ms + (size_t)(2 * s) * 64 * 8);
-      ml[s] = *reinterpret_cast<const f16x4*>(ms + (size_t)(2 * s + 1) * 64 * 8);
-    }
-  };
   auto load_tab = [&](f16x4& th, f16x4& tl, int i) {
     const int t = t0 + (i >> 1), sh = i & 1;
     const _Float16* ts = tab16 + ((size_t)(t * 2 + sh) * 2) * 64 * 8 + tlane;
@@ -1057,10 +1067,12 @@ __global__ __launch_bounds__(256, 4) void k_fused_t16(const _Float16* __restrict
   };
   auto load_psi = [&](int i) {
     const int t = t0 + (i >> 1), sh = i & 1;
-    return psi_tile[(((size_t)etile * geo.n_ptiles + t) * 4 + 2 * sh + (q >> 1)) * 64 + psi_lane];
+    return psi_tile[(((size_t)etile_c * geo.n_ptiles + t) * 4 + 2 * sh + (q >> 1)) * 64 + psi_lane];
   };
-  f16x4 mh[NSTEP], ml[NSTEP], th, tl;
-  f32x4 psi;
+  // screen values and table operands of BOTH sub-tiles of a tile, one whole tile ahead (a sub-tile takes about one memory latency:
+  // requested one sub-tile ahead they arrived late every time)
+  f16x4 thc[2], tlc[2], thn[2], tln[2];
+  f32x4 psic[2], psin[2];
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   f32x4 Dc = zero4, Ds = zero4;
   float sc_c = 0.f, sc_s = 0.f;
@@ -1076,50 +1088,79 @@ __global__ __launch_bounds__(256, 4) void k_fused_t16(const _Float16* __restrict
     Dc = zero4;
     Ds = zero4;
   };
+  const int n_sub = 2 * nt;
   if (n_sub > 0) {
-    load_modes(mh, ml, 0);
-    load_tab(th, tl, 0);
-    psi = load_psi(0);
+#pragma unroll
+    for (int shf = 0; shf < 2; ++shf) {
+      load_tab(thc[shf], tlc[shf], shf);
+      psic[shf] = load_psi(shf);
+    }
   }
-  for (int i = 0; i < n_sub; ++i) {
-    const int inext = min(i + 1, n_sub - 1);
-    f32x4 d1 = zero4, d2 = zero4;
+  for (int tt = 0; tt < nt; ++tt) {
+    // the next tile's modes travel (global -> registers) while this tile is worked on
+    fetch_modes(mstage, t0 + tt + 1);
 #pragma unroll
-    for (int s = 0; s < NSTEP; ++s) {
-      d1 = __builtin_amdgcn_mfma_f32_16x16x16f16(mh[s], bh[s], d1, 0, 0, 0);
-      d2 = __builtin_amdgcn_mfma_f32_16x16x16f16(mh[s], bl[s], d2, 0, 0, 0);
-      d2 = __builtin_amdgcn_mfma_f32_16x16x16f16(ml[s], bh[s], d2, 0, 0, 0);
+    for (int shf = 0; shf < 2; ++shf) {
+      const int inext = min(2 * tt + 2 + shf, n_sub - 1);
+      load_tab(thn[shf], tln[shf], inext);
+      psin[shf] = load_psi(inext);
     }
-    const f32x4 g = lds_sci16[(i >> 1) * 8 + (q & 1) * 4 + 2 * (i & 1) + (q >> 1)];
-    load_modes(mh, ml, inext);   // the operands those matrix ops read are free again
-    f32x4 u;
+    const _Float16* mbuf = reinterpret_cast<const _Float16*>(lds_modes + (size_t)(tt & 1) * MODE_ENTRIES) + mode_lane;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) u[r] = d1[r] * kD1Unscale + (psi[r] + d2[r] * kD2Unscale);
-    psi = load_psi(inext);
-    f16x4 ch, cl, sh, sl;
+    for (int shf = 0; shf < 2; ++shf) {
+      f32x4 d1 = zero4, d2 = zero4;
+      {
+        f16x4 mh[NSTEP], ml[NSTEP];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float cw = __builtin_amdgcn_cosf(u[r]), sw = __builtin_amdgcn_sinf(u[r]);
-      const float us = u[r] * ratio;
-      const float cs = __builtin_amdgcn_cosf(us), ss = __builtin_amdgcn_sinf(us);
-      sc_c = fmaf(cs, g[r], sc_c);
-      sc_s = fmaf(ss, g[r], sc_s);
-      const _Float16 chh = (_Float16)cw, shh = (_Float16)sw;
-      ch[r] = chh;
-      sh[r] = shh;
-      cl[r] = (_Float16)(cw - (float)chh);
-      sl[r] = (_Float16)(sw - (float)shh);
+        for (int s = 0; s < NSTEP; ++s) {
+          mh[s] = *reinterpret_cast<const f16x4*>(mbuf + shf * 16 * 8 + (2 * s) * 64 * 8);
+          ml[s] = *reinterpret_cast<const f16x4*>(mbuf + shf * 16 * 8 + (2 * s + 1) * 64 * 8);
+        }
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+          d1 = __builtin_amdgcn_mfma_f32_16x16x16f16(mh[s], bh[s], d1, 0, 0, 0);
+          d2 = __builtin_amdgcn_mfma_f32_16x16x16f16(mh[s], bl[s], d2, 0, 0, 0);
+          d2 = __builtin_amdgcn_mfma_f32_16x16x16f16(ml[s], bh[s], d2, 0, 0, 0);
+        }
+      }
+      const f32x4 g = lds_sci16[tt * 8 + (q & 1) * 4 + 2 * shf + (q >> 1)];
+      f32x4 u;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) u[r] = d1[r] * kD1Unscale + (psic[shf][r] + d2[r] * kD2Unscale);
+      f16x4 ch, cl, sh, sl;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float cw = __builtin_amdgcn_cosf(u[r]), sw = __builtin_amdgcn_sinf(u[r]);
+        const float us = u[r] * ratio;
+        const float cs = __builtin_amdgcn_cosf(us), ss = __builtin_amdgcn_sinf(us);
+        sc_c = fmaf(cs, g[r], sc_c);
+        sc_s = fmaf(ss, g[r], sc_s);
+        const _Float16 chh = (_Float16)cw, shh = (_Float16)sw;
+        ch[r] = chh;
+        sh[r] = shh;
+        cl[r] = (_Float16)(cw - (float)chh);
+        sl[r] = (_Float16)(sw - (float)shh);
+      }
+      Dc = __builtin_amdgcn_mfma_f32_16x16x16f16(thc[shf], ch, Dc, 0, 0, 0);
+      Ds = __builtin_amdgcn_mfma_f32_16x16x16f16(thc[shf], sh, Ds, 0, 0, 0);
+      Dc = __builtin_amdgcn_mfma_f32_16x16x16f16(thc[shf], cl, Dc, 0, 0, 0);
+      Ds = __builtin_amdgcn_mfma_f32_16x16x16f16(thc[shf], sl, Ds, 0, 0, 0);
+      Dc = __builtin_amdgcn_mfma_f32_16x16x16f16(tlc[shf], ch, Dc, 0, 0, 0);
+      Ds = __builtin_amdgcn_mfma_f32_16x16x16f16(tlc[shf], sh, Ds, 0, 0, 0);
     }
-    Dc = __builtin_amdgcn_mfma_f32_16x16x16f16(th, ch, Dc, 0, 0, 0);
-    Ds = __builtin_amdgcn_mfma_f32_16x16x16f16(th, sh, Ds, 0, 0, 0);
-    Dc = __builtin_amdgcn_mfma_f32_16x16x16f16(th, cl, Dc, 0, 0, 0);
-    Ds = __builtin_amdgcn_mfma_f32_16x16x16f16(th, sl, Ds, 0, 0, 0);
-    Dc = __builtin_amdgcn_mfma_f32_16x16x16f16(tl, ch, Dc, 0, 0, 0);
-    Ds = __builtin_amdgcn_mfma_f32_16x16x16f16(tl, sh, Ds, 0, 0, 0);
-    load_tab(th, tl, inext);
-    if ((i & 7) == 7) flush();   // 128 terms per fp32 accumulator element between folds into float64
+    if ((tt & 3) == 3) flush();   // 128 terms per fp32 accumulator element between folds into float64
+    // publish the next tile's modes: its buffer was last read during tile tt - 1, which every wave has left (barrier below, one tile ago)
+    stash_modes(mstage, (tt + 1) & 1);
+#pragma unroll
+    for (int shf = 0; shf < 2; ++shf) {
+      thc[shf] = thn[shf];
+      tlc[shf] = tln[shf];
+      psic[shf] = psin[shf];
+    }
+    __syncthreads();
   }
   flush();
+  if (etile >= geo.n_etiles) return;
   double* out = partials + (size_t)c * NS * geo.Bp + (size_t)etile * 32 + C0 + col;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {

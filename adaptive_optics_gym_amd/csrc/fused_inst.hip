@@ -37,7 +37,7 @@ void launch_mfma(aog_env* e, hipStream_t s) {
     if (e->tab_mfma && e->fused_t16 && e->mfma_we == 4) {   // (we == 4: one slab per pixel chunk, as this kernel writes them)
       aog::MfmaGeom g16 = g;
       g16.wg_y = (e->n_etiles + 1) / 2;
-      const size_t lds16 = (size_t)e->mfma_tpc * 8 * 16;
+      const size_t lds16 = (size_t)e->mfma_tpc * 8 * 16 + (size_t)2 * (A_PAD / 16) * 2 * 64 * 16;   // science rows + two mode-tile buffers
       hipLaunchKernelGGL((aog::k_fused_t16<A_PAD, MRW>), dim3(round_up(g16.P, 8) * g16.wg_y), dim3(256), lds16, s, reinterpret_cast<const _Float16*>(e->modes16),
                          reinterpret_cast<const _Float16*>(e->tab16), reinterpret_cast<const aog::f32x4*>(e->sci_tile),
                          reinterpret_cast<const aog::f32x4*>(e->psi_tile), reinterpret_cast<const _Float16*>(e->act16), e->partials, g16, ratio);

@@ -263,6 +263,7 @@ def test_sixteen_wide_tile_variant_vs_float64_kernel(monkeypatch):
     a = torch.randn((B, A), device=dev, generator=g) * 0.7071
     kw = dict(act_dim=A, obs_dim=o, rew_type="strehl_ratio", act_type="num_actuators", atm_fried=0.15, timesteps_per_episode=3,
               num_pupil_pixels=N, verbose=False)
+    monkeypatch.delenv("AOG_FUSED_T16", raising=False)
     ref = BatchedAOEnv(B, dev, screens=scr, precision="fp64", **kw)
     tab = BatchedAOEnv(B, dev, screens=scr, kernel="mfma", **kw)
     monkeypatch.setenv("AOG_FUSED_T16", "1")
