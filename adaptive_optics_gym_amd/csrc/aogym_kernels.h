@@ -1004,7 +1004,7 @@ __global__ __launch_bounds__(256, 2) void k_fused_tab(const f16x8* __restrict__ 
 // with per-wave global loads the smaller tiles doubled the bytes through the L1 (64 B/clk) and the variant ran at 75 us.
 // Slabs as k_fused_tab's float64 variant: partials[chunk][s][env].
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-template <int A_PAD, int MRW>
+template <int A_PAD, int MRW, int ABL = 0>   // ABL: timing-only ablations (results meaningless): 1 no sin/cos, 2 no table products, 3 no phase products, 4 no tile barrier
 __global__ __launch_bounds__(256, 3) void k_fused_t16(const _Float16* __restrict__ modes16, const _Float16* __restrict__ tab16,
                                                       const f32x4* __restrict__ sci_tile, const f32x4* __restrict__ psi_tile,
                                                       const _Float16* __restrict__ act16, double* __restrict__ partials, MfmaGeom geo, float ratio) {
@@ -1118,9 +1118,14 @@ __global__ __launch_bounds__(256, 3) void k_fused_t16(const _Float16* __restrict
         }
 #pragma unroll
         for (int s = 0; s < NSTEP; ++s) {
-          d1 = __builtin_amdgcn_mfma_f32_16x16x16f16(mh[s], bh[s], d1, 0, 0, 0);
-          d2 = __builtin_amdgcn_mfma_f32_16x16x16f16(mh[s], bl[s], d2, 0, 0, 0);
-          d2 = __builtin_amdgcn_mfma_f32_16x16x16f16(ml[s], bh[s], d2, 0, 0, 0);
+          if constexpr (ABL == 3) {
+            d1[s & 3] += (float)mh[s][0] * (float)bh[s][0];
+            d2[s & 3] += (float)ml[s][1] * (float)bl[s][1];
+          } else {
+            d1 = __builtin_amdgcn_mfma_f32_16x16x16f16(mh[s], bh[s], d1, 0, 0, 0);
+            d2 = __builtin_amdgcn_mfma_f32_16x16x16f16(mh[s], bl[s], d2, 0, 0, 0);
+            d2 = __builtin_amdgcn_mfma_f32_16x16x16f16(ml[s], bh[s], d2, 0, 0, 0);
+          }
         }
       }
       const f32x4 g = lds_sci16[tt * 8 + (q & 1) * 4 + 2 * shf + (q >> 1)];
@@ -1130,9 +1135,14 @@ __global__ __launch_bounds__(256, 3) void k_fused_t16(const _Float16* __restrict
       f16x4 ch, cl, sh, sl;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float cw = __builtin_amdgcn_cosf(u[r]), sw = __builtin_amdgcn_sinf(u[r]);
         const float us = u[r] * ratio;
-        const float cs = __builtin_amdgcn_cosf(us), ss = __builtin_amdgcn_sinf(us);
+        float cw, sw, cs, ss;
+        if constexpr (ABL == 1) {
+          cw = u[r] * 0.5f; sw = u[r] * 0.25f; cs = us * 0.5f; ss = us * 0.25f;
+        } else {
+          cw = __builtin_amdgcn_cosf(u[r]); sw = __builtin_amdgcn_sinf(u[r]);
+          cs = __builtin_amdgcn_cosf(us); ss = __builtin_amdgcn_sinf(us);
+        }
         sc_c = fmaf(cs, g[r], sc_c);
         sc_s = fmaf(ss, g[r], sc_s);
         const _Float16 chh = (_Float16)cw, shh = (_Float16)sw;
@@ -1141,12 +1151,16 @@ __global__ __launch_bounds__(256, 3) void k_fused_t16(const _Float16* __restrict
         cl[r] = (_Float16)(cw - (float)chh);
         sl[r] = (_Float16)(sw - (float)shh);
       }
+      if constexpr (ABL == 2) {
+        Dc[0] += (float)ch[0] + (float)cl[1] + (float)thc[shf][0]; Ds[0] += (float)sh[2] + (float)sl[3] + (float)tlc[shf][0];
+      } else {
       Dc = __builtin_amdgcn_mfma_f32_16x16x16f16(thc[shf], ch, Dc, 0, 0, 0);
       Ds = __builtin_amdgcn_mfma_f32_16x16x16f16(thc[shf], sh, Ds, 0, 0, 0);
       Dc = __builtin_amdgcn_mfma_f32_16x16x16f16(thc[shf], cl, Dc, 0, 0, 0);
       Ds = __builtin_amdgcn_mfma_f32_16x16x16f16(thc[shf], sl, Ds, 0, 0, 0);
       Dc = __builtin_amdgcn_mfma_f32_16x16x16f16(tlc[shf], ch, Dc, 0, 0, 0);
       Ds = __builtin_amdgcn_mfma_f32_16x16x16f16(tlc[shf], sh, Ds, 0, 0, 0);
+      }
     }
     if ((tt & 3) == 3) flush();   // 128 terms per fp32 accumulator element between folds into float64
     // publish the next tile's modes: its buffer was last read during tile tt - 1, which every wave has left (barrier below, one tile ago)
@@ -1157,7 +1171,7 @@ __global__ __launch_bounds__(256, 3) void k_fused_t16(const _Float16* __restrict
       tlc[shf] = tln[shf];
       psic[shf] = psin[shf];
     }
-    __syncthreads();
+    if constexpr (ABL != 4) __syncthreads();
   }
   flush();
   if (etile >= geo.n_etiles) return;

@@ -38,9 +38,19 @@ void launch_mfma(aog_env* e, hipStream_t s) {
       aog::MfmaGeom g16 = g;
       g16.wg_y = (e->n_etiles + 1) / 2;
       const size_t lds16 = (size_t)e->mfma_tpc * 8 * 16 + (size_t)2 * (A_PAD / 16) * 2 * 64 * 16;   // science rows + two mode-tile buffers
-      hipLaunchKernelGGL((aog::k_fused_t16<A_PAD, MRW>), dim3(round_up(g16.P, 8) * g16.wg_y), dim3(256), lds16, s, reinterpret_cast<const _Float16*>(e->modes16),
-                         reinterpret_cast<const _Float16*>(e->tab16), reinterpret_cast<const aog::f32x4*>(e->sci_tile),
-                         reinterpret_cast<const aog::f32x4*>(e->psi_tile), reinterpret_cast<const _Float16*>(e->act16), e->partials, g16, ratio);
+#define AOG_T16_LAUNCH(ABL)                                                                                                                      \
+  hipLaunchKernelGGL((aog::k_fused_t16<A_PAD, MRW, ABL>), dim3(round_up(g16.P, 8) * g16.wg_y), dim3(256), lds16, s,                                 \
+                     reinterpret_cast<const _Float16*>(e->modes16), reinterpret_cast<const _Float16*>(e->tab16),                                   \
+                     reinterpret_cast<const aog::f32x4*>(e->sci_tile), reinterpret_cast<const aog::f32x4*>(e->psi_tile),                           \
+                     reinterpret_cast<const _Float16*>(e->act16), e->partials, g16, ratio)
+      if constexpr (A_PAD == 64 && MRW == 7) {   // timing-only ablations of the developer variant (AOG_ABLATE=1..4)
+        if (e->ablate == 1) { AOG_T16_LAUNCH(1); return; }
+        if (e->ablate == 2) { AOG_T16_LAUNCH(2); return; }
+        if (e->ablate == 3) { AOG_T16_LAUNCH(3); return; }
+        if (e->ablate == 4) { AOG_T16_LAUNCH(4); return; }
+      }
+      AOG_T16_LAUNCH(0);
+#undef AOG_T16_LAUNCH
       return;
     }
   }
