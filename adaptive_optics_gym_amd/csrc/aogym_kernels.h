@@ -1493,9 +1493,11 @@ __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint
   c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
 }
 
-// standard normal number `idx` of stream (seed, env, extrusion)
-__device__ inline double philox_normal(unsigned long long seed, uint32_t env, uint32_t ext, uint32_t idx) {
-  uint32_t c[4] = {idx >> 1, ext, env, 0u};
+// standard normal numbers 4 idx4 .. 4 idx4 + 3 of stream (seed, env, extrusion): one Philox4x32-10 call = four 32-bit words = two
+// Box-Muller pairs, both the cosine and the sine branch of each used.  Hardware log/sin/cos (fp32 accuracy is ample for a noise
+// sample; parity runs supply their normals from the host instead).
+__device__ inline void philox_normal4(unsigned long long seed, uint32_t env, uint32_t ext, uint32_t idx4, double (&out)[4]) {
+  uint32_t c[4] = {idx4, ext, env, 0u};
   uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
   for (int rr = 0; rr < 10; ++rr) {
@@ -1503,13 +1505,21 @@ __device__ inline double philox_normal(unsigned long long seed, uint32_t env, ui
     k0 += 0x9E3779B9u;
     k1 += 0xBB67AE85u;
   }
-  // Box-Muller on two 32-bit uniforms with the hardware log/sin/cos (fp32 accuracy is ample for a noise sample; parity runs
-  // supply their normals from the host instead), one of the two pairs by parity of idx
-  const uint32_t w0 = (idx & 1) ? c[2] : c[0], w1 = (idx & 1) ? c[3] : c[1];
-  const float u1 = ((float)(w0 >> 8) + 0.5f) * (1.0f / 16777216.0f);   // (0, 1)
-  const float u2 = (float)(w1 >> 8) * (1.0f / 16777216.0f);            // [0, 1) revolutions
-  const float r = sqrtf(-2.0f * __logf(u1));
-  return (double)(r * __builtin_amdgcn_cosf(u2));
+#pragma unroll
+  for (int pr = 0; pr < 2; ++pr) {
+    const float u1 = ((float)(c[2 * pr] >> 8) + 0.5f) * (1.0f / 16777216.0f);   // (0, 1)
+    const float u2 = (float)(c[2 * pr + 1] >> 8) * (1.0f / 16777216.0f);        // [0, 1) revolutions
+    const float r = sqrtf(-2.0f * __logf(u1));
+    out[2 * pr] = (double)(r * __builtin_amdgcn_cosf(u2));
+    out[2 * pr + 1] = (double)(r * __builtin_amdgcn_sinf(u2));
+  }
+}
+// standard normal number `idx` of the same stream (element idx & 3 of call idx >> 2)
+__device__ inline double philox_normal(unsigned long long seed, uint32_t env, uint32_t ext, uint32_t idx) {
+  double v[4];
+  philox_normal4(seed, env, ext, idx >> 2, v);
+  const double a = (idx & 2) ? v[2] : v[0], b = (idx & 2) ? v[3] : v[1];
+  return (idx & 1) ? b : a;
 }
 
 #ifdef AOG_MAIN_TU
@@ -1901,12 +1911,24 @@ __global__ __launch_bounds__(256 * KS) void k_extrude16_split(ExtrudeArgs p, int
     }
     __syncthreads();
     if (dbg) { long long t = wall_clock64(); tm[0] += t - t0; t0 = t; }
-    for (int idx = threadIdx.x; idx < G * N; idx += blockDim.x) {
-      const int g = idx / N, j = idx - g * N;
-      if (!cls(g)) continue;
-      const int env = s_env[g];
-      nb[(size_t)g * ns + j] = (p.noise && r < p.max_ext) ? p.noise[((size_t)env * p.max_ext + r) * N + j]
-                                                          : philox_normal(p.seed, (uint32_t)env, p.ext_counter[env] + (uint32_t)r, (uint32_t)j);
+    if (p.noise && r < p.max_ext) {
+      for (int idx = threadIdx.x; idx < G * N; idx += blockDim.x) {
+        const int g = idx / N, j = idx - g * N;
+        if (!cls(g)) continue;
+        nb[(size_t)g * ns + j] = p.noise[((size_t)s_env[g] * p.max_ext + r) * N + j];
+      }
+    } else {
+      const int n4 = (N + 3) >> 2;   // four normals per Philox call
+      for (int idx = threadIdx.x; idx < G * n4; idx += blockDim.x) {
+        const int g = idx / n4, j4 = idx - g * n4;
+        if (!cls(g)) continue;
+        const int env = s_env[g];
+        double v[4];
+        philox_normal4(p.seed, (uint32_t)env, p.ext_counter[env] + (uint32_t)r, (uint32_t)j4, v);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (4 * j4 + u < N) nb[(size_t)g * ns + 4 * j4 + u] = v[u];
+      }
     }
     __syncthreads();
     if (dbg) { long long t = wall_clock64(); tm[1] += t - t0; t0 = t; }
