@@ -472,7 +472,7 @@ class BatchedAOEnv:
         return int(v.value)
 
     def profile(self, enable=True, every=1):
-        """HIP-event timing of the fused kernel; ``every`` = n times one block of 32 consecutive launches in n (the records hold the
+        """HIP-event timing of the fused kernel; ``every`` = n times one block of 8 consecutive launches in n (the records hold the
         stream ~6 us per timed launch)."""
         _lib.check(self.lib.aog_profile_enable(self._handle, max(1, int(every)) if enable else 0))
 

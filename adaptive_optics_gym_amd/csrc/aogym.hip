@@ -103,8 +103,8 @@ int launch_fused(aog_env* e, hipStream_t s) {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // event timing of one launch block in profile_every: the two records cost ~3 us each on the stream, so a throughput measurement that
   // also wants the kernel's duration samples instead of timing every launch
-  // (blocks of 32 consecutive launches, one block in profile_every: a timed launch sees the same neighbours as with every launch timed)
-  const bool timed = e->profile && ((e->profile_phase++ >> 5) % (unsigned)e->profile_every) == 0;
+  // (blocks of 8 consecutive launches, one block in profile_every: a timed launch mostly sees the same neighbours as with every launch timed)
+  const bool timed = e->profile && ((e->profile_phase++ >> 3) % (unsigned)e->profile_every) == 0;
   if (timed) {
     if (e->events_used == e->events.size()) {
       HIP_TRY(hipEventCreate(&ev0));
@@ -1272,6 +1272,7 @@ int aog_profile_read(aog_env* e, double* mean_ms, int* launches) {
   *launches = (int)e->events_used;
   *mean_ms = e->events_used ? total / (double)e->events_used : 0.0;
   e->events_used = 0;
+  e->profile_phase = 0;   // the next launch opens a timed block: a short measurement after a read still gets its samples
   return AOG_OK;
 }
 

@@ -261,7 +261,7 @@ int aog_selftest_sincos(const float* u_dev, float* sin_dev, float* cos_dev, int 
 
 /* Microseconds-resolution timing of the dominant (fused) kernel of the most recent aog_step/aog_reset calls,
  * measured with HIP events on the stream the kernel was launched on.  Enable, run steps, then read the
- * mean duration (ms) and the number of launches averaged.  enable = n > 1 times one block of 32 consecutive launches in n only: the two event records
+ * mean duration (ms) and the number of launches averaged.  enable = n > 1 times one block of 8 consecutive launches in n only: the two event records
  * of a timed launch hold the stream for ~6 us, which a throughput measurement running at the same time should not pay on
  * every step. */
 int aog_profile_enable(aog_env* env, int enable);

@@ -30,7 +30,7 @@ env.reset()
 for _ in range(20): env.step(a)
 torch.cuda.synchronize()
 env.device_status()
-env.profile(True, every=8)   # one block of 32 launches in 8: the event records hold the stream ~6 us per timed launch
+env.profile(True, every=8)   # one block of 8 launches in 8: the event records hold the stream ~6 us per timed launch
 step = lambda: env.step(a)
 if args.graph:
     g_ = torch.cuda.CUDAGraph()
