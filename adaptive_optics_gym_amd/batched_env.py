@@ -458,6 +458,9 @@ class BatchedAOEnv:
         episode start) inside the step's last kernel — the episode-return sum of the rollout without a launch of its own.
         ``None`` detaches.  The tensor must stay alive while attached (a reference is kept here)."""
         torch = self._torch
+        if getattr(self, "_handle", None) is None:   # closed env: nothing to attach to or detach from
+            self._returns_ref = None
+            return
         if returns is not None:
             ok = returns.dtype == torch.float32 and tuple(returns.shape) == (self.num_envs,) and returns.is_contiguous() and returns.is_cuda
             if not ok:
