@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libaogym.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 AOG_REWARD = {"strehl_ratio": 0, "smf_ssim": 1}
 AOG_PRECISION = {"fast": 0, "fp64": 1}
@@ -21,7 +21,7 @@ class AogConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "abi_version", "num_envs", "n_pupil", "n_modes", "obs_dim", "n_ap", "n_wfs_tables", "n_sci_tables",
         "n_fiber_modes", "reward_type", "sh_operation", "max_steps", "flat_mirror_start", "has_rew_threshold",
-        "precision", "kernel", "pixel_chunks", "atm_dynamic")] + [(n, C.c_double) for n in (
+        "precision", "kernel", "pixel_chunks", "atm_dynamic", "env_id_base", "reserved0")] + [(n, C.c_double) for n in (
         "wavelength_wfs", "wavelength_sci", "surface_rms_target", "rew_threshold", "ssim_ref_peak", "ssim_alpha")]
 
 
@@ -46,6 +46,7 @@ class AogShTables(C.Structure):
 
 class AogActor(C.Structure):  # mirrors aog_actor in include/aogym.h
     _fields_ = [("batch", C.c_int32), ("state_dim", C.c_int32), ("hidden_dim", C.c_int32), ("act_dim", C.c_int32),
+                ("env_id_base", C.c_int32), ("reserved0", C.c_int32),
                 ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p), ("w3", C.c_void_p), ("b3", C.c_void_p),
                 ("wo", C.c_void_p), ("bo", C.c_void_p), ("dropout_p", C.c_float), ("cov_var", C.c_float),
                 ("seed", C.c_uint64), ("call_index", C.c_uint64)]

@@ -29,10 +29,15 @@ class BatchedAOEnv:
     num_envs            B
     device              torch device (default ``cuda:0``)
     num_pupil_pixels    pupil grid side N (reference: 240)
-    seed                seed of the screen generator (env e uses seed + e for ``screen_source='numpy'``)
+    seed                seed of the screen generator (global env g uses seed + g for ``screen_source='numpy'``)
     screen_source       'device' (default: hipFFT synthesis inside libaogym, Philox normals) | 'torch' (same algorithm through
                         torch.fft) | 'numpy' (hcipy's draw order on a numpy legacy stream, float64, host)
     screens             optional [B, N, N] achromatic screens to use instead of generating them
+    global_env_offset   global id of env 0 of this instance (multi-GPU: ``sharding.shard_range(total, rank, world)[0]``)
+    total_envs          size of the global batch this instance is a contiguous slice of (default: offset + num_envs).
+                        Every per-env random stream (wind direction, device screen synthesis, extrusion normals, photon noise,
+                        numpy per-env seeds) is keyed by the GLOBAL env id, so a batch split over several instances / GPUs
+                        gives bit-identical screens to one instance holding all of it
     precision           'fast' (fp32 data, float64 accumulators) | 'fp64' (validation kernel)
     kernel              'auto' | 'mfma' | 'valu'
     """
@@ -41,7 +46,8 @@ class BatchedAOEnv:
                  act_type="num_actuators", act_dim=64, obs_dim=2, rew_type="strehl_ratio", rew_threshold=None,
                  timesteps_per_episode=20, flat_mirror_start_per_episode=True, SH_operation=False, *,
                  num_pupil_pixels=240, seed=None, screen_source="device", screen_oversampling=16, screens=None,
-                 precision="fast", kernel="auto", pixel_chunks=0, rng=None, verbose=True, params=None):
+                 precision="fast", kernel="auto", pixel_chunks=0, rng=None, verbose=True, params=None,
+                 global_env_offset=0, total_envs=None):
         import torch
 
         self._torch = torch
@@ -58,6 +64,10 @@ class BatchedAOEnv:
             raise ValueError("atm_type must be 'quasi_static', 'semi_dynamic' or 'dynamic'")
 
         self.num_envs = int(num_envs)
+        self.global_env_offset = int(global_env_offset)
+        self.total_envs = int(total_envs) if total_envs is not None else self.global_env_offset + self.num_envs
+        if self.global_env_offset < 0 or self.global_env_offset + self.num_envs > self.total_envs:
+            raise ValueError("global_env_offset / total_envs: this instance's envs must lie inside range(total_envs)")
         self.atm_type = atm_type
         self.rew_type = rew_type
         self.act_type = act_type
@@ -110,6 +120,7 @@ class BatchedAOEnv:
         cfg.kernel = _lib.AOG_KERNEL[kernel]
         cfg.pixel_chunks = int(pixel_chunks)
         cfg.atm_dynamic = int(atm_type == "dynamic")
+        cfg.env_id_base = self.global_env_offset
         cfg.wavelength_wfs = self.params.wavelength_wfs
         cfg.wavelength_sci = self.params.wavelength_sci
         cfg.surface_rms_target = self.params.action_rms_fraction * self.params.wavelength_sci
@@ -147,20 +158,26 @@ class BatchedAOEnv:
         N = self.num_pupil_pixels
         theta = np.zeros(self.num_envs)
         layer = None
+        # GLOBAL env 0's draws define the stencils whatever slice of the batch this instance holds.
         if self._host_rng:
+            if self.atm_type == "dynamic" and self.global_env_offset > 0 and self._rng is None and self.seed is not None:
+                r0 = np.random.RandomState(self.seed)      # global env 0's stream, replayed: rand() then the two stencil draws
+                r0.rand()
+                layer = build_layer_tables(N, self.params.pupil_pixel, self.params.outer_scale, r0)
             for e in range(self.num_envs):
                 r = self._env_rng(e)
                 theta[e] = r.rand() * 2 * np.pi
-                if e == 0 and self.atm_type == "dynamic":
+                if e == 0 and self.atm_type == "dynamic" and layer is None:
                     layer = build_layer_tables(N, self.params.pupil_pixel, self.params.outer_scale, r)
                 else:
                     r.geometric(0.5, N)
                     r.geometric(0.5, N)
         else:
             trng = np.random.RandomState(1234 if seed is None else int(seed))
-            theta = trng.rand(self.num_envs) * 2 * np.pi
+            theta = (trng.rand(self.total_envs) * 2 * np.pi)[self.global_env_offset:self.global_env_offset + self.num_envs]
             if self.atm_type == "dynamic":
                 layer = build_layer_tables(N, self.params.pupil_pixel, self.params.outer_scale, trng)
+        self.wind_direction = np.array(theta, dtype=np.float64)
         self.velocity_vectors = float(self.velocity) * np.stack([np.cos(theta), np.sin(theta)], axis=1)  # [B, 2] m/s
         if self.atm_type == "dynamic":
             self._upload_layer(layer)
@@ -183,7 +200,7 @@ class BatchedAOEnv:
         if not hasattr(self, "_rngs"):
             self._rngs = {}
         if e not in self._rngs:
-            self._rngs[e] = np.random.RandomState(self.seed + e)
+            self._rngs[e] = np.random.RandomState(self.seed + self.global_env_offset + e)   # seed + GLOBAL env id
         return self._rngs[e]
 
     def _generate_screens(self, first_call=False, mask=None):
@@ -209,7 +226,9 @@ class BatchedAOEnv:
         else:
             if not hasattr(self, "_gen"):
                 self._gen = torch.Generator(device=self.device)
-                self._gen.manual_seed(1234 if self.seed is None else int(self.seed))
+                # (one torch stream per instance, offset by the instance's first global env id: distinct atmospheres on every rank,
+                # but — unlike 'device' and 'numpy' — not invariant to how the batch is split)
+                self._gen.manual_seed((1234 if self.seed is None else int(self.seed)) + self.global_env_offset)
             psi = screens_torch(self.num_envs, p.num_pupil_pixels, p.pupil_pixel, self.Cn_squared, p.outer_scale,
                                 self.device, self._gen, self.screen_oversampling)
             if mask is None:

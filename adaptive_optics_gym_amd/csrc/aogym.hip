@@ -243,6 +243,7 @@ int evolve_layer(aog_env* e, hipStream_t s) {
   p.pitch = e->pitch;
   p.sqrt_cn2 = e->sqrt_cn2;
   p.seed = e->rng_seed;
+  p.env_base = e->cfg.env_id_base;
   // the lock-step round kernel (k_extrude_round) is correct but not yet faster than the per-group kernel: opt-in
   const bool use_rounds = e->rounds_ok && e->B >= 64 && getenv("AOG_EXTRUDE_ROUNDS") != nullptr;
   if (use_rounds) {
@@ -352,6 +353,7 @@ int aog_create(const aog_config* cfg, int device, aog_env** out) {
   if (cfg->obs_dim * cfg->obs_dim > 64) return fail(AOG_ERR_UNSUPPORTED, "aog_create: obs_dim > 8 not built");
   if (cfg->n_modes > 256) return fail(AOG_ERR_UNSUPPORTED, "aog_create: act_dim > 256 not built");
   if (cfg->n_wfs_tables + cfg->n_sci_tables > 80) return fail(AOG_ERR_UNSUPPORTED, "aog_create: > 80 tables");
+  if (cfg->env_id_base < 0) return fail(AOG_ERR_INVALID, "aog_create: env_id_base must be >= 0");
   int ndev = 0;
   HIP_TRY(hipGetDeviceCount(&ndev));
   if (device < 0 || device >= ndev) return fail(AOG_ERR_HIP, "aog_create: device %d not present (%d HIP devices)", device, ndev);
@@ -434,6 +436,7 @@ int aog_create(const aog_config* cfg, int device, aog_env** out) {
   TRY_ALLOC(dev_alloc(e, &e->act_rev, (size_t)e->A_pad * e->Bp));
   TRY_ALLOC(dev_alloc(e, &e->act16, (size_t)e->n_etiles * e->A_pad * 32 * 2));
   TRY_ALLOC(dev_alloc(e, &e->t_render, e->B));
+  TRY_ALLOC(dev_alloc(e, &e->screen_gen, e->B));
   TRY_ALLOC(dev_alloc(e, &e->dev_status, 16));
   TRY_ALLOC(dev_alloc(e, &e->partials, e->partial_elems));
   TRY_ALLOC(dev_alloc(e, &e->slab_reduced, (size_t)2 * 64 * e->Bp));   // [NS <= 58][Bp] float64 (k_reduce_slabs)
@@ -776,14 +779,14 @@ int aog_generate_screens(aog_env* e, int first, int count, int oversampling, dou
     const double u0 = 2.0 * M_PI / outer_scale;
     const double r0 = std::pow(0.423 * 4.0 * M_PI * M_PI, -3.0 / 5.0);
     const double amp_scale = std::sqrt(0.0229 * std::pow(r0, -5.0 / 3.0)) * std::pow(2.0 * M_PI, 11.0 / 6.0) * (2.0 * M_PI) / du;
-    e->screen_generation += 1;
     aog::ScreenSynthArgs a{};
     a.T = reinterpret_cast<float2*>(e->syn_T);
     a.out = e->syn_out;
     a.N = N;
     a.q = oversampling;
     a.seed = e->rng_seed;
-    a.generation = e->screen_generation;
+    a.gen = e->screen_gen;
+    a.env_base = e->cfg.env_id_base;
     a.du = (float)du;
     a.u0sq = (float)(u0 * u0);
     a.amp_scale = (float)amp_scale;
@@ -803,13 +806,15 @@ int aog_generate_screens(aog_env* e, int first, int count, int oversampling, dou
     const int per_launch = (count + n_launch - 1) / n_launch;   // even shares (no short tail launch)
     for (int done = 0; done < count; done += per_launch) {
       const int nb = std::min(per_launch, count - done);
-      a.first_env = first + done;
+      a.first_local = first + done;
       hipLaunchKernelGGL(rows, dim3((lines + 3) / 4, nb), dim3(256), lds, s, a);
       hipLaunchKernelGGL(cols, dim3((N + aog::kColsWaves - 1) / aog::kColsWaves, nb), dim3(64 * aog::kColsWaves), lds_cols, s, a);
       HIP_TRY(hipGetLastError());
       int rc = set_screens<float>(e, e->syn_out, first + done, nb, s);
       if (rc != AOG_OK) return rc;
     }
+    hipLaunchKernelGGL(aog::k_bump_generation, dim3((count + 255) / 256), dim3(256), 0, s, e->screen_gen + first, count);
+    HIP_TRY(hipGetLastError());
     return AOG_OK;
   }
   if (e->fft_m != m) {
@@ -839,12 +844,11 @@ int aog_generate_screens(aog_env* e, int first, int count, int oversampling, dou
   // a = sqrt(0.0229 r0^(-5/3)) (2 pi)^(11/6) (f^2 + u0^2)^(-11/12) (2 pi) / du
   const double amp_scale = std::sqrt(0.0229 * std::pow(r0, -5.0 / 3.0)) * std::pow(2.0 * M_PI, 11.0 / 6.0) * (2.0 * M_PI) / du;
   const float crop_scale = (float)(std::sqrt(cn_squared) / ((double)m * m * pixel_pitch * pixel_pitch));
-  e->screen_generation += 1;
   for (int done = 0; done < count; done += e->fft_batch) {
     const int nb = std::min(e->fft_batch, count - done);
     const size_t pairs = (size_t)m * m / 2;
     hipLaunchKernelGGL(aog::k_spectrum_fill, dim3((unsigned)((pairs + 255) / 256), nb), dim3(256), 0, s, reinterpret_cast<float2*>(e->fft_work), m,
-                       first + done, e->rng_seed, e->screen_generation, du, u0 * u0, amp_scale);
+                       first + done, e->cfg.env_id_base, e->rng_seed, e->screen_gen, du, u0 * u0, amp_scale);
     HIP_TRY(hipGetLastError());
     // the plan is batched for fft_batch transforms; surplus slots of a short last chunk hold stale (finite) data and are ignored
     if (hipfftExecC2C(plan, reinterpret_cast<hipfftComplex*>(e->fft_work), reinterpret_cast<hipfftComplex*>(e->fft_work), HIPFFT_BACKWARD) !=
@@ -856,6 +860,8 @@ int aog_generate_screens(aog_env* e, int first, int count, int oversampling, dou
     int rc = set_screens<float>(e, e->fft_crop, first + done, nb, s);
     if (rc != AOG_OK) return rc;
   }
+  hipLaunchKernelGGL(aog::k_bump_generation, dim3((count + 255) / 256), dim3(256), 0, s, e->screen_gen + first, count);
+  HIP_TRY(hipGetLastError());
   return AOG_OK;
 }
 
@@ -949,7 +955,8 @@ int aog_sh_update(aog_env* e, const double* noisy_image_dev, double* action_dev,
   const double* img = noisy_image_dev;
   if (!img) {
     e->sh_calls += 1;
-    hipLaunchKernelGGL(aog::k_sh_noise, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, e->sh_image, e->sh_noisy, n, e->rng_seed, e->sh_calls);
+    hipLaunchKernelGGL(aog::k_sh_noise, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, e->sh_image, e->sh_noisy, n,
+                       (size_t)e->cfg.env_id_base * N * N, e->rng_seed, e->sh_calls);
     img = e->sh_noisy;
   }
   aog::ShEstimateArgs p{};
@@ -982,6 +989,7 @@ std::vector<StatePart> state_parts(const aog_env* e) {
   auto add = [&](void* p, size_t b) { if (p && b) v.push_back({p, b}); };
   add(e->act_dm, sizeof(double) * e->B * e->A);
   add(e->t_render, sizeof(int32_t) * e->B);
+  add(e->screen_gen, sizeof(uint32_t) * e->B);
   if (e->cfg.precision == AOG_PRECISION_FAST) {
     add(e->psi_tile, sizeof(float) * (size_t)e->n_etiles * e->n_ptiles * 1024);
     add(e->psi_rev, sizeof(float) * (size_t)e->n_quads * e->Bp * 4);
@@ -1004,7 +1012,7 @@ namespace {
 struct StateTail {  // host-side counters that steer the device RNG streams; stored in the last 256 bytes of the blob
   int64_t timestep;
   uint64_t rng_seed;
-  uint32_t sh_calls, screen_generation;
+  uint32_t sh_calls, reserved;
 };
 }  // namespace
 
@@ -1023,7 +1031,7 @@ int aog_get_state(aog_env* e, void* blob_dev, int64_t* timestep_out, void* strea
     HIP_TRY(hipMemcpyAsync(static_cast<char*>(blob_dev) + off, p.ptr, p.bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
     off += (p.bytes + 255) / 256 * 256;
   }
-  StateTail tail{e->timestep, e->rng_seed, e->sh_calls, e->screen_generation};
+  StateTail tail{e->timestep, e->rng_seed, e->sh_calls, 0u};
   HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
   HIP_TRY(hipMemcpy(static_cast<char*>(blob_dev) + off, &tail, sizeof tail, hipMemcpyHostToDevice));
   if (timestep_out) *timestep_out = e->timestep;
@@ -1046,7 +1054,6 @@ int aog_set_state(aog_env* e, const void* blob_dev, int64_t timestep, void* stre
   e->timestep = timestep;
   e->rng_seed = tail.rng_seed;
   e->sh_calls = tail.sh_calls;
-  e->screen_generation = tail.screen_generation;
   // derived operand layouts follow the restored actuators
   const int n = e->B * e->A_pad;
   hipLaunchKernelGGL(aog::k_load_actuators, dim3((n + 255) / 256), dim3(256), 0, s, e->act_dm, e->act_rev, e->act16, e->B, e->A, e->A_pad, e->Bp,
@@ -1210,6 +1217,7 @@ int aog_actor_act(const aog_actor* n, int device, const void* obs_dev, int obs_i
   a.seed = n->seed;
   a.call_lo = (uint32_t)n->call_index;
   a.call_hi = (uint32_t)(n->call_index >> 32);
+  a.env_base = n->env_id_base;
   const size_t lds = ((size_t)2 * a.kpad * 16 + 16 + (size_t)aog::kActorWFloats) * sizeof(float);
   if (lds > 64 * 1024) {
     // the attribute is per device: remember the largest request made on each (one process normally drives one GPU)

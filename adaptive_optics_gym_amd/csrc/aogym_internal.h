@@ -70,7 +70,7 @@ struct aog_env {
   float* syn_out = nullptr;      // [syn_batch][N][N]
   int syn_batch = 0, syn_m = 0;
   bool syn_attr_set = false;
-  uint32_t screen_generation = 0;
+  uint32_t* screen_gen = nullptr;   // [B] screens synthesised so far per env (Philox stream position of k_screen_rows / k_spectrum_fill)
   // focal-image export (optional)
   int n_focal = 0;
   double* focal_m1 = nullptr;    // [n_focal][N] complex

@@ -1481,6 +1481,7 @@ struct ExtrudeArgs {
   int N, nz_v, nz_h, max_ext;
   double t_prev, t_new, pitch, sqrt_cn2;
   unsigned long long seed;
+  int env_base;              // global id of env 0 of this handle: the Philox streams are keyed by env_base + env
 };
 
 __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
@@ -1578,7 +1579,7 @@ __global__ __launch_bounds__(512) void k_extrude(ExtrudeArgs p, int B) {
       const uint32_t ext = p.ext_counter[env] + (uint32_t)r;
       for (int j = threadIdx.x; j < N; j += blockDim.x)
         nb[(size_t)g * N + j] = (p.noise && r < p.max_ext) ? p.noise[((size_t)env * p.max_ext + r) * N + j]
-                                                           : philox_normal(p.seed, (uint32_t)env, ext, (uint32_t)j);
+                                                           : philox_normal(p.seed, (uint32_t)(p.env_base + env), ext, (uint32_t)j);
     }
     __syncthreads();
     // thread (row i, half kh): rows i = tid % N (+ strides), kh = tid / N in {0, 1} sums one half of the stencil / noise
@@ -1736,7 +1737,7 @@ __global__ __launch_bounds__(512) void k_extrude16(ExtrudeArgs p, int B) {
       if (!cls(g)) continue;
       const int env = env0 + g;
       nb[(size_t)g * ns + j] = (p.noise && r < p.max_ext) ? p.noise[((size_t)env * p.max_ext + r) * N + j]
-                                                          : philox_normal(p.seed, (uint32_t)env, p.ext_counter[env] + (uint32_t)r, (uint32_t)j);
+                                                          : philox_normal(p.seed, (uint32_t)(p.env_base + env), p.ext_counter[env] + (uint32_t)r, (uint32_t)j);
     }
     __syncthreads();
     const int my_cls = cls(li);     // class of the env this lane feeds as the B operand / owns as the D column
@@ -1924,7 +1925,7 @@ __global__ __launch_bounds__(256 * KS) void k_extrude16_split(ExtrudeArgs p, int
         if (!cls(g)) continue;
         const int env = s_env[g];
         double v[4];
-        philox_normal4(p.seed, (uint32_t)env, p.ext_counter[env] + (uint32_t)r, (uint32_t)j4, v);
+        philox_normal4(p.seed, (uint32_t)(p.env_base + env), p.ext_counter[env] + (uint32_t)r, (uint32_t)j4, v);
 #pragma unroll
         for (int u = 0; u < 4; ++u)
           if (4 * j4 + u < N) nb[(size_t)g * ns + 4 * j4 + u] = v[u];
@@ -2167,7 +2168,7 @@ __global__ __launch_bounds__(256) void k_extrude_round(ExtrudeRoundArgs q) {
             } else {
               const int e = s_ext[ge];
               v = (p.noise && e < p.max_ext) ? p.noise[((size_t)env * p.max_ext + e) * N + k]
-                                             : philox_normal(p.seed, (uint32_t)env, p.ext_counter[env] + (uint32_t)e, (uint32_t)k);
+                                             : philox_normal(p.seed, (uint32_t)(p.env_base + env), p.ext_counter[env] + (uint32_t)e, (uint32_t)k);
             }
           }
           Zs[gk + u][ge] = v;
@@ -2382,8 +2383,8 @@ __global__ void k_cgemm_small(const double2* __restrict__ a, const double2* __re
 //   then an un-normalised inverse FFT (hipFFT) and k_screen_crop takes Re of the centred N x N crop / (M delta^2) * sqrt(Cn^2).
 // ------------------------------------------------------------------------------------------------
 #ifdef AOG_MAIN_TU
-__global__ void k_spectrum_fill(float2* __restrict__ spec, int m, int first_env, unsigned long long seed, uint32_t generation, double du,
-                                double u0sq, double amp_scale) {
+__global__ void k_spectrum_fill(float2* __restrict__ spec, int m, int first_local, int env_base, unsigned long long seed,
+                                const uint32_t* __restrict__ gen, double du, double u0sq, double amp_scale) {
   // one thread = two adjacent complex samples (one Philox call = 4 words = 2 Box-Muller pairs)
   const size_t pair = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t per_env = (size_t)m * m / 2;
@@ -2396,7 +2397,9 @@ __global__ void k_spectrum_fill(float2* __restrict__ spec, int m, int first_env,
     return;
   }
   const float line_scale = (v_line == 0 || 2 * v_line == m) ? 1.f : 1.41421356237f;
-  uint32_t c[4] = {(uint32_t)pair, (uint32_t)(pair >> 32) ^ (generation * 0x9E3779B9u), (uint32_t)(first_env + b), 0x5C4EE7u};
+  // stream = (seed, GLOBAL env id, how many screens this env has drawn so far): independent of batch split and reset masks
+  const uint32_t generation = gen[first_local + b] + 1u;
+  uint32_t c[4] = {(uint32_t)pair, (uint32_t)(pair >> 32) ^ (generation * 0x9E3779B9u), (uint32_t)(env_base + first_local + b), 0x5C4EE7u};
   uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
@@ -2421,6 +2424,12 @@ __global__ void k_spectrum_fill(float2* __restrict__ spec, int m, int first_env,
     out[h] = make_float2(r * cs, r * sn);
   }
   reinterpret_cast<float4*>(spec + (size_t)b * m * m)[pair] = make_float4(out[0].x, out[0].y, out[1].x, out[1].y);
+}
+
+// after a synthesis launch: the envs it served have drawn one more screen
+__global__ void k_bump_generation(uint32_t* __restrict__ gen, int count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) gen[i] += 1u;
 }
 
 __global__ void k_screen_crop(const float2* __restrict__ field, float* __restrict__ out, int m, int N, float scale) {
@@ -2448,6 +2457,7 @@ struct ActorArgs {
   float p_drop, keep_scale, std, logp_const;
   unsigned long long seed;
   uint32_t call_lo, call_hi;
+  int env_base;   // global id of obs row 0
 };
 #ifdef AOG_MAIN_TU
 __device__ __forceinline__ void actor_philox(uint32_t (&c)[4], unsigned long long seed) {
@@ -2513,7 +2523,7 @@ __device__ __forceinline__ void actor_layer(const ActorArgs& p, const float* __r
       float bv[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) bv[r] = bias[min(m0 + r, M - 1)];
-      uint32_t c[4] = {(uint32_t)m0 | ((uint32_t)LAYER << 24), (uint32_t)env, p.call_lo, p.call_hi ^ 0xAC70u};
+      uint32_t c[4] = {(uint32_t)m0 | ((uint32_t)LAYER << 24), (uint32_t)(p.env_base + env), p.call_lo, p.call_hi ^ 0xAC70u};
       actor_philox(c, p.seed);
       // Eight k-steps at a time: their 16 LDS reads are in flight together and the matrix ops follow back to back.  Whole groups
       // below K need no clamps or masks (rows past the chunk are clamped to a valid row and dropped at the output), so their reads
@@ -2710,9 +2720,9 @@ __device__ __forceinline__ void dft_lanes(cf32 (&z)[64]) {   // inverse DFT of z
 struct ScreenSynthArgs {
   float2* T;                 // [env in batch][m/2 + 1][N] complex64
   float* out;                // [env in batch][N][N]
-  int N, q, first_env;
+  int N, q, first_local, env_base;   // envs [first_local, ...) of the handle; global id = env_base + local index
   unsigned long long seed;
-  uint32_t generation;
+  const uint32_t* gen;               // [B] screens drawn so far per env (see k_spectrum_fill)
   float du, u0sq, amp_scale, crop_scale;
 };
 
@@ -2848,6 +2858,7 @@ __global__ __launch_bounds__(256, 2) void k_screen_rows(ScreenSynthArgs p) {
   const float fv = p.du * (float)v;
   // (-1)^a, a = lane + LW r (LW is even), times the half-plane weight of this line
   const float sign = ((lane & 1) ? -1.f : 1.f) * ((v == 0 || 2 * v == m) ? 1.f : 1.41421356237f);
+  const uint32_t generation = p.gen[p.first_local + b] + 1u;
   cf32 pending[R];   // second sample of the Philox pair drawn for (a, b even): consumed as (a, b + 1)
   auto load = [&](int bg, int r, auto oddc) -> cf32 {
     // samples come in Philox pairs (u even, u + 1): b even draws, b odd uses the second half
@@ -2856,7 +2867,7 @@ __global__ __launch_bounds__(256, 2) void k_screen_rows(ScreenSynthArgs p) {
     if constexpr (decltype(oddc)::v == 1) return pending[r];   // (only reached with q > 1: q = 1 has the single b = 0)
     const size_t idx = (size_t)v * m + (u & ~1);
     const size_t pair = idx >> 1;
-    uint32_t c[4] = {(uint32_t)pair, (uint32_t)(pair >> 32) ^ (p.generation * 0x9E3779B9u), (uint32_t)(p.first_env + b), 0x5C4EE7u};
+    uint32_t c[4] = {(uint32_t)pair, (uint32_t)(pair >> 32) ^ (generation * 0x9E3779B9u), (uint32_t)(p.env_base + p.first_local + b), 0x5C4EE7u};
     uint32_t k0 = (uint32_t)p.seed, k1 = (uint32_t)(p.seed >> 32);
 #pragma unroll
     for (int rr = 0; rr < 10; ++rr) {
@@ -2968,10 +2979,12 @@ __global__ void k_sh_intensity(const double2* __restrict__ f, double* __restrict
 
 // hcipy.util.large_poisson with the handle's Philox stream: normal approximation above 1e6 (like hcipy), and below it exact
 // inversion for lambda < 30, rounded normal approximation otherwise (indistinguishable at those counts)
-__global__ void k_sh_noise(const double* __restrict__ image, double* __restrict__ noisy, size_t n, unsigned long long seed, uint32_t call) {
-  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= n) return;
-  const double lam = image[idx];
+__global__ void k_sh_noise(const double* __restrict__ image, double* __restrict__ noisy, size_t n, size_t idx_base, unsigned long long seed,
+                           uint32_t call) {
+  const size_t il = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (il >= n) return;
+  const double lam = image[il];
+  const size_t idx = idx_base + il;   // pixel index in the GLOBAL batch (idx_base = env_id_base * N * N): the stream does not depend on the batch split
   double out;
   if (lam < 30.0) {
     uint32_t c[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), call, 0x50155u};
@@ -2986,7 +2999,7 @@ __global__ void k_sh_noise(const double* __restrict__ image, double* __restrict_
     const double g = philox_normal(seed ^ 0xA5A5A5A5ull, (uint32_t)(idx >> 32) ^ call, (uint32_t)idx, 0u);
     out = fmax(0.0, rint(lam + g * sqrt(lam)));
   }
-  noisy[idx] = out;
+  noisy[il] = out;
 }
 
 struct ShEstimateArgs {

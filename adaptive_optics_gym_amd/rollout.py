@@ -65,9 +65,12 @@ class DeviceActor:
     """The policy query (``Actor.forward`` + ``get_action``, network.py:48-69) as ONE library launch (``aog_actor_act``): the
     weights of a torch module built by ``make_actor`` (or any module exposing ``hidden`` = three ``nn.Linear`` and ``out``)
     are read in place on every call, so a learner may keep updating them.  Dropout masks / Gaussian noise come from the
-    library's Philox streams (seed, call counter), not from torch's generator."""
+    library's Philox streams keyed by (seed, call counter, GLOBAL env id, layer, unit), not from torch's generator.  Keep ONE
+    instance alive for the whole training run: its call counter is what makes every query draw fresh masks and noise
+    (``rollout`` caches it on the actor module for that reason).  ``env_id_base`` = global id of obs row 0 (multi-GPU: the
+    env's ``global_env_offset``), so ranks explore with independent noise and a split batch reproduces the unsplit one."""
 
-    def __init__(self, actor, seed: int = 0, dropout_p: float = 0.5):
+    def __init__(self, actor, seed: int = 0, dropout_p: float = 0.5, env_id_base: int = 0):
         import ctypes as C
 
         from . import _lib
@@ -77,6 +80,7 @@ class DeviceActor:
         self.actor = actor
         self.seed = int(seed)
         self.dropout_p = float(dropout_p)
+        self.env_id_base = int(env_id_base)
         self.calls = 0
 
     def __call__(self, obs, cov_var: float = 0.5, out=None):
@@ -100,7 +104,7 @@ class DeviceActor:
             mean = torch.empty((B, A), dtype=torch.float32, device=obs.device)
         else:
             action, log_prob, mean = out
-        net = _lib.AogActor(B, S, H, A, *[C.c_void_p(t.data_ptr()) for layer in layers for t in (layer.weight, layer.bias)],
+        net = _lib.AogActor(B, S, H, A, self.env_id_base, 0, *[C.c_void_p(t.data_ptr()) for layer in layers for t in (layer.weight, layer.bias)],
                             self.dropout_p, float(cov_var), self.seed, self.calls)
         self.calls += 1
         _lib.check(self.lib.aog_actor_act(C.byref(net), obs.device.index or 0, C.c_void_p(obs.data_ptr()), int(obs.dtype == torch.float16),
@@ -109,11 +113,15 @@ class DeviceActor:
         return action, log_prob, mean
 
 
-def rollout(env, actor, episodes: int = 1, cov_var: float = 0.5, gatherer=None, generator=None, actor_impl: str = "auto", seed: int = 0):
+def rollout(env, actor, episodes: int = 1, cov_var: float = 0.5, gatherer=None, generator=None, actor_impl: str = "auto", seed: int = 0,
+            dev_actor=None):
     """Collect ``episodes`` lock-step episodes from ``env`` (a ``BatchedAOEnv``).
 
     ``actor_impl``: "hip" = the fused policy-query kernel (``DeviceActor``), "torch" = the module's own forward +
-    ``sample_action``, "auto" = "hip" for CUDA modules with the ``make_actor`` structure.  Returns a dict of device tensors
+    ``sample_action``, "auto" = "hip" for CUDA modules with the ``make_actor`` structure.  The ``DeviceActor`` (and with it the
+    call counter of its random streams) persists across calls: pass one in as ``dev_actor``, or let this function cache it on
+    the actor module — a training loop that calls ``rollout`` once per iteration (algorithm.py:156) then explores with fresh
+    dropout masks and noise in every iteration, like the reference's torch generator does.  Returns a dict of device tensors
     shaped ``[T*E, B, ...]`` (obs, act, log_prob, rew, next_obs, done), ``ep_returns`` ``[E, B_global]`` (gathered over ranks
     when ``gatherer`` is distributed) and ``avg_ep_rew`` (the reference's logged scalar)."""
     import torch
@@ -127,7 +135,17 @@ def rollout(env, actor, episodes: int = 1, cov_var: float = 0.5, gatherer=None, 
     if actor_impl == "auto":
         structured = hasattr(actor, "hidden") and hasattr(actor, "out") and len(list(actor.hidden)) == 3
         actor_impl = "hip" if structured and next(actor.parameters()).is_cuda else "torch"
-    dev_actor = DeviceActor(actor, seed=seed) if actor_impl == "hip" else None
+    if actor_impl != "hip":
+        dev_actor = None
+    elif dev_actor is None:
+        base = int(getattr(env, "global_env_offset", 0))
+        dev_actor = getattr(actor, "_aog_device_actor", None)
+        if dev_actor is None or dev_actor.seed != int(seed) or dev_actor.env_id_base != base or dev_actor.actor is not actor:
+            dev_actor = DeviceActor(actor, seed=seed, env_id_base=base)
+            try:
+                object.__setattr__(actor, "_aog_device_actor", dev_actor)   # (plain attribute, not a registered submodule)
+            except Exception:
+                pass
     import inspect
 
     step_takes_out = "out" in inspect.signature(env.step).parameters

@@ -9,7 +9,8 @@ from __future__ import annotations
 
 
 def shard_range(total: int, rank: int, world: int):
-    """Contiguous block of ``range(total)`` owned by ``rank`` (first ``total % world`` ranks get one extra)."""
+    """Contiguous block of ``range(total)`` owned by ``rank`` (first ``total % world`` ranks get one extra).  Pass the result to
+    ``BatchedAOEnv(..., global_env_offset=start, total_envs=total)`` and ``EpisodeReturnGatherer(..., total_envs=total)``."""
     if not (0 <= rank < world):
         raise ValueError(f"rank {rank} outside world {world}")
     base, extra = divmod(total, world)
@@ -26,7 +27,10 @@ class EpisodeReturnGatherer:
     """Accumulates per-env rewards of the local shard and all-gathers the episode returns when the episode ends
     (the logged quantity of the reference's rollout is built from them: algorithm.py:509-510)."""
 
-    def __init__(self, local_envs: int, device, distributed: bool, group=None):
+    def __init__(self, local_envs: int, device, distributed: bool, group=None, total_envs=None):
+        """``total_envs`` (optional): size of the global batch when it does not divide evenly over the ranks
+        (``shard_range`` shards); the all-gather then runs on shards padded to ``ceil(total / world)`` and the result is
+        trimmed back to ``total`` entries in global-env order."""
         import torch
 
         self._torch = torch
@@ -41,7 +45,22 @@ class EpisodeReturnGatherer:
 
             self._dist = dist
             self.world = dist.get_world_size(group)
-            self._out = torch.empty(self.world * self.local_envs, dtype=torch.float32, device=device)
+            self.total_envs = int(total_envs) if total_envs is not None else self.world * self.local_envs
+            self.padded = -(-self.total_envs // self.world)     # ceil: every rank contributes the same number of slots
+            rank = dist.get_rank(group)
+            if self.local_envs > self.padded or shard_range(self.total_envs, rank, self.world)[1] - \
+                    shard_range(self.total_envs, rank, self.world)[0] != self.local_envs:
+                raise ValueError(f"EpisodeReturnGatherer: rank {rank} holds {self.local_envs} envs, which is not its "
+                                 f"shard_range share of {self.total_envs} envs over {self.world} ranks")
+            self._out = torch.empty(self.world * self.padded, dtype=torch.float32, device=device)
+            self._stage = dist.get_backend(group) == "gloo" and torch.device(device).type == "cuda"
+            self._send = self.returns if self.padded == self.local_envs else torch.zeros(self.padded, dtype=torch.float32, device=device)
+            # positions of the real entries inside the padded gather, in global-env order
+            keep = []
+            for r in range(self.world):
+                s_, e_ = shard_range(self.total_envs, r, self.world)
+                keep.extend(range(r * self.padded, r * self.padded + (e_ - s_)))
+            self._keep = None if len(keep) == self.world * self.padded else torch.tensor(keep, dtype=torch.long, device=device)
 
         self._attached = None
 
@@ -66,8 +85,15 @@ class EpisodeReturnGatherer:
     def finish_episode(self):
         """Returns the [world * local_envs] tensor of episode returns ordered by global env id."""
         if self.distributed:
-            self._dist.all_gather_into_tensor(self._out, self.returns, group=self.group)
-            self.last_global_returns = self._out
+            if self._send is not self.returns:
+                self._send[: self.local_envs].copy_(self.returns)
+            if self._stage:     # gloo does not all-gather device tensors: single-GPU rehearsals stage through the host
+                out = self._torch.empty(self._out.shape, dtype=self._out.dtype)
+                self._dist.all_gather_into_tensor(out, self._send.cpu(), group=self.group)
+                self._out.copy_(out)
+            else:
+                self._dist.all_gather_into_tensor(self._out, self._send, group=self.group)
+            self.last_global_returns = self._out if self._keep is None else self._out.index_select(0, self._keep)
         else:
             self.last_global_returns = self.returns.clone()
         return self.last_global_returns

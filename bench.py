@@ -1,180 +1,345 @@
 #!/usr/bin/env python3
 """Headline benchmark: batched env-steps/s of the AOEnv.step() hot path on MI355X.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config 2|3|4|5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1], per GPU): 1024 envs, quasi_static, 256x256 pupil, act_type=num_actuators
-act_dim=64, obs_dim=2, strehl_ratio reward, 30-step episodes; synthetic von Karman screens (r0 = 0.20 m at
-2.2 um, L0 = 10 m) synthesised on the device, actions ~ N(0, 0.5 I) resident in HBM.  A "step" is one
-``BatchedAOEnv.step`` of all envs; every 30 steps the episode ends: ``reset()`` and one all-gather of the
-per-env episode returns (RCCL when N > 1).  Envs are sharded across ranks with no data-path collective
-(weak scaling: per-GPU batch fixed).
+Started WITHOUT torchrun (``WORLD_SIZE`` unset) and ``--gpus N > 1`` this script spawns its N ranks itself, as child
+processes created before anything in the parent touches the GPU; started under torchrun it checks ``WORLD_SIZE == --gpus``
+and exits non-zero otherwise.  One rank per GPU, RCCL (``nccl`` backend) for the one collective.
 
-Rank 0 prints ONE JSON line (see the task contract): value = total env-steps / max-over-ranks wall time,
-plus ``roofline`` (dominant kernel, timed live with HIP events on its own stream) and ``cpu_baseline`` (the
-float64 numpy restatement of the reference's literal dataflow, timed on this box's host cores).
+Workloads (BASELINE.json ``configs``; per GPU, weak scaling — the global batch is ``N x`` the per-GPU batch):
+
+  --config 2 (default, the headline line)  configs[1]: 1024 envs, quasi_static, 256x256 pupil, num_actuators A=64, o=2,
+             strehl_ratio, 30-step episodes.  step = ``BatchedAOEnv.step``; every 30 steps ``reset()`` + all-gather of returns.
+  --config 3  configs[2]: 4096 envs, semi_dynamic (requested atm_vel=10 is coerced to 0 like the reference), r0=0.15, o=5,
+             20-step episodes; every reset regenerates all screens on the device (oversampling 16).
+  --config 4  configs[3]'s per-GPU shard: 1024 envs, dynamic v=10 m/s (random direction per env), o=2, SAC-style rollout:
+             policy query (fused actor kernel, hidden 150) + step + in-place transition writes, 30-step episodes.
+  --config 5  configs[4]: 2048 envs, 512x512 pupil, zernike A=20, o=5, smf_ssim, SH_operation=True; step = ``SH_step`` + ``step``.
+
+Synthetic inputs: von Karman screens synthesised inside the library (Philox keyed by the GLOBAL env id = rank * batch + e, seed
+1234), actions ~ N(0, 0.5 I) for the global batch from torch seed 10 (main.py:155), sliced per rank — resident in HBM before the
+timed region.  Rank 0 prints ONE JSON line: value = total env-steps / max-over-ranks wall time, ``roofline`` (the fused kernel,
+timed live with HIP events on its own stream) and ``cpu_baseline`` (the float64 numpy restatement of the reference's literal
+dataflow, timed on this box's host cores in the three modes SURVEY.md §8d prescribes).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-WORKLOAD = dict(batch_per_gpu=1024, n_pupil=256, act_dim=64, obs_dim=2, atm_type="quasi_static", atm_fried=0.20,
-                act_type="num_actuators", rew_type="strehl_ratio", timesteps_per_episode=30)
+WORKLOADS = {
+    2: dict(name="configs[1]", batch_per_gpu=1024, n_pupil=256, act_dim=64, obs_dim=2, atm_type="quasi_static", atm_vel=0, atm_fried=0.20,
+            act_type="num_actuators", rew_type="strehl_ratio", timesteps_per_episode=30, SH_operation=False, rollout=False,
+            text="batch=1024 envs/GPU, quasi_static, 256x256 pupil, act_type=num_actuators act_dim=64, obs_dim=2, strehl_ratio, "
+                 "30-step episodes with reset + all-gather of returns"),
+    3: dict(name="configs[2]", batch_per_gpu=4096, n_pupil=256, act_dim=64, obs_dim=5, atm_type="semi_dynamic", atm_vel=10, atm_fried=0.15,
+            act_type="num_actuators", rew_type="strehl_ratio", timesteps_per_episode=20, SH_operation=False, rollout=False,
+            text="batch=4096 envs/GPU, semi_dynamic (atm_vel=10 coerced to 0 like the reference) atm_fried=0.15, 256x256 pupil, 64 actuators, "
+                 "obs_dim=5, 20-step episodes; every reset regenerates all screens on the device (16x oversampled von Karman synthesis)"),
+    4: dict(name="configs[3] per-GPU shard", batch_per_gpu=1024, n_pupil=256, act_dim=64, obs_dim=2, atm_type="dynamic", atm_vel=10, atm_fried=0.15,
+            act_type="num_actuators", rew_type="strehl_ratio", timesteps_per_episode=30, SH_operation=False, rollout=True,
+            text="batch=1024 envs/GPU (8192 over 8 GPUs), dynamic atmosphere v=10 m/s random direction per env, 256x256 pupil, 64 actuators, "
+                 "obs_dim=2, SAC-style rollout (fused policy kernel, hidden 150, dropout on, N(0, 0.5 I) exploration) writing the "
+                 "transition buffers in place, 30-step episodes, all-gather of returns per episode"),
+    5: dict(name="configs[4]", batch_per_gpu=2048, n_pupil=512, act_dim=20, obs_dim=5, atm_type="quasi_static", atm_vel=0, atm_fried=0.15,
+            act_type="zernike", rew_type="smf_ssim", timesteps_per_episode=20, SH_operation=True, rollout=False,
+            text="batch=2048 envs/GPU, 512x512 pupil, act_type=zernike act_dim=20, obs_dim=5, smf_ssim, SH_operation=True: every step is "
+                 "SH_step (Shack-Hartmann sensor image, photon noise, slopes, leaky integrator on the device) + step"),
+}
 
-HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
-SPINUP_STEPS = 300         # steps (spin-up + warm-up) before the timed region: see main()
-PROFILE_EVERY = 8          # HIP events around one block of 8 launches of the fused kernel in 8 inside the timed region
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+F16_MFMA_PEAK_TFLOPS = 2516.6  # MI355X_MICROARCH.md: dense f16/bf16 matrix peak (256 CUs x 4096 flop/clk x 2.4 GHz)
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9   # wave-instructions / s: 256 CUs x 4 SIMDs x 2.4 GHz, one vector instruction per SIMD and cycle
+SPINUP_STEPS = 300           # steps (spin-up + warm-up) before the timed region: see main()
+PROFILE_EVERY = 8            # HIP events around one block of 8 launches of the fused kernel in 8 inside the timed region
 
 
 def algorithmic_per_step(n_pupil, act_dim, obs_dim, batch, n_ap):
-    """compulsory HBM bytes and flops of one env-step of the fused, collapsed dataflow."""
+    """compulsory HBM bytes and flops of one env-step of the fused, collapsed dataflow (contract figure), and
+    the bytes the aperture-packed layout really has to move (4 n_ap instead of 4 N^2 per screen; shared tables amortised)."""
     K = obs_dim ** 2 + 4
     n2 = n_pupil * n_pupil
-    bytes_ = 4 * n2 + 4 * act_dim + 4 * obs_dim ** 2 + 2 * obs_dim ** 2 + 9 + 4 * n2 * (act_dim + 2 * K) / batch
+    io = 4 * act_dim + 4 * obs_dim ** 2 + 2 * obs_dim ** 2 + 9
+    bytes_ = 4 * n2 + io + 4 * n2 * (act_dim + 2 * K) / batch
+    layout = 4 * n_ap + io + 4 * n_ap * (act_dim + 2 * K) / batch
     flops = n_ap * (2 * act_dim + 8 * (obs_dim ** 2 + 3) + 10)
-    return bytes_, flops
+    return bytes_, flops, layout
 
 
-def cpu_baseline(budget_s=12.0):
-    """Time the CPU oracle (literal HCIPy dataflow restated in numpy float64) on the same single-env shape."""
-    import numpy as np
+# ---------------------------------------------------------------------------------------------------------------------------------
+# CPU baseline (the ONLY part of this file that touches oracle/): float64 numpy restatement of the literal HCIPy dataflow
+# ---------------------------------------------------------------------------------------------------------------------------------
+_CPU_WORKER = r"""
+import os, sys, time, json
+sys.path.insert(0, {root!r})
+import numpy as np
+from scipy.ndimage import gaussian_filter
+from oracle.ao_env_oracle import AOEnvOracle
+w = {w!r}
+N = w["n_pupil"]
+rng = np.random.RandomState({seed})
+screen = gaussian_filter(rng.randn(N, N), 8.0)
+screen = screen / screen.std() * 3e-6
+env = AOEnvOracle(atm_type="quasi_static", atm_fried=w["atm_fried"], act_type=w["act_type"], act_dim=w["act_dim"], obs_dim=w["obs_dim"],
+                  rew_type=w["rew_type"], timesteps_per_episode=w["timesteps_per_episode"], num_pupil_pixels=N, screen=screen.ravel(),
+                  rng=rng, verbose=False)
+env.reset()
+a = rng.randn(w["act_dim"]).astype(np.float32)
+for _ in range(3):
+    env.step(a)
+sys.stdout.write("ready\n"); sys.stdout.flush()
+sys.stdin.readline()                      # all workers start their timed loop together
+n, t0 = 0, time.perf_counter()
+while time.perf_counter() - t0 < {budget}:
+    _, _, done, _, _ = env.step(a)
+    n += 1
+    if done:
+        env.reset()
+dt = time.perf_counter() - t0
+threads = 1
+try:
+    from threadpoolctl import threadpool_info
+    threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+except Exception:
+    pass
+print(json.dumps({{"n": n, "dt": dt, "threads": threads}}))
+"""
 
-    from oracle.ao_env_oracle import AOEnvOracle
 
-    w = WORKLOAD
-    N = w["n_pupil"]
-    rng = np.random.RandomState(0)
-    from scipy.ndimage import gaussian_filter
-
-    screen = gaussian_filter(rng.randn(N, N), 8.0)
-    screen = screen / screen.std() * 3e-6
-    env = AOEnvOracle(atm_type=w["atm_type"], atm_fried=w["atm_fried"], act_type=w["act_type"], act_dim=w["act_dim"],
-                      obs_dim=w["obs_dim"], rew_type=w["rew_type"], timesteps_per_episode=w["timesteps_per_episode"],
-                      num_pupil_pixels=N, screen=screen.ravel(), verbose=False)
-    env.reset()
-    a = rng.randn(w["act_dim"]).astype(np.float32)
-    for _ in range(3):
-        env.step(a)
-    n, t0 = 0, time.perf_counter()
-    while True:
-        _, _, done, _, _ = env.step(a)
-        n += 1
-        if done:
-            env.reset()
-        if time.perf_counter() - t0 > budget_s:
-            break
-    dt = time.perf_counter() - t0
-    threads = os.cpu_count()
+def _host_cpus():
+    """(logical cores the OS reports, cores this process may actually use: affinity mask and cgroup quota)."""
+    total = os.cpu_count() or 1
+    usable = total
     try:
-        from threadpoolctl import threadpool_info
-
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+        usable = min(usable, len(os.sched_getaffinity(0)))
     except Exception:
         pass
-    return {"value": n / dt, "unit": "env-steps/s", "cores": int(threads), "kind": "port",
-            "sample": f"{n} single-env steps (N=256, A=64, o=2, float64 numpy restatement of the literal HCIPy dataflow, "
-                      f"not HCIPy itself) in {dt:.1f} s; host has {os.cpu_count()} logical cores"}
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            usable = min(usable, max(1, int(float(q) / float(per))))
+    except Exception:
+        pass
+    # a 1-GPU box of this pool gives a job 16 host cores whatever the OS reports: never start more workers than that unless told to
+    cap = int(os.environ.get("AOG_CPU_WORKERS", "16"))
+    return total, max(1, min(usable, cap))
 
 
-def strehl_check(env, screens_dev, torch):
-    """Strehl / obs error of the device path vs the CPU oracle on the first 2 envs (same screens, same action)."""
+def _cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def _run_cpu_workers(w, procs, threads, budget):
+    """``procs`` worker processes, each stepping its own single-env oracle for ``budget`` seconds with ``threads`` BLAS threads
+    (None = library default).  Returns (aggregate env-steps/s, BLAS threads a worker really used, total steps)."""
+    env = dict(os.environ)
+    if threads is not None:
+        for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "BLIS_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
+            env[k] = str(threads)
+    env["HIP_VISIBLE_DEVICES"] = ""          # the workers are CPU-only
+    env.pop("LD_PRELOAD", None)              # (a profiler's preloaded library stays with the GPU process)
+    ws = [subprocess.Popen([sys.executable, "-c", _CPU_WORKER.format(root=ROOT, w={k: w[k] for k in (
+        "n_pupil", "atm_fried", "act_type", "act_dim", "obs_dim", "rew_type", "timesteps_per_episode")}, seed=i, budget=budget)],
+        stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, env=env) for i in range(procs)]
+    for p in ws:
+        assert p.stdout.readline().strip() == "ready"
+    for p in ws:
+        p.stdin.write("go\n")
+        p.stdin.flush()
+    res = [json.loads(p.communicate()[0].strip().splitlines()[-1]) for p in ws]
+    return sum(r["n"] / r["dt"] for r in res), max(r["threads"] for r in res), sum(r["n"] for r in res)
+
+
+def cpu_baseline(w, budget_s=8.0):
+    """(i) 1 process x 1 BLAS thread, (ii) 1 process x default threads, (iii) one single-thread process per usable
+    host core.  ``value`` is (iii), the fair "all host cores" number; the other two are in ``modes``."""
+    total, usable = _host_cpus()
+    one, _, n1 = _run_cpu_workers(w, 1, 1, budget_s)
+    dflt, dthreads, n2 = _run_cpu_workers(w, 1, None, budget_s)
+    allc, _, n3 = _run_cpu_workers(w, usable, 1, budget_s)
+    import numpy as np
+
+    return {"value": allc, "unit": "env-steps/s", "cores": int(usable), "kind": "port",
+            "modes": {"1proc_1thread": one, "1proc_default_threads": dflt, "default_threads": int(dthreads),
+                      f"{usable}procs_1thread": allc},
+            "cpu_model": _cpu_model(), "os_cpu_count": int(total), "usable_cores": int(usable), "numpy": np.__version__,
+            "sample": f"single-env steps of the float64 numpy restatement of the literal HCIPy dataflow (not HCIPy itself) at N={w['n_pupil']}, "
+                      f"A={w['act_dim']}, o={w['obs_dim']}, {w['rew_type']}: {n1} steps in {budget_s:.0f} s (1 process, 1 BLAS thread), {n2} steps in "
+                      f"{budget_s:.0f} s (1 process, {dthreads} BLAS threads), {n3} steps in {budget_s:.0f} s ({usable} processes x 1 thread = the cores "
+                      f"this job may use: min(affinity, cgroup quota, 16 per GPU of the box); the OS reports {total})"}
+
+
+def parity_check(env, w, actions, torch):
+    """Strehl / obs error of the device path vs the CPU oracle on 2 envs at full size (same screens, same action).  Quasi-static
+    handles only (the screens are read back from the handle)."""
     import numpy as np
 
     from oracle.ao_env_oracle import AOEnvOracle
 
-    w = WORKLOAD
-    a = torch.randn((env.num_envs, w["act_dim"]), device=env.device, generator=torch.Generator(env.device).manual_seed(5))
-    _, _, _, _, info = env.step(a)
-    out = {"strehl_abs_err": 0.0, "obs_rel_err": 0.0}
-    for b in range(2):
-        ref = AOEnvOracle(atm_type=w["atm_type"], atm_fried=w["atm_fried"], act_type=w["act_type"], act_dim=w["act_dim"],
-                          obs_dim=w["obs_dim"], rew_type=w["rew_type"], timesteps_per_episode=w["timesteps_per_episode"],
-                          num_pupil_pixels=w["n_pupil"], screen=screens_dev[b].double().cpu().numpy().ravel(), verbose=False)
+    env.reset()
+    _, _, _, _, info = env.step(actions)
+    out = {"strehl_abs_err": 0.0, "obs_rel_err": 0.0, "envs": 2}
+    for b in (0, env.num_envs - 1):
+        screen = env.phase_screen(b).double().cpu().numpy().ravel() * (w_lambda(env) / (2 * np.pi))   # radians at lambda_wfs -> phase * lambda
+        ref = AOEnvOracle(atm_type="quasi_static", atm_fried=w["atm_fried"], act_type=w["act_type"], act_dim=w["act_dim"], obs_dim=w["obs_dim"],
+                          rew_type=w["rew_type"], timesteps_per_episode=w["timesteps_per_episode"], num_pupil_pixels=w["n_pupil"],
+                          screen=screen, verbose=False)
         ref.reset()
-        ref.step(a[b].cpu().numpy())
-        out["strehl_abs_err"] = max(out["strehl_abs_err"], abs(float(info["strehl"][b]) - ref.last_strehl))
-        out["obs_rel_err"] = max(out["obs_rel_err"],
-                                 float(np.max(np.abs(info["obs_raw"][b].cpu().numpy() / ref.last_obs_raw - 1))))
+        ref.step(actions[b].cpu().numpy())
+        if w["rew_type"] == "strehl_ratio":
+            out["strehl_abs_err"] = max(out["strehl_abs_err"], abs(float(info["strehl"][b]) - ref.last_strehl))
+        o, r = info["obs_raw"][b].double().cpu().numpy(), ref.last_obs_raw
+        out["obs_rel_err"] = max(out["obs_rel_err"], float(np.max(np.abs(o - r) / np.maximum(np.abs(r), 1e-3 * r.max()))))
     return out
+
+
+def w_lambda(env):
+    return env.wavelength_wfs
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+def spawn_ranks(args, argv):
+    """--gpus N without a launcher: start the N ranks as children (this process has not touched the GPU and never will)."""
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    if rc:
+        print(f"bench.py: a rank exited with status {rc}", file=sys.stderr)
+    return rc
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # defaults: 50 episodes timed after 10 of warm-up (~0.15 s of device time).  A process's first few hundred steps run ~5 % slower
-    # than steady state (tools/fixed_overhead.py; independent of event timing and of what the device did before), so short runs
-    # under-report: 300 steps after 30 give ~13.0 M env-steps/s, 1500 after 300 ~13.7 M
-    ap.add_argument("--steps", type=int, default=1500)
-    ap.add_argument("--warmup", type=int, default=300)
+    # defaults: 50 episodes timed after 10 of warm-up (~0.15 s of device time at config 2).  A process's first few hundred steps run
+    # ~5 % slower than steady state (device clocks), so short runs under-report: see SPINUP_STEPS
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(WORKLOADS))
     ap.add_argument("--kernel", default="auto", choices=["auto", "mfma", "valu"])
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU env batch (tests / rehearsals only; the JSON line reports it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-spinup", action="store_true")
     args = ap.parse_args()
+    w = dict(WORKLOADS[args.config])
+    if args.batch:
+        w["batch_per_gpu"] = args.batch
+    if args.steps is None:
+        args.steps = {2: 1500, 3: 200, 4: 300, 5: 40}[args.config]
+    if args.warmup is None:
+        args.warmup = {2: 300, 3: 40, 4: 60, 5: 10}[args.config]
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args, sys.argv[1:]))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} != WORLD_SIZE {world} (launch one rank per GPU, or drop the launcher and let "
+                         f"bench.py spawn them)")
 
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     distributed = world > 1 or os.environ.get("AOG_FORCE_DIST") == "1"   # the latter: rehearse the RCCL path with one rank
-    if args.gpus != world and distributed:
-        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    share = os.environ.get("AOG_BENCH_SHARE_GPU") == "1"                 # single-GPU rehearsal of --gpus N: every rank on card 0, gloo
+    if not share and world > 1 and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} HIP device(s) are visible")
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", device_id=device)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
 
     from adaptive_optics_gym_amd import BatchedAOEnv
-    from adaptive_optics_gym_amd.atmosphere_host import cn_squared_from_fried_parameter, screens_torch
-    from adaptive_optics_gym_amd.params import OpticalParams
     from adaptive_optics_gym_amd.sharding import EpisodeReturnGatherer
 
-    w = WORKLOAD
     B = w["batch_per_gpu"]
-    p = OpticalParams(num_pupil_pixels=w["n_pupil"])
-    # The handle first (seconds of host-side table building with the GPU idle), the synthetic input screens after it: the device then
-    # goes from half a second of transform work straight into the warm-up instead of waking from idle inside the timed region
-    # (the first ~25 ms after an idle spell run ~5 % slow).
-    env = BatchedAOEnv(B, device, atm_type=w["atm_type"], atm_fried=w["atm_fried"], act_type=w["act_type"],
-                       act_dim=w["act_dim"], obs_dim=w["obs_dim"], rew_type=w["rew_type"],
-                       timesteps_per_episode=w["timesteps_per_episode"], num_pupil_pixels=w["n_pupil"],
-                       screens=torch.zeros((B, w["n_pupil"], w["n_pupil"]), dtype=torch.float32, device=device),
-                       kernel=args.kernel, verbose=False)
-    gen = torch.Generator(device).manual_seed(1234 + rank)       # global env id = rank*B + e lives in the seed offset
-    screens = screens_torch(B, p.num_pupil_pixels, p.pupil_pixel, cn_squared_from_fried_parameter(w["atm_fried"], p.wavelength_sci),
-                            p.outer_scale, device, gen, oversampling=16)
-    env.set_screens(screens)
+    total = world * B
     T = w["timesteps_per_episode"]
-    agen = torch.Generator(device).manual_seed(10 + rank)        # main.py:155 seed; cov 0.5 I (algorithm.py:107)
-    actions = torch.randn((T, B, w["act_dim"]), device=device, generator=agen) * (0.5 ** 0.5)
-    gather = EpisodeReturnGatherer(B, device, distributed)
+    env = BatchedAOEnv(B, device, atm_type=w["atm_type"], atm_vel=w["atm_vel"], atm_fried=w["atm_fried"], act_type=w["act_type"],
+                       act_dim=w["act_dim"], obs_dim=w["obs_dim"], rew_type=w["rew_type"], timesteps_per_episode=T,
+                       SH_operation=w["SH_operation"], num_pupil_pixels=w["n_pupil"], seed=1234, screen_source="device",
+                       screen_oversampling=16, kernel=args.kernel, verbose=False, global_env_offset=rank * B, total_envs=total)
+    # actions of the GLOBAL batch from one seed (main.py:155; cov 0.5 I, algorithm.py:107), this rank's slice kept
+    agen = torch.Generator(device).manual_seed(10)
+    actions = (torch.randn((T, total, w["act_dim"]), device=device, generator=agen) * (0.5 ** 0.5))[:, rank * B:(rank + 1) * B].contiguous()
+    gather = EpisodeReturnGatherer(B, device, distributed, total_envs=total)
     gather.attach(env)                                            # episode returns accumulate inside the step's epilogue kernel
 
-    def run(n_steps):
-        t = 0
-        env.reset()
+    if w["rollout"]:
+        from adaptive_optics_gym_amd.rollout import DeviceActor, make_actor
+
+        torch.manual_seed(10)
+        actor = make_actor(w["obs_dim"] ** 2, w["act_dim"], 150, device=device)        # SAC actor, hidden 150 (main.py:170)
+        dev_actor = DeviceActor(actor, seed=10, env_id_base=rank * B)
+        n_o = w["obs_dim"] ** 2
+        buf = {"obs": torch.empty((T + 1, B, n_o), dtype=torch.float16, device=device), "act": torch.empty((T, B, w["act_dim"]), device=device),
+               "log_prob": torch.empty((T, B), device=device), "rew": torch.empty((T, B), device=device),
+               "done": torch.empty((T, B), dtype=torch.bool, device=device), "mean": torch.empty((B, w["act_dim"]), device=device)}
+
+    state = {"t": 0, "obs": None}
+
+    def start_episode():
+        obs, _ = env.reset()
         gather.start_episode()
-        for i in range(n_steps):
-            _, rew, _, _, _ = env.step(actions[t])
-            gather.add(rew)
-            t += 1
-            if t == T:                                            # lock-step episode end (AO_env.py:147)
+        state["t"] = 0
+        if w["rollout"]:
+            buf["obs"][0].copy_(obs)
+
+    def run(n_steps):
+        for _ in range(n_steps):
+            t = state["t"]
+            if w["rollout"]:          # algorithm.py:242-270: policy query, env.step, transition stored (here: written in place)
+                a, _, _ = dev_actor(buf["obs"][t], 0.5, out=(buf["act"][t], buf["log_prob"][t], buf["mean"]))
+                env.step(a, out=(buf["obs"][t + 1], buf["rew"][t], buf["done"][t]))
+            elif w["SH_operation"]:   # algorithm.py:253 + :262
+                a, _ = env.SH_step()
+                env.step(a)
+            else:
+                env.step(actions[t])
+            state["t"] = t + 1
+            if t + 1 == T:                                        # lock-step episode end (AO_env.py:147)
                 gather.finish_episode()                           # all-gather of per-env episode returns
-                env.reset()
-                gather.start_episode()
-                t = 0
+                start_episode()
 
     def fence():
         if distributed:
@@ -183,9 +348,10 @@ def main():
 
     env.profile(True, every=PROFILE_EVERY)   # switched on ahead of the warm-up: the first timed launches of a process pay ~1 ms of runtime set-up
     # Device spin-up (reported as config.spinup_steps): a process's first few hundred steps run ~5 % slower than steady state (device
-    # clocks; tools/fixed_overhead.py).  With a caller-chosen warm-up shorter than that, the difference is run here, ahead of the
-    # W warm-up steps, so that the K timed steps measure the steady state a long-running job sees.
-    spinup = max(0, SPINUP_STEPS - args.warmup)
+    # clocks).  With a caller-chosen warm-up shorter than that, the difference is run here, ahead of the W warm-up steps, so that the K
+    # timed steps measure the steady state a long-running job sees.  Config 2 only (the other configs' steps are 5-100x longer).
+    spinup = max(0, SPINUP_STEPS - args.warmup) if (args.config == 2 and not args.no_spinup) else 0
+    start_episode()
     if spinup:
         run(spinup)
     run(args.warmup)
@@ -197,54 +363,66 @@ def main():
     dt = time.perf_counter() - t0
     kernel_ms, launches = env.profile_read()
     env.profile(False)
+    status = env.device_status()
     if distributed:
-        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    if status != 0:
+        raise SystemExit(f"bench.py: device status {status} (an inter-workgroup wait timed out): results invalid")
 
     if rank == 0:
-        bytes_step, flops_step = algorithmic_per_step(w["n_pupil"], w["act_dim"], w["obs_dim"], B, env.tables.n_ap)
+        n_ap = env.tables.n_ap
+        bytes_step, flops_step, layout_step = algorithmic_per_step(w["n_pupil"], w["act_dim"], w["obs_dim"], B, n_ap)
         if launches == 0 or kernel_ms <= 0:
             raise SystemExit("bench.py: no fused-kernel launch was timed inside the measured region")
         k_s = kernel_ms * 1e-3
-        traffic = None
+        traffic, pmc = None, {}
         tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tfile):
+        if os.path.exists(tfile) and args.config == 2 and not args.batch:
             try:
-                traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+                pmc = json.load(open(tfile))
+                traffic = pmc.get("hbm_bytes_per_launch")
             except Exception:
-                traffic = None
-        ach_tf = flops_step * B / k_s / 1e12
+                traffic, pmc = None, {}
         ach_gbs = bytes_step * B / k_s / 1e9
+        lay_gbs = layout_step * B / k_s / 1e9
+        # matrix work of the fused kernel as issued: split-f16 contractions, 3 products per operand pair
+        #   phase: 3 x (2 A_pad) flop per (pixel, env); tables: 2 (cos, sin) x 3 x 2 x 32 rows per (pixel, env)
+        a_pad = env.info.n_modes_padded
+        n_pix_pad = env.info.n_ap_padded
+        mfma_flops = (3 * 2 * a_pad + 2 * 3 * 2 * 32) * n_pix_pad * env.info.num_envs_padded
         result = {
             "metric": "env_steps_per_sec", "value": world * B * args.steps / dt, "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: batch=1024 envs/GPU, quasi_static, 256x256 pupil, act_type=num_actuators "
-                                   "act_dim=64, obs_dim=2, strehl_ratio, 30-step episodes with reset + all-gather of returns",
-                       "batch_per_gpu": B, "global_batch": world * B, "n_pupil": w["n_pupil"], "act_dim": w["act_dim"],
-                       "obs_dim": w["obs_dim"], "kernel": {1: "valu", 2: "mfma"}.get(env.info.kernel, "ref"), "spinup_steps": spinup,
-                       "parallelism": f"envs sharded over {world} GPU(s), no data-path collective"},
+            "config": {"workload": f"{w['name']}: {w['text']}", "batch_per_gpu": B, "global_batch": total, "n_pupil": w["n_pupil"],
+                       "act_dim": w["act_dim"], "obs_dim": w["obs_dim"], "atm_type": w["atm_type"],
+                       "kernel": {1: "valu", 2: "mfma"}.get(env.info.kernel, "ref"), "spinup_steps": spinup,
+                       "parallelism": f"envs sharded over {world} GPU(s) by global env id, no data-path collective; one all-gather of "
+                                      f"episode returns per episode"},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_fused_mfma" if os.environ.get("AOG_TABLES_MFMA") == "0" else "k_fused_tab",
+                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_fused_tab" if env.info.kernel == 2 else "k_fused_valu",
                          "kernel_ms": kernel_ms, "launches_timed": launches, "bytes_per_env_step": bytes_step,
+                         "layout_bytes_per_env_step": layout_step, "achieved_layout": lay_gbs, "frac_layout": lay_gbs / HBM_PEAK_GBS,
                          "timed_every": PROFILE_EVERY,
-                         "note": "algorithmic bytes (SURVEY.md 8d: 282,913 B per env-step) x 1024 envs per launch / mean "
-                                 "HIP-event duration of the fused kernel over the timed region (one block of 8 launches in 8 carries "
-                                 "the two event records: they hold the stream ~6 us, which would otherwise be in every step); "
-                                 "traffic = PMC (2*FETCH_SIZE + WRITE_SIZE) KiB per "
-                                 "launch from profiles/traffic_latest.json; 6.29 TB/s is the measured copy ceiling"},
-            "roofline_fp32": {"bound": "valu", "achieved": ach_tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": ach_tf / FP32_PEAK_TFLOPS, "flops_per_env_step": flops_step,
-                              "note": "SURVEY.md 8d algorithmic flops priced at the fp32 vector/MFMA peak; the surface "
-                                      "contraction (2*A*n_ap of them) and the table sums actually run as split-f16 MFMAs, so "
-                                      "this fraction overstates fp32 pipe use — the kernel is bound by the per-CU L2-served fill "
-                                      "rate of its operands and its sin/cos work, then by HBM"},
+                         "f16_mfma": {"achieved": mfma_flops / k_s / 1e12, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                      "frac": mfma_flops / k_s / 1e12 / F16_MFMA_PEAK_TFLOPS,
+                                      "note": "matrix flops as issued (split-f16: 3 products per operand pair, padded tiles)"},
+                         "valu_issue": ({"achieved": pmc["valu_insts_per_launch"] / k_s, "peak": VALU_ISSUE_PEAK, "unit": "wave-instructions/s",
+                                         "frac": pmc["valu_insts_per_launch"] / k_s / VALU_ISSUE_PEAK,
+                                         "note": "SQ_INSTS_VALU per launch (PMC, profiles/traffic_latest.json) / kernel time, against one vector "
+                                                 "instruction per SIMD and cycle"} if pmc.get("valu_insts_per_launch") else None),
+                         "note": "achieved = algorithmic bytes (SURVEY.md 8d: 4 N^2 + ... per env-step) x envs per launch / mean HIP-event "
+                                 "duration of the fused kernel over the timed region (one block of 8 launches in 8 carries the two event "
+                                 "records); achieved_layout = the same with the bytes the aperture-packed layout must move (4 n_ap per "
+                                 "screen); traffic = PMC (2*FETCH_SIZE + WRITE_SIZE) per launch from profiles/traffic_latest.json; "
+                                 "6.29 TB/s is the measured copy ceiling"},
         }
-        if not args.no_parity:
-            result["parity"] = strehl_check(env, screens, torch)
+        if not args.no_parity and w["atm_type"] == "quasi_static" and not w["SH_operation"]:
+            result["parity"] = parity_check(env, w, actions[0], torch)
         if not args.no_cpu_baseline and world == 1:
-            result["cpu_baseline"] = cpu_baseline()
+            result["cpu_baseline"] = cpu_baseline(w)
         print(json.dumps(result), flush=True)
     if distributed:
         dist.barrier()

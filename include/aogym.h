@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define AOG_ABI_VERSION 12
+#define AOG_ABI_VERSION 13
 
 typedef struct aog_env aog_env;
 
@@ -61,6 +61,11 @@ typedef struct {
   int32_t kernel;               /* AOG_KERNEL_* (fast precision only)                            */
   int32_t pixel_chunks;         /* 0 = auto; number of pixel chunks the fused kernel splits into */
   int32_t atm_dynamic;          /* 1: atm_type == 'dynamic' (float64 master screens + wind extrusion each step) */
+  int32_t env_id_base;          /* global id of this handle's env 0 (multi-GPU: rank r of a batch sharded contiguously owns
+                                   envs [env_id_base, env_id_base + num_envs)).  Every device random stream — screen synthesis,
+                                   extrusion normals, Shack-Hartmann photon noise — is keyed by the GLOBAL env id, so results do
+                                   not depend on how the batch is split over handles / GPUs              */
+  int32_t reserved0;            /* = 0                                                                                          */
   double wavelength_wfs;        /* 1.5e-6 (AO_env.py:219)                                        */
   double wavelength_sci;        /* 2.2e-6 (AO_env.py:220)                                        */
   double surface_rms_target;    /* 0.1*wavelength_sci (AO_env.py:120)                            */
@@ -239,10 +244,12 @@ int aog_focal_image(aog_env* env, int env_index, float* field_dev /* [n_focal][n
  * (the reference never leaves training mode while acting), action = mean + sqrt(cov_var) eps, eps ~ N(0, I),
  * log_prob = MultivariateNormal(mean, cov_var I).log_prob(action).  Weights are torch nn.Linear layouts [out][in], float32,
  * device pointers; they are read on every call (the learner updates them between rollouts).  Dropout masks and eps come from
- * Philox4x32-10 keyed by (seed, call_index, env, layer, unit): statistically, not bit-wise, torch's streams.
+ * Philox4x32-10 keyed by (seed, call_index, global env id, layer, unit): statistically, not bit-wise, torch's streams.
  * One launch per call; independent of any aog_env handle. */
 typedef struct aog_actor {
   int32_t batch, state_dim, hidden_dim, act_dim;
+  int32_t env_id_base;                  /* global id of obs row 0: dropout masks and eps are keyed by the GLOBAL env id */
+  int32_t reserved0;                    /* = 0 */
   const float* w1; const float* b1;     /* [hidden][state],  [hidden] */
   const float* w2; const float* b2;     /* [hidden][hidden], [hidden] */
   const float* w3; const float* b3;     /* [hidden][hidden], [hidden] */

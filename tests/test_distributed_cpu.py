@@ -28,7 +28,7 @@ def _worker(rank, world, port, total_envs, steps, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     s, e = shard_range(total_envs, rank, world)
-    g = EpisodeReturnGatherer(e - s, torch.device("cpu"), True)
+    g = EpisodeReturnGatherer(e - s, torch.device("cpu"), True, total_envs=total_envs)
     out = []
     for ep in range(2):
         g.start_episode()
@@ -42,8 +42,9 @@ def _worker(rank, world, port, total_envs, steps, q):
     dist.destroy_process_group()
 
 
-def test_episode_return_allgather_world2():
-    world, total, steps = 2, 16, 5
+@pytest.mark.parametrize("total", [16, 17])   # 17: uneven shards (9 + 8) -> padded all-gather, trimmed back to global-env order
+def test_episode_return_allgather_world2(total):
+    world, steps = 2, 5
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -58,6 +59,25 @@ def test_episode_return_allgather_world2():
     for ep, vals in enumerate(got):
         expect = [-(i + 1) * tri * (ep + 1) for i in range(total)]
         assert vals == pytest.approx(expect)
+    # the gathered order IS the single-process order: one gatherer over all envs fed the same per-env rewards
+    from adaptive_optics_gym_amd.sharding import EpisodeReturnGatherer
+
+    one = EpisodeReturnGatherer(total, torch.device("cpu"), False)
+    for ep, vals in enumerate(got):
+        one.start_episode()
+        for t in range(steps):
+            one.add(-(torch.arange(total, dtype=torch.float32) + 1) * (t + 1) * (ep + 1))
+        assert one.finish_episode().tolist() == vals
+
+
+def test_shard_ranges_tile_the_batch():
+    from adaptive_optics_gym_amd.sharding import global_env_ids, shard_range
+
+    for total, world in ((8192, 8), (17, 2), (5, 8), (1000, 3)):
+        ids = [i for r in range(world) for i in global_env_ids(total, r, world)]
+        assert ids == list(range(total))
+        sizes = [shard_range(total, r, world)[1] - shard_range(total, r, world)[0] for r in range(world)]
+        assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
 
 
 def test_single_process_gatherer_matches():
