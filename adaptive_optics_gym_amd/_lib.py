@@ -62,6 +62,7 @@ class AogInfo(C.Structure):
 SYMBOLS = {
     "aog_abi_version": (C.c_int, []),
     "aog_last_error": (C.c_char_p, []),
+    "aog_struct_size": (C.c_int64, [C.c_int]),
     "aog_create": (C.c_int, [C.POINTER(AogConfig), C.c_int, C.POINTER(C.c_void_p)]),
     "aog_destroy": (None, [C.c_void_p]),
     "aog_get_info": (C.c_int, [C.c_void_p, C.POINTER(AogInfo)]),
@@ -72,7 +73,7 @@ SYMBOLS = {
     "aog_set_wind": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]),
     "aog_set_extrusion_noise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "aog_set_rng_seed": (C.c_int, [C.c_void_p, C.c_uint64]),
-    "aog_get_screens_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "aog_get_screens_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "aog_generate_screens": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p]),
     "aog_upload_sh": (C.c_int, [C.c_void_p, C.POINTER(AogShTables)]),
     "aog_sh_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -84,7 +85,6 @@ SYMBOLS = {
     "aog_actor_act": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "aog_device_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "aog_set_return_accumulator": (C.c_int, [C.c_void_p, C.c_void_p]),
-    "aog_debug_read_partials": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "aog_get_actuators": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "aog_set_actuators": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "aog_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -118,6 +118,9 @@ def load():
         fn.argtypes = args
     if lib.aog_abi_version() != ABI_VERSION:
         raise RuntimeError(f"libaogym.so ABI {lib.aog_abi_version()} != binding ABI {ABI_VERSION}; rebuild")
+    for which, cls in enumerate((AogConfig, AogTables, AogLayerTables, AogShTables, AogActor, AogInfo)):
+        if lib.aog_struct_size(which) != C.sizeof(cls):
+            raise RuntimeError(f"{cls.__name__}: ctypes layout is {C.sizeof(cls)} bytes, the library's struct {lib.aog_struct_size(which)}")
     _lib = lib
     return lib
 

@@ -93,6 +93,8 @@ class BatchedAOEnv:
         self._rng = rng
         self._episode_returns = None
         self._trunc = None
+        self._persistent_out = False   # see persistent_outputs()
+        self._pack = None
 
 
         self.observation_space = make_box(-1, 1, (self.obs_dim ** 2,), np.float16)  # AO_env.py:45
@@ -156,7 +158,7 @@ class BatchedAOEnv:
         # AR matrices shared by the whole batch (for B = 1 this is exactly the reference's layer).
         self._host_rng = self._rng is not None or screen_source == "numpy"
         N = self.num_pupil_pixels
-        theta = np.zeros(self.num_envs)
+        wind_u = np.zeros(self.num_envs)   # hcipy draws theta = rand() * 2 pi per layer
         layer = None
         # GLOBAL env 0's draws define the stencils whatever slice of the batch this instance holds.
         if self._host_rng:
@@ -166,7 +168,7 @@ class BatchedAOEnv:
                 layer = build_layer_tables(N, self.params.pupil_pixel, self.params.outer_scale, r0)
             for e in range(self.num_envs):
                 r = self._env_rng(e)
-                theta[e] = r.rand() * 2 * np.pi
+                wind_u[e] = r.rand()
                 if e == 0 and self.atm_type == "dynamic" and layer is None:
                     layer = build_layer_tables(N, self.params.pupil_pixel, self.params.outer_scale, r)
                 else:
@@ -174,10 +176,11 @@ class BatchedAOEnv:
                     r.geometric(0.5, N)
         else:
             trng = np.random.RandomState(1234 if seed is None else int(seed))
-            theta = (trng.rand(self.total_envs) * 2 * np.pi)[self.global_env_offset:self.global_env_offset + self.num_envs]
+            wind_u = trng.rand(self.total_envs)[self.global_env_offset:self.global_env_offset + self.num_envs]
             if self.atm_type == "dynamic":
                 layer = build_layer_tables(N, self.params.pupil_pixel, self.params.outer_scale, trng)
-        self.wind_direction = np.array(theta, dtype=np.float64)
+        self.wind_u = np.array(wind_u, dtype=np.float64)
+        theta = self.wind_u * 2 * np.pi
         self.velocity_vectors = float(self.velocity) * np.stack([np.cos(theta), np.sin(theta)], axis=1)  # [B, 2] m/s
         if self.atm_type == "dynamic":
             self._upload_layer(layer)
@@ -332,12 +335,26 @@ class BatchedAOEnv:
         self._noise_dev = torch.from_numpy(noise).to(self.device)  # kept alive until the step has run
         _lib.check(self.lib.aog_set_extrusion_noise(self._handle, C.c_void_p(self._noise_dev.data_ptr()), max_ext, self._stream()))
 
-    def get_screens(self):
-        """Dynamic atmosphere: every env's current achromatic screen, [B, N, N] float64."""
+    def set_extrusion_noise(self, noise):
+        """Standard normals for the extrusions of the NEXT ``step`` (dynamic atmosphere, parity runs): ``[B, max_ext, N]`` float64
+        device tensor, row k of env b = the ``normal(0, 1, N)`` draw of its k-th extrusion in hcipy's order (x shifts first, then
+        y).  Without this call the step draws from the handle's Philox stream."""
+        torch = self._torch
+        n = torch.as_tensor(noise, device=self.device).to(torch.float64).contiguous()
+        if n.dim() != 3 or n.shape[0] != self.num_envs or n.shape[2] != self.num_pupil_pixels:
+            raise ValueError("set_extrusion_noise: expected [num_envs, max_ext, N]")
+        self._noise_dev = n   # kept alive until the step has run
+        _lib.check(self.lib.aog_set_extrusion_noise(self._handle, C.c_void_p(n.data_ptr()), int(n.shape[1]), self._stream()))
+
+    def get_screens(self, first=0, count=None):
+        """Current achromatic screens (hcipy's ``layer._achromatic_screen``: phase * lambda) of envs [first, first + count), default
+        all: [count, N, N] float64.  Dynamic atmosphere: the float64 master screens.  Otherwise the stored screen exactly as the step
+        kernels read it (aperture pixels only, aperture mean removed)."""
         torch = self._torch
         N = self.num_pupil_pixels
-        out = torch.empty((self.num_envs, N, N), dtype=torch.float64, device=self.device)
-        _lib.check(self.lib.aog_get_screens_f64(self._handle, C.c_void_p(out.data_ptr()), self._stream()))
+        count = self.num_envs - first if count is None else int(count)
+        out = torch.empty((count, N, N), dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.aog_get_screens_f64(self._handle, C.c_void_p(out.data_ptr()), int(first), count, self._stream()))
         return out
 
     def set_screens(self, screens, first=0):
@@ -389,15 +406,23 @@ class BatchedAOEnv:
             self._host_extrusion_noise()
         n = self.obs_dim ** 2
         B = self.num_envs
-        # allocations per step: fp32 block (obs_raw | power | strehl [| reward]), and unless handed in: fp16 obs, uint8 done
-        f32 = torch.empty((B * (n + 3),), dtype=torch.float32, device=self.device)
+        # ONE allocation per step: fp32 block (obs_raw | reward | power | strehl), fp16 obs, uint8 done — or none at all when the
+        # caller asked for a persistent block (``persistent_outputs``: the single-env wrapper copies it to the host in one transfer)
+        nb32, nb16 = 4 * B * (n + 3), 2 * B * n
+        if self._persistent_out:
+            if self._pack is None:
+                self._pack = torch.empty((nb32 + nb16 + B,), dtype=torch.uint8, device=self.device)
+            pack = self._pack
+        else:
+            pack = torch.empty((nb32 + nb16 + B,), dtype=torch.uint8, device=self.device)
+        f32 = pack[:nb32].view(torch.float32)
         obs_raw = f32[: B * n].view(B, n)
         power = f32[B * (n + 1): B * (n + 2)]
         strehl = f32[B * (n + 2):]
         if out is None:
             reward = f32[B * n: B * (n + 1)]
-            obs = torch.empty((B, n), dtype=torch.float16, device=self.device)
-            done = torch.empty((B,), dtype=torch.uint8, device=self.device)
+            obs = pack[nb32:nb32 + nb16].view(torch.float16).view(B, n)
+            done = pack[nb32 + nb16:]
         else:
             obs, reward, done = out
             ok = (obs.dtype == torch.float16 and tuple(obs.shape) == (B, n) and reward.dtype == torch.float32 and tuple(reward.shape) == (B,)
@@ -414,6 +439,17 @@ class BatchedAOEnv:
         if self._trunc is None:
             self._trunc = torch.zeros((B,), dtype=torch.bool, device=self.device)
         return obs, reward, done if done.dtype == torch.bool else done.view(torch.bool), self._trunc, {"power": power, "obs_raw": obs_raw, "strehl": strehl}
+
+    def persistent_outputs(self, enable=True):
+        """Write every ``step``'s outputs into ONE block that lives as long as the env instead of fresh tensors: the tensors a step
+        returns are then views that the NEXT step overwrites.  For callers that consume a step's outputs before stepping again (the
+        single-env wrapper: one device-to-host copy of the block per step); returns the block layout (n = obs_dim^2):
+        float32 [B n] obs_raw | [B] reward | [B] power | [B] strehl, then float16 [B n] obs, then uint8 [B] done."""
+        self._persistent_out = bool(enable)
+        if not enable:
+            self._pack = None
+        n, B = self.obs_dim ** 2, self.num_envs
+        return {"float32_bytes": 4 * B * (n + 3), "float16_bytes": 2 * B * n, "uint8_bytes": B}
 
     # ------------------------------------------------------------------------------------------------
     def get_actuators(self):

@@ -12,6 +12,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -45,6 +47,21 @@ struct DevBuf {
 
 }  // namespace
 
+
+namespace aog_host {
+int ensure_dynamic_lds(const void* fn, size_t bytes, int device) {
+  if (bytes <= 64 * 1024) return AOG_OK;   // the default limit
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, size_t> granted;
+  std::lock_guard<std::mutex> lock(mu);
+  size_t& have = granted[{fn, device}];
+  if (bytes > have) {
+    HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    have = bytes;
+  }
+  return AOG_OK;
+}
+}  // namespace aog_host
 
 namespace {
 
@@ -145,7 +162,7 @@ int launch_epilogue(aog_env* e, bool is_step, float* obs_raw, uint16_t* obs, flo
   p.Bp = e->Bp;
   const bool ref = e->cfg.precision == AOG_PRECISION_FP64;
   p.n_chunks = ref ? 1 : e->n_chunks;
-  if (e->tab_mfma && e->MRW > 8 && e->cfg.precision == AOG_PRECISION_FAST) {
+  if (e->kernel == AOG_KERNEL_MFMA && e->MRW > 8 && e->cfg.precision == AOG_PRECISION_FAST) {
     // many short float chunks: fold them first with a fully coalesced pass, the epilogue then reads one float64 slab
     const int NSr = 2 * (e->MRW + e->MRS);
     hipLaunchKernelGGL(aog::k_reduce_slabs, dim3(e->Bp / 64, (NSr + 3) / 4), dim3(256), 0, s, reinterpret_cast<const float*>(e->partials),
@@ -171,10 +188,7 @@ int launch_epilogue(aog_env* e, bool is_step, float* obs_raw, uint16_t* obs, flo
   p.ssim_alpha = e->cfg.ssim_alpha;
   const int NS = 2 * (p.MRW + p.MRS);
   const size_t lds = aog::epilogue_lds_bytes(NS, p.n_obs, p.n_fiber, p.MRW_used, p.MRS_used);
-  if (lds > 64 * 1024 && !e->epilogue_attr_set) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(aog::k_epilogue), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    e->epilogue_attr_set = true;
-  }
+  if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_epilogue), lds, e->device)) return rc;
   hipLaunchKernelGGL(aog::k_epilogue, dim3((e->Bp + aog::kEpiEnvs - 1) / aog::kEpiEnvs), dim3(1024), lds, s, p);
   HIP_TRY(hipGetLastError());
   return AOG_OK;
@@ -269,31 +283,23 @@ int evolve_layer(aog_env* e, hipStream_t s) {
     const size_t lds = ext_split_lds(e);
     static const int ks = getenv("AOG_EXTRUDE_KS") ? atoi(getenv("AOG_EXTRUDE_KS")) : 2;
     auto kern = ks == 4 ? aog::k_extrude16_split<4> : ks == 1 ? aog::k_extrude16_split<1> : aog::k_extrude16_split<2>;
-    if (lds > 64 * 1024 && !e->extrude_split_attr_set) {
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      e->extrude_split_attr_set = true;
-    }
+    if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, e->device)) return rc;
     HIP_TRY(hipMemsetAsync(e->ext_bar, 0, sizeof(unsigned) * round_up(e->n_ext_groups, 4), s));
     p.origin = e->origin;
     const int groups8 = round_up(e->n_ext_groups, 8);
-    hipLaunchKernelGGL(kern, dim3(groups8 * aog::kExtParts), dim3(256 * (ks == 4 ? 4 : ks == 1 ? 1 : 2)), lds, s, p, e->B, e->ext_perm, e->ext_bar, e->dev_status);
+    hipLaunchKernelGGL(kern, dim3(groups8 * aog::kExtParts), dim3(256 * (ks == 4 ? 4 : ks == 1 ? 1 : 2)), lds, s, p, e->B, e->ext_perm, e->ext_bar, e->dev_status,
+                       e->host_flag_dev);
     HIP_TRY(hipGetLastError());
   } else if (!getenv("AOG_EXTRUDE_SIMPLE") && ext16_lds(e) <= kLdsBytes) {
     // default: float64 matrix-core form, 16 envs per workgroup (a workgroup owns whole envs: no cross-workgroup hazard)
     const size_t lds = (size_t)aog::kExt16G * ((std::max(e->nz_v, e->nz_h) | 1) + (e->cfg.n_pupil | 1)) * sizeof(double);
-    if (lds > 64 * 1024 && !e->extrude_attr_set) {
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(aog::k_extrude16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      e->extrude_attr_set = true;
-    }
+    if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_extrude16), lds, e->device)) return rc;
     p.origin = e->origin;
     hipLaunchKernelGGL(aog::k_extrude16, dim3((e->B + aog::kExt16G - 1) / aog::kExt16G), dim3(512), lds, s, p, e->B);
     HIP_TRY(hipGetLastError());
   } else {
     const size_t lds = (size_t)aog::kExtG * (std::max(e->nz_v, e->nz_h) + 2 * e->cfg.n_pupil) * sizeof(double);
-    if (lds > 64 * 1024 && !e->extrude_attr_set) {
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(aog::k_extrude), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      e->extrude_attr_set = true;
-    }
+    if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_extrude), lds, e->device)) return rc;
     p.origin = e->origin;
     hipLaunchKernelGGL(aog::k_extrude, dim3((e->B + aog::kExtG - 1) / aog::kExtG), dim3(aog::kExtThreads), lds, s, p, e->B);
     HIP_TRY(hipGetLastError());
@@ -301,6 +307,16 @@ int evolve_layer(aog_env* e, hipStream_t s) {
   e->next_noise = nullptr;
   e->next_noise_max_ext = 0;
   return pack_from_master(e, 0, e->B, s, true);
+}
+
+// A bounded inter-workgroup wait of an earlier launch timed out (k_extrude16_split): every screen that launch touched is suspect.
+// The flag lives in pinned host memory, so this costs one load and no synchronisation; it is seen at the latest by the call after
+// the one whose launch tripped it.  Installing fresh screens for the whole batch (aog_set_screens / aog_set_state) clears it.
+int check_poisoned(const aog_env* e, const char* who) {
+  if (e->host_flag && *static_cast<volatile const int*>(e->host_flag) != 0)
+    return fail(AOG_ERR_STATE, "%s: an inter-workgroup wait of the dynamic-atmosphere kernel timed out in an earlier step; the screens of "
+                "this handle are invalid (install new screens or restore a saved state)", who);
+  return AOG_OK;
 }
 
 template <typename T>
@@ -326,6 +342,11 @@ int set_screens(aog_env* e, const T* psi, int first, int count, hipStream_t s) {
     HIP_TRY(hipGetLastError());
   }
   e->screens_ready = true;
+  if (first == 0 && count == e->B && e->host_flag && *static_cast<volatile int*>(e->host_flag)) {
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipMemset(e->dev_status, 0, sizeof(int)));
+    *static_cast<volatile int*>(e->host_flag) = 0;
+  }
   return AOG_OK;
 }
 
@@ -336,6 +357,18 @@ extern "C" {
 int aog_abi_version(void) { return AOG_ABI_VERSION; }
 
 const char* aog_last_error(void) { return g_last_error.c_str(); }
+
+int64_t aog_struct_size(int which) {
+  switch (which) {
+    case 0: return (int64_t)sizeof(aog_config);
+    case 1: return (int64_t)sizeof(aog_tables);
+    case 2: return (int64_t)sizeof(aog_layer_tables);
+    case 3: return (int64_t)sizeof(aog_sh_tables);
+    case 4: return (int64_t)sizeof(aog_actor);
+    case 5: return (int64_t)sizeof(aog_info);
+    default: return -1;
+  }
+}
 
 int aog_create(const aog_config* cfg, int device, aog_env** out) {
   if (!cfg || !out) return fail(AOG_ERR_INVALID, "aog_create: null argument");
@@ -377,7 +410,6 @@ int aog_create(const aog_config* cfg, int device, aog_env** out) {
   // sin/cos flavour of the fast kernels: "hwraw" (default; v_sin_f32/v_cos_f32 on the revolutions, the instruction
   // reduces them itself), "hw" (same instructions after an explicit exact reduction), "poly" (degree-7/8 polynomial)
   e->sincos_hw = 2;
-  if (const char* ab = getenv("AOG_ABLATE")) e->ablate = atoi(ab);
   if (const char* sc = getenv("AOG_SINCOS")) e->sincos_hw = strcmp(sc, "poly") == 0 ? 0 : (strcmp(sc, "hwraw") == 0 ? 2 : 1);
 
   if (cfg->precision == AOG_PRECISION_FAST) {
@@ -391,11 +423,6 @@ int aog_create(const aog_config* cfg, int device, aog_env** out) {
                   "use AOG_PRECISION_FP64 for this shape");
     }
     e->kernel = cfg->kernel == AOG_KERNEL_AUTO ? AOG_KERNEL_MFMA : cfg->kernel;
-    if (e->kernel == AOG_KERNEL_MFMA && e->A_pad > 64 && getenv("AOG_WIDE_VALU")) e->kernel = AOG_KERNEL_VALU;   // developer comparison
-    // table reduction on the matrix cores: the default; AOG_TABLES_MFMA=0 selects the vector-unit form (k_fused_mfma)
-    e->tab_mfma = e->kernel == AOG_KERNEL_MFMA;
-    if (const char* tm = getenv("AOG_TABLES_MFMA")) e->tab_mfma = e->kernel == AOG_KERNEL_MFMA && atoi(tm) != 0;
-    if (const char* t16 = getenv("AOG_FUSED_T16")) e->fused_t16 = atoi(t16) != 0;   // developer variant, see k_fused_t16
     // launch geometry: aim at ~3 (VALU) / ~2 (MFMA) waves per SIMD over 256 CUs
     const int n_groups = e->Bp / 64;
     int P = cfg->pixel_chunks > 0 ? cfg->pixel_chunks : std::max(1, (256 * 4 * 3 + n_groups - 1) / n_groups);
@@ -408,9 +435,7 @@ int aog_create(const aog_config* cfg, int device, aog_env** out) {
     // P pixel chunks (proportional split of the tiles), 2 workgroups per CU when the batch allows; the table stage of a
     // chunk must fit 60 KiB of LDS
     int Pm = cfg->pixel_chunks > 0 ? cfg->pixel_chunks : std::max(1, (256 * 2) / wg_y);
-    int max_tpc = std::max(1, (int)(60 * 1024 / (8 * (e->MRW + 1) * 16)));
-    if (e->MRW >= 20) max_tpc = std::min(max_tpc, aog::kF32AccTiles * wp);   // fp32-only accumulation: bounded terms per lane
-    if (e->tab_mfma) max_tpc = e->MRW > 8 ? aog::kTabF32Tiles * wp : 4096;   // no table stage in LDS; fp32-only variants: bounded chunks
+    const int max_tpc = e->MRW > 8 ? aog::kTabF32Tiles * wp : 4096;   // fp32-only sums (many-table variants): bounded chunks
     Pm = std::max(Pm, (e->n_ptiles + max_tpc - 1) / max_tpc);
     Pm = std::min(Pm, e->n_ptiles);
     e->mfma_chunks_x = Pm;
@@ -438,6 +463,18 @@ int aog_create(const aog_config* cfg, int device, aog_env** out) {
   TRY_ALLOC(dev_alloc(e, &e->t_render, e->B));
   TRY_ALLOC(dev_alloc(e, &e->screen_gen, e->B));
   TRY_ALLOC(dev_alloc(e, &e->dev_status, 16));
+  {
+    void* hp = nullptr;
+    void* dp = nullptr;
+    if (hipHostMalloc(&hp, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) {
+      if (hp) (void)hipHostFree(hp);
+      aog_destroy(e);
+      return fail(AOG_ERR_HIP, "aog_create: pinned status word allocation failed");
+    }
+    memset(hp, 0, 64);
+    e->host_flag = static_cast<int*>(hp);
+    e->host_flag_dev = static_cast<int*>(dp);
+  }
   TRY_ALLOC(dev_alloc(e, &e->partials, e->partial_elems));
   TRY_ALLOC(dev_alloc(e, &e->slab_reduced, (size_t)2 * 64 * e->Bp));   // [NS <= 58][Bp] float64 (k_reduce_slabs)
   if (cfg->atm_dynamic) {
@@ -466,7 +503,6 @@ int aog_create(const aog_config* cfg, int device, aog_env** out) {
     TRY_ALLOC(dev_alloc(e, &e->modes_f32, (size_t)e->n_ap_pad * e->A_pad));
     TRY_ALLOC(dev_alloc(e, &e->modes16, (size_t)e->n_ap_pad * e->A_pad * 2));
     TRY_ALLOC(dev_alloc(e, &e->tabs_f32, (size_t)e->n_ap_pad * TROW));
-    TRY_ALLOC(dev_alloc(e, &e->tabs_tile, (size_t)e->n_ap_pad * (e->MRW + e->MRS)));
     TRY_ALLOC(dev_alloc(e, &e->tab16, (size_t)e->n_ptiles * 2 * 2 * 64 * 8));
     TRY_ALLOC(dev_alloc(e, &e->sci_tile, (size_t)e->n_ptiles * 32));
     TRY_ALLOC(dev_alloc(e, &e->psi_rev, (size_t)e->n_quads * e->Bp * 4));
@@ -485,6 +521,7 @@ void aog_destroy(aog_env* e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
   for (void* p : e->allocs) (void)hipFree(p);
+  if (e->host_flag) (void)hipHostFree(e->host_flag);
   if (e->fft_plan) hipfftDestroy((hipfftHandle)(uintptr_t)e->fft_plan);
   if (e->sh_plan) hipfftDestroy((hipfftHandle)(uintptr_t)e->sh_plan);
   for (auto& ev : e->events) {
@@ -550,7 +587,7 @@ int aog_upload_tables(aog_env* e, const aog_tables* t) {
         m16[base * 8 + el] = hi;
         m16[(base + 64) * 8 + el] = lo;
       }
-    std::vector<float> tf((size_t)e->n_ap_pad * TROW, 0.f), tt((size_t)e->n_ap_pad * MR, 0.f);
+    std::vector<float> tf((size_t)e->n_ap_pad * TROW, 0.f);
     auto tab = [&](int m, int p) -> float {
       if (m < e->MRW_used) return (float)t->wfs_tables[(size_t)m * n_ap + p];
       if (m >= e->MRW && m - e->MRW < e->MRS_used) return (float)t->sci_tables[(size_t)(m - e->MRW) * n_ap + p];
@@ -558,11 +595,7 @@ int aog_upload_tables(aog_env* e, const aog_tables* t) {
     };
     for (int p = 0; p < n_ap; ++p)
       for (int m = 0; m < MR; ++m) {
-        const float v = tab(m, p);
-        tf[(size_t)p * TROW + m] = v;
-        // tabs_tile[pt][g][h][m][r], pixel i = 8g + 4h + r
-        const int pt = p >> 5, i = p & 31, g = i >> 3, h = (i >> 2) & 1, r = i & 3;
-        tt[((((size_t)pt * 4 + g) * 2 + h) * MR + m) * 4 + r] = v;
+        tf[(size_t)p * TROW + m] = tab(m, p);
       }
     HIP_TRY(hipMemcpy(e->modes_f32, mf.data(), sizeof(float) * mf.size(), hipMemcpyHostToDevice));
     {
@@ -592,7 +625,6 @@ int aog_upload_tables(aog_env* e, const aog_tables* t) {
     }
     HIP_TRY(hipMemcpy(e->modes16, m16.data(), sizeof(_Float16) * m16.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->tabs_f32, tf.data(), sizeof(float) * tf.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(e->tabs_tile, tt.data(), sizeof(float) * tt.size(), hipMemcpyHostToDevice));
   }
   if (t->focal_m1 && t->focal_m2 && t->n_focal > 0 && !e->focal_m1) {
     const int N = e->cfg.n_pupil, nf = t->n_focal;
@@ -734,13 +766,23 @@ int aog_set_rng_seed(aog_env* e, uint64_t seed) {
   return AOG_OK;
 }
 
-int aog_get_screens_f64(aog_env* e, double* psi_dev, void* stream) {
+int aog_get_screens_f64(aog_env* e, double* psi_dev, int first, int count, void* stream) {
   if (!e || !psi_dev) return fail(AOG_ERR_INVALID, "aog_get_screens_f64: null argument");
-  if (!e->cfg.atm_dynamic) return fail(AOG_ERR_STATE, "aog_get_screens_f64: only dynamic handles keep float64 master screens");
+  if (!e->screens_ready) return fail(AOG_ERR_STATE, "aog_get_screens_f64 before any screen was installed");
+  if (first < 0 || count < 0 || first + count > e->B) return fail(AOG_ERR_INVALID, "aog_get_screens_f64: env range outside [0,%d)", e->B);
+  if (count == 0) return AOG_OK;
   HIP_TRY(hipSetDevice(e->device));
-  const size_t n = (size_t)e->B * e->cfg.n_pupil * e->cfg.n_pupil;
-  hipLaunchKernelGGL(aog::k_unroll_master, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     e->psi_master, e->origin, psi_dev, e->B, e->cfg.n_pupil);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int N = e->cfg.n_pupil;
+  const size_t n = (size_t)count * N * N;
+  if (e->cfg.atm_dynamic) {
+    hipLaunchKernelGGL(aog::k_unroll_master, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, e->psi_master, e->origin, psi_dev, first, count, N);
+  } else {
+    HIP_TRY(hipMemsetAsync(psi_dev, 0, sizeof(double) * n, s));
+    const bool fast = e->cfg.precision == AOG_PRECISION_FAST;
+    hipLaunchKernelGGL(aog::k_screens_from_store, dim3((e->n_ap + 255) / 256, count), dim3(256), 0, s, fast ? e->psi_tile : nullptr,
+                       fast ? nullptr : e->psi64, e->ap_index, psi_dev, first, e->n_ap, e->n_ptiles, N * N, 2.0 * M_PI * e->cfg.wavelength_wfs);
+  }
   HIP_TRY(hipGetLastError());
   return AOG_OK;
 }
@@ -797,11 +839,8 @@ int aog_generate_screens(aog_env* e, int first, int count, int oversampling, dou
                          : (R == 1 ? aog::k_screen_rows<1, 60> : R == 2 ? aog::k_screen_rows<2, 60> : R == 4 ? aog::k_screen_rows<4, 60> : aog::k_screen_rows<8, 60>);
     auto cols = LW == 64 ? (R == 1 ? aog::k_screen_cols<1, 64> : R == 2 ? aog::k_screen_cols<2, 64> : R == 4 ? aog::k_screen_cols<4, 64> : aog::k_screen_cols<8, 64>)
                          : (R == 1 ? aog::k_screen_cols<1, 60> : R == 2 ? aog::k_screen_cols<2, 60> : R == 4 ? aog::k_screen_cols<4, 60> : aog::k_screen_cols<8, 60>);
-    if (!e->syn_attr_set) {
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(rows), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(cols), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cols));
-      e->syn_attr_set = true;
-    }
+    if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(rows), lds, e->device)) return rc;
+    if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(cols), lds_cols, e->device)) return rc;
     const int n_launch = (count + e->syn_batch - 1) / e->syn_batch;
     const int per_launch = (count + n_launch - 1) / n_launch;   // even shares (no short tail launch)
     for (int done = 0; done < count; done += per_launch) {
@@ -1054,6 +1093,10 @@ int aog_set_state(aog_env* e, const void* blob_dev, int64_t timestep, void* stre
   e->timestep = timestep;
   e->rng_seed = tail.rng_seed;
   e->sh_calls = tail.sh_calls;
+  if (e->host_flag && *static_cast<volatile int*>(e->host_flag)) {   // a restored state replaces every screen: the handle is usable again
+    HIP_TRY(hipMemset(e->dev_status, 0, sizeof(int)));
+    *static_cast<volatile int*>(e->host_flag) = 0;
+  }
   // derived operand layouts follow the restored actuators
   const int n = e->B * e->A_pad;
   hipLaunchKernelGGL(aog::k_load_actuators, dim3((n + 255) / 256), dim3(256), 0, s, e->act_dm, e->act_rev, e->act16, e->B, e->A, e->A_pad, e->Bp,
@@ -1078,14 +1121,6 @@ int aog_get_phase_screen(aog_env* e, int env_index, float* phase_dev, void* stre
   return AOG_OK;
 }
 
-int aog_debug_read_partials(aog_env* e, void* dst_host, size_t nbytes) {
-  if (!e || !dst_host) return fail(AOG_ERR_INVALID, "aog_debug_read_partials: null argument");
-  HIP_TRY(hipSetDevice(e->device));
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(dst_host, e->partials, nbytes, hipMemcpyDeviceToHost));
-  return AOG_OK;
-}
-
 int aog_set_return_accumulator(aog_env* e, float* returns_dev) {
   if (!e) return fail(AOG_ERR_INVALID, "aog_set_return_accumulator: null handle");
   e->ret_acc = returns_dev;
@@ -1098,7 +1133,7 @@ int aog_device_status(aog_env* e, int32_t* status_out) {
   HIP_TRY(hipDeviceSynchronize());
   int v[16];
   HIP_TRY(hipMemcpy(v, e->dev_status, sizeof v, hipMemcpyDeviceToHost));
-  *status_out = v[0];
+  *status_out = v[0] | *static_cast<volatile int*>(e->host_flag);
   if (getenv("AOG_EXTRUDE_TIMING")) {   // developer aid: phase clocks (10 ns ticks) of workgroup 0 of k_extrude16_split
     if (v[1]) fprintf(stderr, "[aogym] extrude16_split WG0 ticks: gather %d noise %d compute %d (matrix passes %d, exchange %d) barrier %d rounds %d\n", v[4], v[5], v[6], v[9], v[10], v[7], v[8]);
     const int one = 1;
@@ -1130,6 +1165,7 @@ int aog_set_actuators(aog_env* e, const double* act_dev, void* stream) {
 int aog_reset(aog_env* e, const uint8_t* mask, float* obs_raw, uint16_t* obs, void* stream) {
   if (!e) return fail(AOG_ERR_INVALID, "aog_reset: null handle");
   if (!e->tables_ready || !e->screens_ready) return fail(AOG_ERR_STATE, "aog_reset before aog_upload_tables/aog_set_screens");
+  if (int rc = check_poisoned(e, "aog_reset")) return rc;
   HIP_TRY(hipSetDevice(e->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
   {
@@ -1150,6 +1186,7 @@ int aog_step(aog_env* e, const float* action, float* obs_raw, uint16_t* obs, flo
              float* strehl, void* stream) {
   if (!e || !action) return fail(AOG_ERR_INVALID, "aog_step: null argument");
   if (!e->tables_ready || !e->screens_ready) return fail(AOG_ERR_STATE, "aog_step before aog_upload_tables/aog_set_screens");
+  if (int rc = check_poisoned(e, "aog_step")) return rc;
   if (e->cfg.reward_type == AOG_REWARD_SMF_SSIM && e->n_obs < 7)
     return fail(AOG_ERR_INVALID, "win_size exceeds image extent (smf_ssim needs obs_dim**2 >= 7; AO_env.py:495)");
   HIP_TRY(hipSetDevice(e->device));
@@ -1219,15 +1256,7 @@ int aog_actor_act(const aog_actor* n, int device, const void* obs_dev, int obs_i
   a.call_hi = (uint32_t)(n->call_index >> 32);
   a.env_base = n->env_id_base;
   const size_t lds = ((size_t)2 * a.kpad * 16 + 16 + (size_t)aog::kActorWFloats) * sizeof(float);
-  if (lds > 64 * 1024) {
-    // the attribute is per device: remember the largest request made on each (one process normally drives one GPU)
-    static std::atomic<size_t> attr_bytes[64];
-    const int slot = device >= 0 && device < 64 ? device : 0;
-    if (lds > attr_bytes[slot].load(std::memory_order_relaxed)) {
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(aog::k_actor_act), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr_bytes[slot].store(lds, std::memory_order_relaxed);
-    }
-  }
+  if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_actor_act), lds, device)) return rc;
   hipLaunchKernelGGL(aog::k_actor_act, dim3((n->batch + 15) / 16), dim3(aog::kActorThreads), lds, static_cast<hipStream_t>(stream), a);
   HIP_TRY(hipGetLastError());
   return AOG_OK;

@@ -19,7 +19,6 @@ struct aog_env {
   int n_obs = 0, n_out = 0;
   int kernel = AOG_KERNEL_VALU;  // resolved
   int sincos_hw = 0;
-  int ablate = 0;  // AOG_ABLATE diagnostic (timing only; results are wrong by construction)
   // launch geometry
   int valu_chunks = 0, valu_qpc = 0;
   int mfma_we = 1, mfma_chunks_x = 0, mfma_tpc = 0;
@@ -30,12 +29,8 @@ struct aog_env {
   float* modes_f32 = nullptr;    // [n_ap_pad][A_pad]
   _Float16* modes16 = nullptr;   // [n_ptiles][A_pad/16][hi|lo][64][8]
   float* tabs_f32 = nullptr;     // [n_ap_pad][TROW]
-  float* tabs_tile = nullptr;    // [n_ptiles][4][2][MRW+MRS][4]
   _Float16* tab16 = nullptr;     // table-MFMA form: [n_ptiles][step 2][hi|lo][lane 64][8] A operands of the wfs tables
   float* sci_tile = nullptr;     // [n_ptiles][h 2][16] science table in accumulator order
-  bool tab_mfma = false;         // table reduction on the matrix cores (k_fused_tab)
-  bool fused_t16 = false;        // opt-in (AOG_FUSED_T16=1 at aog_create): 16 x 16 x 16 tile variant k_fused_t16 (<= 8 tables)
-  bool tab_attr_set = false;
   double* gram = nullptr;        // [A][A]
   double* wfs_coef = nullptr;    // [n_out][MRW_used][2]
   double* sci_coef = nullptr;    // [MRS_used][2]
@@ -69,7 +64,6 @@ struct aog_env {
   float* syn_T = nullptr;        // pruned synthesis: [syn_batch][m][N] complex64 (lines after pass A)
   float* syn_out = nullptr;      // [syn_batch][N][N]
   int syn_batch = 0, syn_m = 0;
-  bool syn_attr_set = false;
   uint32_t* screen_gen = nullptr;   // [B] screens synthesised so far per env (Philox stream position of k_screen_rows / k_spectrum_fill)
   // focal-image export (optional)
   int n_focal = 0;
@@ -87,13 +81,12 @@ struct aog_env {
   int32_t* t_render = nullptr;   // [B]
   // dynamic atmosphere (cfg.atm_dynamic)
   bool layer_ready = false;
-  bool extrude_attr_set = false;
-  bool epilogue_attr_set = false;
-  bool extrude_split_attr_set = false;
   bool rounds_ok = false;        // stencils never sample the dropped row/column -> lock-step round kernel is race-free
   int32_t* origin_alt = nullptr; // second origin buffer (rounds ping-pong)
   unsigned* ext_bar = nullptr;   // group-barrier tickets of k_extrude16_split (zeroed before every launch)
   int* dev_status = nullptr;     // sticky device-side error word (1 = a bounded spin timed out)
+  int* host_flag = nullptr;      // the same flag in pinned, device-mapped host memory: read by the host without a synchronisation
+  int* host_flag_dev = nullptr;  // its device address
   int n_ext_groups = 0;
   int32_t* ext_perm = nullptr;   // [n_ext_groups * 16] group slot -> env id, -1 = padding (envs sorted by wind, see aog_set_wind)
   double max_wind = 0;           // max |component| of any env's velocity (bounds the rounds per step)
@@ -136,6 +129,9 @@ struct aog_env {
 
 namespace aog_host {
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to the FUNCTION (per device), not to a handle: remember the largest request
+// made for each (function, device) in this process and only ever raise it, so that handles of different shapes coexist.
+int ensure_dynamic_lds(const void* fn, size_t bytes, int device);
 // Fused-kernel launchers, one translation unit per padded mode count so the build parallelises
 // (fused_inst.hip compiled with -DAOG_INST_APAD=16|32|64|128).
 void launch_fused_apad16(aog_env* e, hipStream_t s);

@@ -335,14 +335,7 @@ struct MfmaGeom {
   int skew;   // start-up skew of every second workgroup, x 16 cycles (kSkewNops unless the developer override AOG_SKEW_NOPS is set)
 };
 
-// ---- compile-time interleave plan -------------------------------------------------------------------------------
-// The vector work of one finished tile is cut into micro-ops
-//   SC(i)    sincos of accumulator register i at both wavelengths            (i = 4g + r, 16 per tile)
-//   TB(g,m)  table m against the 4 pixels of register group g: 1 ds_read_b128 + 8 fma   (4 * MR per tile)
-//   FL(f)    flush a third of the fp32 tile sums into the float64 running sums           (3 per tile)
-// in an order that keeps SC of group g+1 ahead of TB of group g+1.  Slot 0 (no MFMA) takes LEAD_PCT % of the issue
-// cost — the time the next tile's mode/screen loads need to land — and the rest is dealt evenly behind the NM matrix
-// instructions of the NEXT tile's contraction.  sched_barrier(0) between slots pins the plan.
+// compile-time loops (indices usable as template arguments)
 template <int K>
 struct IC { static constexpr int v = K; };
 template <int... Is, class F>
@@ -350,365 +343,14 @@ __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
-// fp32 partial sums of the table reduction are folded into the float64 accumulators every kFlushTiles tiles (16 pixels per lane
-// each): the conversions + float64 adds are half-rate vector work, 16 of ~115 issue cycles per (pixel, env) if done every tile
+// The 8-table variant of k_fused_tab folds its fp32 table sums into float64 every kFlushTiles tiles (32 terms per tile and accumulator
+// element); the many-table variants run fp32 over a chunk of at most kTabF32Tiles tiles.
 constexpr int kFlushTiles = 4;
-constexpr int kTabF32Tiles = 13;   // same for the table-MFMA form (32 terms per tile and accumulator element)
-constexpr int kF32AccTiles = 13;   // longest chunk (tiles per wave) of the variants that accumulate in fp32 only
+constexpr int kTabF32Tiles = 13;
 constexpr int kSkewNops = 150;   // x 16 cycles: start-up skew of the second workgroup of a CU (about half a stage)
 
-template <int A_PAD, int MRW, int MRS, int SINCOS>
-struct Plan {
-  static constexpr int MR = MRW + MRS, NS = 2 * MR;
-  static constexpr int NSTEP = A_PAD / 16;   // K=16 steps
-  static constexpr int NM = 3 * NSTEP;       // matrix instructions per tile
-  static constexpr int NSLOT = NM + 1;
-  static constexpr int LEAD_PCT = 40;
-  static constexpr int PREFETCH_CAP = 4;
-  static constexpr int U_SC = SINCOS == 0 ? 44 : (SINCOS == 1 ? 13 : 9);
-  static constexpr int U_TB = 5, N_FL = 3, U_FL = NS / kFlushTiles + 1;
-  static constexpr int N_OPS = 16 + 4 * MR + N_FL;
-  struct Table {
-    int type[N_OPS], a[N_OPS], b[N_OPS];
-    int first[NSLOT + 1];  // ops [first[k], first[k+1]) run in slot k
-    int max_tb;            // most TB ops in any slot
-  };
-  static constexpr Table make() {
-    Table t{};
-    int o = 0;
-    for (int j = 0; j < 4; ++j) { t.type[o] = 0; t.a[o] = j; t.b[o] = 0; ++o; }
-    for (int g = 0; g < 4; ++g) {
-      int j = 0;
-      for (int m = 0; m < MR; ++m) {
-        t.type[o] = 1; t.a[o] = g; t.b[o] = m; ++o;
-        while (g < 3 && j < 4 && (m + 1) * 4 >= (j + 1) * MR) { t.type[o] = 0; t.a[o] = 4 * (g + 1) + j; t.b[o] = 0; ++o; ++j; }
-      }
-    }
-    for (int f = 0; f < N_FL; ++f) { t.type[o] = 2; t.a[o] = f; t.b[o] = 0; ++o; }
-    long long total = 0;
-    for (int i = 0; i < N_OPS; ++i) total += t.type[i] == 0 ? U_SC : (t.type[i] == 1 ? U_TB : U_FL);
-    const long long lead = total * LEAD_PCT / 100;
-    long long cum = 0;
-    int k = 0;
-    t.first[0] = 0;
-    for (int i = 0; i < N_OPS; ++i) {
-      int slot = cum < lead ? 0 : 1 + (int)((cum - lead) * NM / (total - lead));
-      if (slot > NSLOT - 1) slot = NSLOT - 1;
-      while (k < slot) { ++k; t.first[k] = i; }
-      cum += t.type[i] == 0 ? U_SC : (t.type[i] == 1 ? U_TB : U_FL);
-    }
-    while (k < NSLOT) { ++k; t.first[k] = N_OPS; }
-    t.max_tb = 1;  // rows are read one slot ahead only in slots with at most PREFETCH_CAP table ops
-    for (int q = 0; q < NSLOT; ++q) {
-      int c = 0;
-      for (int i = t.first[q]; i < t.first[q + 1]; ++i) c += t.type[i] == 1;
-      if (c <= PREFETCH_CAP && c > t.max_tb) t.max_tb = c;
-    }
-    return t;
-  }
-  static constexpr Table T = make();
-  // index (0-based) of TB op i among the TB ops of its own slot
-  static constexpr int tb_rank(int i, int k) {
-    int c = 0;
-    for (int q = T.first[k]; q < i; ++q) c += T.type[q] == 1;
-    return c;
-  }
-  static constexpr bool slot_prefetches(int k) {
-    int c = 0;
-    for (int q = T.first[k]; q < T.first[k + 1]; ++q) c += T.type[q] == 1;
-    return c <= PREFETCH_CAP;
-  }
-};
-
-// ABL (diagnostic builds only, never the product path): 1 = skip the matrix instructions, 2 = skip the vector work,
-// 3 = matrix instructions only with no global loads inside the loop, 4 = global loads only, 5 = vector work only (no loads in the
-// loop, no matrix instructions), 6 = full kernel that records a per-wave timeline into `partials` (tools/fused_timeline.py)
-template <int A_PAD, int MRW, int MRS, int SINCOS, int ABL = 0>
-__global__ __launch_bounds__(256, (MRW <= 12 && A_PAD <= 64 ? 2 : 1)) void k_fused_mfma(const f16x8* __restrict__ modes16, const f32x4* __restrict__ tabs_tile,
-                                                    const f32x4* __restrict__ psi_tile, const f16x8* __restrict__ act16,
-                                                    double* __restrict__ partials, MfmaGeom geo, float ratio) {
-  using PL = Plan<A_PAD, MRW, MRS, SINCOS>;
-  constexpr int NS = PL::NS, MR = PL::MR, NSTEP = PL::NSTEP, NM = PL::NM, NSLOT = PL::NSLOT;
-  constexpr int MAXTB = PL::T.max_tb;
-  constexpr bool kDeep = MRW <= 7 && A_PAD <= 64;   // two-deep screen prefetch + two unrolled stage bodies: only where registers allow
-  const long long t_kernel = ABL == 6 ? wall_clock64() : 0;
-  extern __shared__ f32x4 lds_tabs[];  // [tile in chunk][g][h][MR]
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int L = blockIdx.x;
-  const int j = L >> 3;
-  const int c = (j / geo.wg_y) * 8 + (L & 7);
-  if (c >= geo.P) return;  // whole workgroup: no barrier has been reached yet
-  const int we = geo.we, wp = 4 / we;                    // env tiles / pixel sub-chunks per workgroup
-  const int w_e = wave % we, w_p = wave / we;
-  const int etile = (j % geo.wg_y) * we + w_e;
-  const int t0 = (int)(((long long)c * geo.n_ptiles) / geo.P);
-  const int t1 = (int)(((long long)(c + 1) * geo.n_ptiles) / geo.P);
-
-  // Everything the first tile needs is requested BEFORE the chunk's tables are staged, so its latency overlaps the staging.
-  const int h = lane >> 5;
-  const int etile_c = min(etile, geo.n_etiles - 1);   // waves past the last env tile load in-bounds dummies and leave after the barrier
-  const int first = t0 + w_p;
-  const int n = first < t1 ? (t1 - first + wp - 1) / wp : 0;
-  const int last = n > 0 ? first + (n - 1) * wp : min(t0, geo.n_ptiles - 1);   // loads clamp to it: always a valid tile
-  f16x8 bh[NSTEP], bl[NSTEP];   // actuators of this env tile, hi / lo halves (B operand)
-  {
-    const f16x8* asrc = act16 + ((size_t)etile_c * NSTEP * 2) * 64 + lane;
-#pragma unroll
-    for (int s = 0; s < NSTEP; ++s) {
-      bh[s] = asrc[(2 * s) * 64];
-      bl[s] = asrc[(2 * s + 1) * 64];
-    }
-  }
-  const size_t psi_base = (size_t)etile_c * geo.n_ptiles;
-  auto load_modes = [&](f16x8 (&mh)[NSTEP], f16x8 (&ml)[NSTEP], int t) {
-    const f16x8* ms = modes16 + ((size_t)min(t, last) * NSTEP * 2) * 64 + lane;
-#pragma unroll
-    for (int s = 0; s < NSTEP; ++s) {
-      mh[s] = ms[(2 * s) * 64];
-      ml[s] = ms[(2 * s + 1) * 64];
-    }
-  };
-  auto load_psi = [&](int t) {
-    const f32x4* ps = psi_tile + ((psi_base + min(t, last)) * 4) * 64 + lane;
-    f32x16 d;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x4 v = ps[g * 64];
-      d[4 * g + 0] = v[0]; d[4 * g + 1] = v[1]; d[4 * g + 2] = v[2]; d[4 * g + 3] = v[3];
-    }
-    return d;
-  };
-  f16x8 mh[NSTEP], ml[NSTEP];
-  f32x16 p_first, p_next;
-  const bool hoist = geo.max_tiles >= 0;   // (negative: developer switch AOG_NO_HOIST)
-  if (hoist) {
-    load_modes(mh, ml, first);
-    p_first = load_psi(first);
-    p_next = load_psi(first + wp);   // the screen stream comes from HBM: kept TWO tiles ahead (the mode halves, shared by every
-                                     // env tile, are L2 hits and stay one tile ahead)
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  // stage this chunk's tables (contiguous in global memory) into LDS, 8 loads in flight per thread
-  {
-    const int n4 = (t1 - t0) * 8 * MR;
-    const f32x4* src = tabs_tile + (size_t)t0 * 8 * MR;
-    for (int i0 = threadIdx.x; i0 < n4; i0 += 8 * 256) {
-      f32x4 v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = src[min(i0 + u * 256, n4 - 1)];
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (i0 + u * 256 < n4) lds_tabs[i0 + u * 256] = v[u];
-    }
-  }
-  __syncthreads();
-  if (etile >= geo.n_etiles) return;
-  if (!hoist) {
-    load_modes(mh, ml, first);
-    p_first = load_psi(first);
-    p_next = load_psi(first + wp);
-  }
-  // Workgroups j and j + 32 of an XCD share a CU (two passes of the dispatcher over its 32 CUs) and would run in lock step: both
-  // waves of every SIMD issuing their 12 loads, then both doing vector work.  Half a stage of skew lets one wave's load issue
-  // overlap the other's arithmetic (a counted s_nop loop; s_sleep works as well).  NOTE: the table reduction below uses scalar
-  // FMAs and the library is built with -fno-slp-vectorize: a v_pk_fma_f32 reading the (cos, sin) pair straight from two
-  // transcendental results returned stale low halves in one lane quarter whenever another wave's MFMA co-executed at the wrong
-  // phase (reproducer tools/microbench/pk_fma_coexec.hip).
-  if constexpr (ABL == 0 || ABL >= 6) {
-    if ((j & 32) != 0 && kSkewNops > 0) {
-      for (int q = 0; q < kSkewNops; ++q) asm volatile("s_nop 15");
-    }
-  }
-
-  // Many-table variants keep NO float64 running sums (58 of them would be 116 registers and cost the second wave per SIMD):
-  // their fp32 pair sums run over the whole chunk, which the host keeps at <= kF32AccTiles tiles (<= 208 terms per lane;
-  // error budget in DESIGN.md), and are widened once at the end.
-  constexpr bool kF32Acc = MRW >= 20;
-  double acc[kF32Acc ? 1 : NS];
-#pragma unroll
-  for (int i = 0; i < (kF32Acc ? 1 : NS); ++i) acc[i] = 0.0;
-  // fp32 sums (cos * g at 2m, sin * g at 2m + 1).  Scalar FMAs on purpose: the packed form (v_pk_fma_f32 with a broadcast table
-  // value) produced wrong low halves in lanes 16-31 whenever the two waves of a SIMD ran out of phase.
-  float ts[NS];
-#pragma unroll
-  for (int i = 0; i < NS; ++i) ts[i] = 0.f;
-
-  // This wave's tiles: t0 + w_p + i*wp, i < n.  Stage i (all inside one wave):
-  //   issue the loads of tile i+1 (mode halves) and i+2 (screen), run slot 0 of tile i's vector work while they land, then the
-  //   NM matrix instructions of tile i+1 with the rest of tile i's vector work dealt behind them, then
-  //   d(i+1) = screen + D1 + 2^-11 D2.
-  if (n > 0) {
-    // matrix instruction q of a tile: s = q / 3; (Mh.ah -> D1), (Mh.al -> D2), (Ml.ah -> D2)
-    auto mfma_q = [&](auto qc, const f16x8 (&mh)[NSTEP], const f16x8 (&ml)[NSTEP], f32x16& d1, f32x16& d2) {
-      constexpr int q = decltype(qc)::v, s = q / 3, w = q % 3;
-      if constexpr (w == 0) d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[s], bh[s], d1, 0, 0, 0);
-      else if constexpr (w == 1) d2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[s], bl[s], d2, 0, 0, 0);
-      else d2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ml[s], bh[s], d2, 0, 0, 0);
-    };
-    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-
-    f32x16 d;                      // phases (revolutions at lambda_wfs) of the tile being reduced
-    bool flush = false;            // does the tile being reduced end a group of kFlushTiles?
-    long long tdbg[4] = {0, 0, 0, 0};
-    const long long t_enter = ABL == 6 ? wall_clock64() : 0;
-    f32x2 ew[2][4], es[2][4];      // (cos, sin) at the sensing / science wavelength of two register groups in flight
-    f32x4 gvb[2][MAXTB];           // table rows read one slot ahead
-
-    // one micro-op of the plan, on tile `d` with table rows at `lt`; k < 0: unplanned (rows read in place)
-    auto run_op = [&](auto oc, auto kc, const f32x4* lt) {
-      constexpr int o = decltype(oc)::v, k = decltype(kc)::v;
-      constexpr int type = PL::T.type[o], a = PL::T.a[o], bb = PL::T.b[o];
-      if constexpr (type == 0) {
-        constexpr int g = a >> 2, r = a & 3, par = g & 1;
-        const float u = d[a];
-        if constexpr (SINCOS == 2) {
-          ew[par][r] = f32x2{__builtin_amdgcn_cosf(u), __builtin_amdgcn_sinf(u)};
-          const float us = u * ratio;
-          es[par][r] = f32x2{__builtin_amdgcn_cosf(us), __builtin_amdgcn_sinf(us)};
-        } else {
-          float sn, cc;
-          sincos_rev<SINCOS>(u, sn, cc);
-          ew[par][r] = f32x2{cc, sn};
-          sincos_rev<SINCOS>(u * ratio, sn, cc);
-          es[par][r] = f32x2{cc, sn};
-        }
-      } else if constexpr (type == 1) {
-        constexpr int g = a, m = bb, par = g & 1;
-        f32x4 gv;
-        if constexpr (k >= 0 && PL::slot_prefetches(k >= 0 ? k : 0)) gv = gvb[k & 1][PL::tb_rank(o, k >= 0 ? k : 0)];
-        else gv = lt[(g * 2) * MR + m];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const f32x2 e = m < MRW ? ew[par][r] : es[par][r];
-          ts[2 * m] = fmaf(e[0], gv[r], ts[2 * m]);
-          ts[2 * m + 1] = fmaf(e[1], gv[r], ts[2 * m + 1]);
-        }
-      } else {
-        constexpr int lo = a * MR / PL::N_FL, hi = (a + 1) * MR / PL::N_FL;
-        if constexpr (kF32Acc) {
-          // nothing: the pair sums are widened after the last tile
-        } else if (kDeep ? flush : true) {   // wave-uniform: every kFlushTiles tiles (a run-time condition here costs the many-table variants ~300 registers: they flush every tile)
-#pragma unroll
-          for (int i = lo; i < hi; ++i) {
-            acc[2 * i] += (double)ts[2 * i];
-            acc[2 * i + 1] += (double)ts[2 * i + 1];
-            ts[2 * i] = 0.f;
-            ts[2 * i + 1] = 0.f;
-          }
-        }
-      }
-    };
-    // table rows of slot k's TB ops -> gvb[k & 1]
-    auto fetch_rows = [&](auto kc, const f32x4* lt) {
-      constexpr int k = decltype(kc)::v;
-      if constexpr (PL::slot_prefetches(k)) {
-        static_for<PL::T.first[k + 1] - PL::T.first[k]>([&](auto qc) {
-          constexpr int o = PL::T.first[k] + decltype(qc)::v;
-          if constexpr (PL::T.type[o] == 1) gvb[k & 1][PL::tb_rank(o, k)] = lt[(PL::T.a[o] * 2) * MR + PL::T.b[o]];
-        });
-      }
-    };
-    auto run_slot = [&](auto kc, const f32x4* lt) {
-      constexpr int k = decltype(kc)::v;
-      static_for<PL::T.first[k + 1] - PL::T.first[k]>([&](auto qc) { run_op(IC<PL::T.first[k] + decltype(qc)::v>{}, kc, lt); });
-    };
-    auto reduce_plain = [&](const f32x4* lt) {
-      static_for<PL::N_OPS>([&](auto oc) { run_op(oc, IC<-1>{}, lt); });
-    };
-    auto lds_row = [&](int t) { return lds_tabs + (size_t)(t - t0) * 8 * MR + h * MR; };
-
-    {  // first tile: nothing to overlap with (its operands were requested at kernel entry)
-      f32x16 d1 = zero16, d2 = zero16;
-      static_for<NM>([&](auto qc) { mfma_q(qc, mh, ml, d1, d2); });
-      d = d1 * kD1Unscale + (p_first + d2 * kD2Unscale);
-    }
-    if constexpr (ABL == 6) { asm volatile("" ::"v"(d[0])); tdbg[3] = wall_clock64(); }
-    // One stage: vector work of tile t, matrix work of tile t + wp; `p_use` already holds the screen of tile t + wp and the
-    // screen of tile t + 2 wp is requested into `p_load`.  The loop alternates the two register sets so that no copy (and with
-    // it no full drain of the loads just issued) sits between stages.
-    auto stage = [&](int i, int t, f32x16& p_use, f32x16& p_load) {
-      f32x16 d1 = zero16, d2 = zero16;
-      if constexpr (ABL == 3 || ABL == 5) {
-        p_use = d;
-      } else if constexpr (kDeep) {
-        load_modes(mh, ml, t + wp);       // consumed from slot 1 on
-        __builtin_amdgcn_sched_barrier(0);
-        p_load = load_psi(t + 2 * wp);    // issued AFTER the mode halves: vmcnt retires in order, and the matrix ops wait for those only
-      } else {
-        load_modes(mh, ml, t + wp);
-        if (i > 0) p_use = load_psi(t + wp);   // one tile ahead (tile `first + wp` was requested at kernel entry)
-      }
-      const f32x4* lt = lds_row(t);
-      flush = (i % kFlushTiles) == kFlushTiles - 1;
-      long long tq0 = 0;
-      if constexpr (ABL == 6) tq0 = wall_clock64();
-      if constexpr (ABL == 0 || ABL == 1 || ABL >= 5) {
-        fetch_rows(IC<0>{}, lt);
-        fetch_rows(IC<1>{}, lt);
-        run_slot(IC<0>{}, lt);
-      } else {
-        acc[0] += (double)d[0];   // (ablation builds only)
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (ABL == 6) { const long long tq = wall_clock64(); tdbg[0] += tq - tq0; tq0 = tq; }
-      static_for<NM>([&](auto qc) {
-        constexpr int q = decltype(qc)::v, k = q + 1;
-        if constexpr (ABL != 1 && ABL != 4 && ABL != 5) mfma_q(qc, mh, ml, d1, d2);
-        else asm volatile("" ::"v"(mh[q / 3]), "v"(ml[q / 3]));
-        if constexpr (ABL == 0 || ABL == 1 || ABL >= 5) {
-          if constexpr (k + 1 < NSLOT) fetch_rows(IC<k + 1>{}, lt);
-          run_slot(IC<k>{}, lt);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      });
-      d = d1 * kD1Unscale + (p_use + d2 * kD2Unscale);
-      if constexpr (ABL == 6) { asm volatile("" ::"v"(d[0])); tdbg[1] += wall_clock64() - tq0; }
-      if constexpr (ABL == 7) {   // self-check: the screen values just consumed against a fresh load of the same addresses
-        const f32x16 chk = load_psi(t + wp);
-        int bad = 0;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) bad += (chk[q] != p_use[q]) ? 1 : 0;
-        if (bad) printf("[fused chk] psi mismatch wg %d wave %d lane %d tile %d: %d of 16\n", (int)blockIdx.x, (int)(threadIdx.x >> 6), lane, t + wp, bad);
-      }
-    };
-    if constexpr (kDeep) {
-      f32x16 p_alt = zero16;
-      int i = 0, t = first;
-      for (; i + 2 < n; i += 2, t += 2 * wp) {
-        stage(i, t, p_next, p_alt);
-        stage(i + 1, t + wp, p_alt, p_next);
-      }
-      if (i + 1 < n) stage(i, t, p_next, p_alt);
-    } else {
-      // many-table variants (o >= 3) are register-bound: one stage body, the screen one tile ahead in a single register set
-      for (int i = 0, t = first; i + 1 < n; ++i, t += wp) stage(i, t, p_next, p_next);
-    }
-    if constexpr (ABL == 6) tdbg[2] = wall_clock64();
-    flush = true;
-    reduce_plain(lds_row(last));
-    if constexpr (ABL == 6) {
-      if ((threadIdx.x & 63) == 0) {   // timeline record (overwrites the partial sums: this build's results are meaningless)
-        long long* rec = reinterpret_cast<long long*>(partials) + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;
-        rec[0] = t_enter; rec[1] = tdbg[0]; rec[2] = tdbg[1]; rec[3] = tdbg[2]; rec[4] = wall_clock64(); rec[5] = t_kernel; rec[6] = tdbg[3];
-      }
-    }
-  }
-  // the two half waves hold different pixels of the same 32 envs: fold h=1 into h=0, then store
-  const int chunk = c * wp + w_p;
-  double* out = partials + (size_t)chunk * NS * geo.Bp + (size_t)etile * 32 + (lane & 31);
-#pragma unroll
-  for (int i = 0; i < NS; ++i) {
-    double a;
-    if constexpr (kF32Acc) a = (double)ts[i];
-    else a = acc[i];
-    const double v = a + __shfl_down(a, 32, 64);
-    if (h == 0) out[(size_t)i * geo.Bp] = v;
-  }
-}
-
 // ---- K3b'  fused pupil pass with BOTH contractions on the f16 matrix cores ("table-MFMA" form) ---------------------------------
-// Same phase stage as k_fused_mfma.  The table reduction  Z_m(env) = sum_p G_m(p) (cos, sin)(u_p,env)  is a second MFMA:
+// The phase stage is the K3b contraction above.  The table reduction  Z_m(env) = sum_p G_m(p) (cos, sin)(u_p,env)  is a second MFMA:
 //   A = table rows (m < 32) x 16 pixels, f16 hi + lo (unscaled: v_mfma keeps f16 subnormals, measured), pre-arranged on the host
 //       in the pixel order in which the phase accumulator hands its 16 values per lane to the B operand (tab16);
 //   B = cos / sin of this lane's 8 pixels of the step, f16 hi + lo;  Gh Eh + Gh El + Gl Eh accumulate into ONE fp32 accumulator.
@@ -985,211 +627,6 @@ __global__ __launch_bounds__(256, 2) void k_fused_tab(const f16x8* __restrict__ 
       out[(size_t)(2 * MRW) * geo.Bp] = (float)vc;
       out[(size_t)(2 * MRW + 1) * geo.Bp] = (float)vs;
     }
-  }
-}
-
-// ---- K3b''  the same two contractions on 16 x 16 x 16 matrix tiles: four waves per SIMD instead of two ---------------------------
-// k_fused_tab holds 232 registers (32 x 32 accumulators), two waves per SIMD, and on this hardware the vector unit's issue rate
-// scales with the number of resident waves (tools/microbench/valu_rates.hip: one instruction per 6 / 3 / 1.5 cycles with 1 / 2 / 4
-// waves per SIMD).  Here a wave owns a 16-pixel x 16-env sub-tile: 4-register accumulators, two-register operands, < 128 registers.
-// It reads the SAME operand arrays as k_fused_tab (host layouts are for the 32 x 32 x 16 instruction): a lane of the 16 x 16 x 16
-// operand (row or column = lane & 15, k = 4 (lane >> 4) + j) finds its four halves as one 8-byte piece of a 16-byte entry:
-//   mode / actuator operands : entry lane 32 (kg >> 1) + R0 + row,  halves 4 (kg & 1) ..     (k = 8 kgrp + e)
-//   table operands           : entry lane 32 (kg & 1) + m,          halves 4 (kg >> 1) ..    (pixel = 16 s + 8 (e >> 2) + 4 kgrp + (e & 3))
-//   screen / science rows    : float4 of group g = 2 s + (q >> 1), half h = q & 1, column C0 + c   (rows 8 g + 4 h + r = R0 + 4 q + r)
-// and the phase accumulator's layout (column = env, rows 4 q + r) IS the B-operand layout of the table product (k = pixel 4 q + j).
-// Workgroup = pixel chunk x two env tiles; wave w: env tile 2 eg + (w >> 1), env half C0 = 16 (w & 1); every wave walks all the
-// tiles of the chunk, both pixel halves.  The mode tile (8 KB per 32 pixels at 64 modes) is fetched ONCE per workgroup — global ->
-// registers while the previous tile is worked on, -> LDS, one barrier per tile — and the four waves read their operands from LDS:
-// with per-wave global loads the smaller tiles doubled the bytes through the L1 (64 B/clk) and the variant ran at 75 us.
-// Slabs as k_fused_tab's float64 variant: partials[chunk][s][env].
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-template <int A_PAD, int MRW, int ABL = 0>   // ABL: timing-only ablations (results meaningless): 1 no sin/cos, 2 no table products, 3 no phase products, 4 no tile barrier
-__global__ __launch_bounds__(256, 3) void k_fused_t16(const _Float16* __restrict__ modes16, const _Float16* __restrict__ tab16,
-                                                      const f32x4* __restrict__ sci_tile, const f32x4* __restrict__ psi_tile,
-                                                      const _Float16* __restrict__ act16, double* __restrict__ partials, MfmaGeom geo, float ratio) {
-  static_assert(MRW <= 8, "two table row groups of four");
-  constexpr int NSTEP = A_PAD / 16, NS = 2 * (MRW + 1);
-  constexpr int MODE_ENTRIES = NSTEP * 2 * 64;   // 16-byte entries of one 32-pixel mode tile (hi and lo halves)
-  extern __shared__ f32x4 lds_sci16[];   // science rows [tile in chunk][h][4] float4 | two mode-tile buffers [MODE_ENTRIES] x 16 B
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int L = blockIdx.x, j = L >> 3;
-  const int c = (j / geo.wg_y) * 8 + (L & 7);
-  if (c >= geo.P) return;
-  const int etile = (j % geo.wg_y) * 2 + (wave >> 1);
-  const int etile_c = min(etile, geo.n_etiles - 1);   // a padding tile computes on a copy of the last one and stores nothing
-  const int C0 = 16 * (wave & 1);
-  const int t0 = (int)(((long long)c * geo.n_ptiles) / geo.P);
-  const int t1 = (int)(((long long)(c + 1) * geo.n_ptiles) / geo.P);
-  const int nt = t1 - t0;
-  const int col = lane & 15, q = lane >> 4;
-  f16x8* lds_modes = reinterpret_cast<f16x8*>(lds_sci16 + (size_t)geo.max_tiles * 8);
-  // the mode tile of the chunk's first pixel tile goes to buffer 0 together with the science rows
-  constexpr int MPT = (MODE_ENTRIES + 255) / 256;   // 16-byte pieces of a mode tile per thread
-  auto fetch_modes = [&](f16x8 (&r)[MPT], int t) {
-    const f16x8* src = reinterpret_cast<const f16x8*>(modes16) + (size_t)min(t, t1 - 1) * MODE_ENTRIES;
-#pragma unroll
-    for (int u = 0; u < MPT; ++u) r[u] = src[min((int)threadIdx.x + 256 * u, MODE_ENTRIES - 1)];
-  };
-  auto stash_modes = [&](const f16x8 (&r)[MPT], int buf) {
-#pragma unroll
-    for (int u = 0; u < MPT; ++u)
-      if ((int)threadIdx.x + 256 * u < MODE_ENTRIES) lds_modes[(size_t)buf * MODE_ENTRIES + threadIdx.x + 256 * u] = r[u];
-  };
-  f16x8 mstage[MPT];
-  fetch_modes(mstage, t0);
-  {
-    const int n4 = nt * 8;
-    const f32x4* src = sci_tile + (size_t)t0 * 8;
-    for (int i = threadIdx.x; i < n4; i += 256) lds_sci16[i] = src[i];
-  }
-  // actuator operands of this wave's 16 envs: constant for the whole kernel
-  f16x4 bh[NSTEP], bl[NSTEP];
-  {
-    const _Float16* asrc = act16 + ((size_t)etile_c * NSTEP * 2) * 64 * 8 + (size_t)(32 * (q >> 1) + C0 + col) * 8 + 4 * (q & 1);
-#pragma unroll
-    for (int s = 0; s < NSTEP; ++s) {
-      bh[s] = *reinterpret_cast<const f16x4*>(asrc + (size_t)(2 * s) * 64 * 8);
-      bl[s] = *reinterpret_cast<const f16x4*>(asrc + (size_t)(2 * s + 1) * 64 * 8);
-    }
-  }
-  stash_modes(mstage, 0);
-  __syncthreads();
-  // per-lane pieces of the addresses
-  const int mode_lane = (32 * (q >> 1) + col) * 8 + 4 * (q & 1);       // halves inside a mode tile; + R0 * 8
-  const int tlane = (col <= MRW ? 32 * (q & 1) + col : 31) * 8 + 4 * (q >> 1);   // rows >= MRW are zero: one shared zero entry (row 31 of the first half)
-  const size_t psi_lane = (size_t)(q & 1) * 32 + C0 + col;
-  auto load_tab = [&](f16x4& th, f16x4& tl, int i) {
-    const int t = t0 + (i >> 1), sh = i & 1;
-    const _Float16* ts = tab16 + ((size_t)(t * 2 + sh) * 2) * 64 * 8 + tlane;
-    th = *reinterpret_cast<const f16x4*>(ts);
-    tl = *reinterpret_cast<const f16x4*>(ts + 64 * 8);
-  };
-  auto load_psi = [&](int i) {
-    const int t = t0 + (i >> 1), sh = i & 1;
-    return psi_tile[(((size_t)etile_c * geo.n_ptiles + t) * 4 + 2 * sh + (q >> 1)) * 64 + psi_lane];
-  };
-  // screen values and table operands of BOTH sub-tiles of a tile, one whole tile ahead (a sub-tile takes about one memory latency:
-  // requested one sub-tile ahead they arrived late every time)
-  f16x4 thc[2], tlc[2], thn[2], tln[2];
-  f32x4 psic[2], psin[2];
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  f32x4 Dc = zero4, Ds = zero4;
-  float sc_c = 0.f, sc_s = 0.f;
-  double acc_c[4] = {0, 0, 0, 0}, acc_s[4] = {0, 0, 0, 0}, acc_sc = 0, acc_ss = 0;
-  auto flush = [&] {
-    acc_sc += (double)sc_c; acc_ss += (double)sc_s;
-    sc_c = 0.f; sc_s = 0.f;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      acc_c[r] += (double)Dc[r];
-      acc_s[r] += (double)Ds[r];
-    }
-    Dc = zero4;
-    Ds = zero4;
-  };
-  const int n_sub = 2 * nt;
-  if (n_sub > 0) {
-#pragma unroll
-    for (int shf = 0; shf < 2; ++shf) {
-      load_tab(thc[shf], tlc[shf], shf);
-      psic[shf] = load_psi(shf);
-    }
-  }
-  for (int tt = 0; tt < nt; ++tt) {
-    // the next tile's modes travel (global -> registers) while this tile is worked on
-    fetch_modes(mstage, t0 + tt + 1);
-#pragma unroll
-    for (int shf = 0; shf < 2; ++shf) {
-      const int inext = min(2 * tt + 2 + shf, n_sub - 1);
-      load_tab(thn[shf], tln[shf], inext);
-      psin[shf] = load_psi(inext);
-    }
-    const _Float16* mbuf = reinterpret_cast<const _Float16*>(lds_modes + (size_t)(tt & 1) * MODE_ENTRIES) + mode_lane;
-#pragma unroll
-    for (int shf = 0; shf < 2; ++shf) {
-      f32x4 d1 = zero4, d2 = zero4;
-      {
-        f16x4 mh[NSTEP], ml[NSTEP];
-#pragma unroll
-        for (int s = 0; s < NSTEP; ++s) {
-          mh[s] = *reinterpret_cast<const f16x4*>(mbuf + shf * 16 * 8 + (2 * s) * 64 * 8);
-          ml[s] = *reinterpret_cast<const f16x4*>(mbuf + shf * 16 * 8 + (2 * s + 1) * 64 * 8);
-        }
-#pragma unroll
-        for (int s = 0; s < NSTEP; ++s) {
-          if constexpr (ABL == 3) {
-            d1[s & 3] += (float)mh[s][0] * (float)bh[s][0];
-            d2[s & 3] += (float)ml[s][1] * (float)bl[s][1];
-          } else {
-            d1 = __builtin_amdgcn_mfma_f32_16x16x16f16(mh[s], bh[s], d1, 0, 0, 0);
-            d2 = __builtin_amdgcn_mfma_f32_16x16x16f16(mh[s], bl[s], d2, 0, 0, 0);
-            d2 = __builtin_amdgcn_mfma_f32_16x16x16f16(ml[s], bh[s], d2, 0, 0, 0);
-          }
-        }
-      }
-      const f32x4 g = lds_sci16[tt * 8 + (q & 1) * 4 + 2 * shf + (q >> 1)];
-      f32x4 u;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) u[r] = d1[r] * kD1Unscale + (psic[shf][r] + d2[r] * kD2Unscale);
-      f16x4 ch, cl, sh, sl;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float us = u[r] * ratio;
-        float cw, sw, cs, ss;
-        if constexpr (ABL == 1) {
-          cw = u[r] * 0.5f; sw = u[r] * 0.25f; cs = us * 0.5f; ss = us * 0.25f;
-        } else {
-          cw = __builtin_amdgcn_cosf(u[r]); sw = __builtin_amdgcn_sinf(u[r]);
-          cs = __builtin_amdgcn_cosf(us); ss = __builtin_amdgcn_sinf(us);
-        }
-        sc_c = fmaf(cs, g[r], sc_c);
-        sc_s = fmaf(ss, g[r], sc_s);
-        const _Float16 chh = (_Float16)cw, shh = (_Float16)sw;
-        ch[r] = chh;
-        sh[r] = shh;
-        cl[r] = (_Float16)(cw - (float)chh);
-        sl[r] = (_Float16)(sw - (float)shh);
-      }
-      if constexpr (ABL == 2) {
-        Dc[0] += (float)ch[0] + (float)cl[1] + (float)thc[shf][0]; Ds[0] += (float)sh[2] + (float)sl[3] + (float)tlc[shf][0];
-      } else {
-      Dc = __builtin_amdgcn_mfma_f32_16x16x16f16(thc[shf], ch, Dc, 0, 0, 0);
-      Ds = __builtin_amdgcn_mfma_f32_16x16x16f16(thc[shf], sh, Ds, 0, 0, 0);
-      Dc = __builtin_amdgcn_mfma_f32_16x16x16f16(thc[shf], cl, Dc, 0, 0, 0);
-      Ds = __builtin_amdgcn_mfma_f32_16x16x16f16(thc[shf], sl, Ds, 0, 0, 0);
-      Dc = __builtin_amdgcn_mfma_f32_16x16x16f16(tlc[shf], ch, Dc, 0, 0, 0);
-      Ds = __builtin_amdgcn_mfma_f32_16x16x16f16(tlc[shf], sh, Ds, 0, 0, 0);
-      }
-    }
-    if ((tt & 3) == 3) flush();   // 128 terms per fp32 accumulator element between folds into float64
-    // publish the next tile's modes: its buffer was last read during tile tt - 1, which every wave has left (barrier below, one tile ago)
-    stash_modes(mstage, (tt + 1) & 1);
-#pragma unroll
-    for (int shf = 0; shf < 2; ++shf) {
-      thc[shf] = thn[shf];
-      tlc[shf] = tln[shf];
-      psic[shf] = psin[shf];
-    }
-    if constexpr (ABL != 4) __syncthreads();
-  }
-  flush();
-  if (etile >= geo.n_etiles) return;
-  double* out = partials + (size_t)c * NS * geo.Bp + (size_t)etile * 32 + C0 + col;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int m = 4 * q + r;
-    if (m < MRW) {
-      out[(size_t)(2 * m) * geo.Bp] = acc_c[r];
-      out[(size_t)(2 * m + 1) * geo.Bp] = acc_s[r];
-    }
-  }
-  double vc = acc_sc, vs = acc_ss;
-  vc += __shfl_xor(vc, 16, 64); vs += __shfl_xor(vs, 16, 64);
-  vc += __shfl_xor(vc, 32, 64); vs += __shfl_xor(vs, 32, 64);
-  if (q == 0) {
-    out[(size_t)(2 * MRW) * geo.Bp] = vc;
-    out[(size_t)(2 * MRW + 1) * geo.Bp] = vs;
   }
 }
 
@@ -1831,13 +1268,15 @@ __global__ __launch_bounds__(512) void k_extrude16(ExtrudeArgs p, int B) {
 // s_waitcnt vmcnt(0) -> __syncthreads -> lane 0: agent-scope release fence, ticket add on the group's counter, relaxed poll
 // (bounded) until all four tickets of this round are in, agent-scope acquire fence -> __syncthreads (cdna_hip_programming.md
 // Guideline 16, counter form).  Counters are zeroed by a memset ahead of every launch.  Workgroup L sits on XCD L % 8; the map
-// below keeps a group's four workgroups on one XCD (speed only).  A timed-out spin sets *status and the kernel still terminates.
+// below keeps a group's four workgroups on one XCD (speed only).  A timed-out spin sets *status and *host_flag (pinned host memory the
+// library polls without synchronising) and the kernel still terminates; aog_step / aog_reset then fail with AOG_ERR_STATE.
 constexpr int kExtParts = 4;
 __host__ __device__ inline int ext_split_stride(int n) { return ((n + 27) / 32) * 32 + 4; }   // smallest s >= n, s = 4 mod 32
 constexpr int kExtKsMax = 4;   // slices of the contraction per row block (template parameter KS: 4 KS waves per workgroup)
 #ifdef AOG_MAIN_TU
 template <int KS>
-__global__ __launch_bounds__(256 * KS) void k_extrude16_split(ExtrudeArgs p, int B, const int* __restrict__ perm, unsigned* __restrict__ bar, int* __restrict__ status) {
+__global__ __launch_bounds__(256 * KS) void k_extrude16_split(ExtrudeArgs p, int B, const int* __restrict__ perm, unsigned* __restrict__ bar, int* __restrict__ status,
+                                                              int* __restrict__ host_flag) {
   extern __shared__ double lds[];  // z [16][zs] | noise [16][ns] | partial sums [KS-1][4][256]
   constexpr int G = kExt16G;
   const int N = p.N;
@@ -2041,8 +1480,9 @@ __global__ __launch_bounds__(256 * KS) void k_extrude16_split(ExtrudeArgs p, int
       unsigned spins = 0;
       while (__hip_atomic_load(&bar[group], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         __builtin_amdgcn_s_sleep(2);
-        if (++spins > (1u << 24)) {   // ~seconds: a partner never arrived (not co-resident); flag it and carry on
-          atomicExch(status, 1);
+        if (++spins > (1u << 24)) {   // ~seconds: a partner never arrived (not co-resident).  The launch still terminates, but its
+          atomicExch(status, 1);      // screens are invalid: flag it on the device and in host-visible memory — the host refuses
+          __hip_atomic_store(host_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // every later call on the handle
           break;
         }
       }
@@ -2319,11 +1759,11 @@ __global__ void k_refresh_offsets(double* __restrict__ offset, double* __restric
 
 // ring buffer -> plain [B][N][N] (tests, checkpointing)
 __global__ void k_unroll_master(const double* __restrict__ master, const int32_t* __restrict__ origin, double* __restrict__ out,
-                                int B, int N) {
+                                int first, int count, int N) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (size_t)B * N * N) return;
-  const int env = (int)(idx / ((size_t)N * N));
-  const int flat = (int)(idx - (size_t)env * N * N);
+  if (idx >= (size_t)count * N * N) return;
+  const int env = first + (int)(idx / ((size_t)N * N));
+  const int flat = (int)(idx - (size_t)(env - first) * N * N);
   const int iy = flat / N, ix = flat - iy * N;
   int py = iy + origin[2 * env + 1], px = ix + origin[2 * env];
   if (py >= N) py -= N;
@@ -3052,6 +2492,17 @@ __global__ __launch_bounds__(256) void k_sh_estimate(ShEstimateArgs p) {
 #endif  // AOG_MAIN_TU
 
 #ifdef AOG_MAIN_TU
+// stored screens of envs [first, first + count) of a quasi_static / semi_dynamic handle as achromatic float64 [count][N*N] (hcipy's
+// unit: phase * lambda), exactly the values the fused kernel reads (fp32 revolutions widened: no rounding), 0 outside the aperture
+__global__ void k_screens_from_store(const float* __restrict__ psi_tile, const double* __restrict__ psi64, const int32_t* __restrict__ ap_index,
+                                     double* __restrict__ out, int first, int n_ap, int n_ptiles, int N2, double two_pi_lambda) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int env = first + blockIdx.y;
+  if (p >= n_ap) return;
+  const double v = psi64 ? psi64[(size_t)env * n_ap + p] : (double)psi_tile[psi_tile_index(env, p, n_ptiles)] * two_pi_lambda;
+  out[(size_t)blockIdx.y * N2 + ap_index[p]] = v;
+}
+
 // atmosphere phase (radians at lambda_wfs) of one env on the full grid, from the tiled fp32 screens
 __global__ void k_phase_screen(const float* __restrict__ psi_tile, const int32_t* __restrict__ ap_index, float* __restrict__ out, int env,
                                int n_ap, int n_ptiles) {

@@ -39,6 +39,16 @@ class AOEnv(env_base()):
         self.timestep = 0          # AO_env.py:70 — monotone across episodes
         self.episode_no = 0        # AO_env.py:71
         self.timestep_render = 0
+        # one pinned staging buffer each way: a step is ONE host-to-device copy (the action), the library's launches, ONE
+        # device-to-host copy of the packed outputs and ONE stream synchronisation
+        import torch
+
+        self._torch = torch
+        lay = e.persistent_outputs(True)
+        self._nb32, self._nb16 = lay["float32_bytes"], lay["float16_bytes"]
+        self._host_out = torch.empty((self._nb32 + self._nb16 + lay["uint8_bytes"],), dtype=torch.uint8).pin_memory()
+        self._host_act = torch.empty((1, e.num_modes), dtype=torch.float32).pin_memory()
+        self._dev_act = torch.empty((1, e.num_modes), dtype=torch.float32, device=e.device)
 
     def reset(self, seed=None, options=None):
         obs, info = self._env.reset()
@@ -47,16 +57,25 @@ class AOEnv(env_base()):
         return obs[0].cpu().numpy(), {}
 
     def step(self, action):
-        a = np.asarray(action, dtype=np.float32).reshape(1, self.num_modes)
-        obs, reward, done, trunc, info = self._env.step(a)
+        torch = self._torch
+        e = self._env
+        self._host_act.numpy()[...] = np.asarray(action, dtype=np.float32).reshape(1, self.num_modes)
+        self._dev_act.copy_(self._host_act, non_blocking=True)
+        e.step(self._dev_act)
+        self._host_out.copy_(e._pack, non_blocking=True)
+        torch.cuda.current_stream(e.device).synchronize()            # the step's only synchronisation
         self.timestep += 1
         self.timestep_render += 1
-        d = bool(done[0].item())
+        n = e.obs_dim ** 2
+        host = self._host_out.numpy()
+        f32 = host[:self._nb32].view(np.float32)                       # obs_raw [n] | reward | power | strehl
+        obs = host[self._nb32:self._nb32 + self._nb16].view(np.float16).copy()
+        d = bool(host[self._nb32 + self._nb16])
         if d:
             self.episode_no += 1
-        self.last_obs_raw = info["obs_raw"][0].cpu().numpy()
-        self.last_strehl = float(info["strehl"][0].item())
-        return obs[0].cpu().numpy(), float(reward[0].item()), d, False, {"power": float(info["power"][0].item())}
+        self.last_obs_raw = f32[:n].copy()
+        self.last_strehl = float(f32[n + 2])
+        return obs, float(f32[n]), d, False, {"power": float(f32[n + 1])}
 
     def render_data(self):
         """The three images the reference's render() draws (AO_env.py:156-194), as numpy arrays: atmospheric phase screen OPD in

@@ -196,7 +196,7 @@ def parity_check(env, w, actions, torch):
     _, _, _, _, info = env.step(actions)
     out = {"strehl_abs_err": 0.0, "obs_rel_err": 0.0, "envs": 2}
     for b in (0, env.num_envs - 1):
-        screen = env.phase_screen(b).double().cpu().numpy().ravel() * (w_lambda(env) / (2 * np.pi))   # radians at lambda_wfs -> phase * lambda
+        screen = env.get_screens(b, 1)[0].cpu().numpy().ravel()      # the stored screen, hcipy's unit (phase * lambda)
         ref = AOEnvOracle(atm_type="quasi_static", atm_fried=w["atm_fried"], act_type=w["act_type"], act_dim=w["act_dim"], obs_dim=w["obs_dim"],
                           rew_type=w["rew_type"], timesteps_per_episode=w["timesteps_per_episode"], num_pupil_pixels=w["n_pupil"],
                           screen=screen, verbose=False)
@@ -207,10 +207,6 @@ def parity_check(env, w, actions, torch):
         o, r = info["obs_raw"][b].double().cpu().numpy(), ref.last_obs_raw
         out["obs_rel_err"] = max(out["obs_rel_err"], float(np.max(np.abs(o - r) / np.maximum(np.abs(r), 1e-3 * r.max()))))
     return out
-
-
-def w_lambda(env):
-    return env.wavelength_wfs
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------

@@ -108,6 +108,10 @@ typedef struct {
 
 int aog_abi_version(void);
 const char* aog_last_error(void);
+/* sizeof() of the structs of this header as the library was compiled, so that a binding in another language can verify its own
+ * declarations at load time: which = 0 aog_config, 1 aog_tables, 2 aog_layer_tables, 3 aog_sh_tables, 4 aog_actor, 5 aog_info;
+ * -1 for any other value. */
+int64_t aog_struct_size(int which);
 
 /* AOEnv.__init__ (AO_env.py:17-71): allocate the handle and its state on `device`. */
 int aog_create(const aog_config* cfg, int device, aog_env** out);
@@ -151,8 +155,10 @@ int aog_set_wind(aog_env* env, const double* velocity_dev, double max_abs_compon
 int aog_set_extrusion_noise(aog_env* env, const double* noise_dev, int max_ext, void* stream);
 int aog_set_rng_seed(aog_env* env, uint64_t seed);
 
-/* layer._achromatic_screen of every env as plain [B][N][N] float64 (dynamic atmosphere only). */
-int aog_get_screens_f64(aog_env* env, double* psi_dev, void* stream);
+/* layer._achromatic_screen of envs [first, first + count) as plain [count][N][N] float64 (hcipy's unit: phase * lambda).  Dynamic
+ * handles return their float64 master screens; quasi_static / semi_dynamic handles return the stored screen exactly as the step
+ * kernels read it: aperture pixels only (0 outside), aperture mean removed, fp32 values widened without rounding. */
+int aog_get_screens_f64(aog_env* env, double* psi_dev, int first, int count, void* stream);
 
 /* layer.reset() / layer construction (AO_env.py:77, :370): synthesise new von Karman screens for envs [first, first+count) ON THE
  * DEVICE and install them — hcipy's FiniteAtmosphericLayer + SpectralNoiseFactoryFFT: complex normals on the (oversampling N)^2
@@ -202,10 +208,6 @@ int aog_set_state(aog_env* env, const void* blob_dev, int64_t timestep, void* st
  * atmosphere only (what render() shows as the phase screen, AO_env.py:87-88,128-129).  float32 [N*N]. */
 int aog_get_phase_screen(aog_env* env, int env_index, float* phase_dev, void* stream);
 
-/* Developer aid: copies the first nbytes of the fused kernel's partial-sum buffer to host memory (synchronises).  With the
- * AOG_ABLATE=6 diagnostic build of the fused kernel that buffer holds per-wave timeline records instead of sums. */
-int aog_debug_read_partials(aog_env* env, void* dst_host, size_t nbytes);
-
 /* Episode-return accumulation of the rollout (algorithm.py:509-510 sums the rewards of an episode on the host): when
  * returns_dev ([B] float32, caller-owned, device) is set, every aog_step also does returns_dev[env] += reward[env] (float32, the
  * same arithmetic as the caller's own `returns += reward`) in its last kernel.  NULL detaches.  The caller zeroes the buffer at
@@ -213,7 +215,9 @@ int aog_debug_read_partials(aog_env* env, void* dst_host, size_t nbytes);
 int aog_set_return_accumulator(aog_env* env, float* returns_dev);
 
 /* Synchronises the device and returns the handle's sticky device-side status word: 0 = fine, 1 = a bounded inter-workgroup wait
- * timed out (results of that step are invalid). */
+ * timed out (results of that step are invalid).  The library also watches the same flag through pinned host memory without
+ * synchronising: once it is set, aog_step and aog_reset fail with AOG_ERR_STATE (at the latest from the call after the one whose
+ * launch tripped it) until new screens are installed for the whole batch (aog_set_screens_*) or a state is restored. */
 int aog_device_status(aog_env* env, int32_t* status_out);
 
 /* deformable_mirror.actuators for all envs (metres; AO_env.py:116).  [B][A] float64 device pointers. */

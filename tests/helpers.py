@@ -44,3 +44,38 @@ def run_oracle(screens, actions_seq, **kw):
     for k in ("obs_raw", "obs", "reward", "done", "power", "strehl"):
         out[k] = np.stack([np.stack(p[k]) for p in per_env], axis=1)  # [T, B, ...]
     return out
+
+
+class ScriptedRNG:
+    """Stands in for the numpy legacy generator the oracle's InfiniteAtmosphericLayer draws from (hcipy's order: ``rand()`` wind
+    direction, ``geometric(0.5, n)`` twice for the stencils, then ``normal(0, 1, N)`` per extrusion), replaying values a device
+    run used: its wind draw, the batch's shared stencil draws and the normals handed to ``set_extrusion_noise``."""
+
+    def __init__(self, wind_u, geometric_draws, normals=()):
+        self._u = float(wind_u)
+        self._geo = [np.asarray(g) for g in geometric_draws]
+        self.normals = list(normals)     # rows are consumed front to back; the test appends each step's rows before stepping the oracle
+
+    def rand(self):
+        return self._u
+
+    def geometric(self, p, n):
+        g = self._geo.pop(0)
+        assert p == 0.5 and len(g) == n
+        return g
+
+    def normal(self, loc, scale, size):
+        row = np.asarray(self.normals.pop(0), dtype=np.float64)
+        assert loc == 0 and scale == 1 and row.shape == (size,)
+        return row
+
+    def randn(self, *a):
+        raise AssertionError("the scripted stream holds no screen normals: pass the oracle its initial screen")
+
+
+def device_mode_stencil_draws(seed, total_envs, n):
+    """The two ``geometric(0.5, n)`` stencil draws of a ``BatchedAOEnv(screen_source='device', seed=seed, total_envs=...)``: its
+    host stream is RandomState(seed): rand(total_envs) wind directions, then the draws of build_layer_tables."""
+    r = np.random.RandomState(seed)
+    r.rand(total_envs)
+    return [r.geometric(0.5, n), r.geometric(0.5, n)]

@@ -1,0 +1,265 @@
+"""Every BASELINE.json config at its STATED shape on the GPU, each with oracle contact: the full batch runs on the device, 3 sampled
+envs (first, middle, last) are read back (screens, actions, noise) and replayed through ``AOEnvOracle`` step by step; full-batch
+property checks ride along.  Tolerances are north_star's: observations before the float16 cast, Strehl and fiber power within 1e-5
+relative (``_assert_obs_close`` states the deep-null rule), ``done`` exact.
+
+  configs[1]  B=1024  quasi_static   N=256 A=64 o=2 strehl_ratio                         test_config2_*
+  configs[2]  B=4096  semi_dynamic   N=256 A=64 o=5, one episode incl. both resets       test_config3_*
+  configs[3]  B=1024  dynamic v=10   N=256 A=64 o=2, rollout with k_actor_act, 30 steps  test_config4_*   (per-GPU shard of 8192)
+  configs[4]  B=2048  N=512 zernike-20 o=5 smf_ssim SH_operation=True                    test_config5_*
+"""
+import numpy as np
+import pytest
+
+from helpers import ScriptedRNG, device_mode_stencil_draws
+from test_gpu_parity import RTOL, _assert_obs_close, _torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _sample_ids(B):
+    return [0, B // 2 - 1, B - 1]
+
+
+def _check_step(info, rew, done, ref, r_rew, r_done, r_info, b, strehl_reward):
+    _assert_obs_close(info["obs_raw"][b].double().cpu().numpy(), ref.last_obs_raw)
+    np.testing.assert_allclose(float(info["power"][b]), r_info["power"], rtol=RTOL)
+    if strehl_reward:
+        np.testing.assert_allclose(float(info["strehl"][b]), ref.last_strehl, rtol=RTOL)
+        np.testing.assert_allclose(float(rew[b]), r_rew, rtol=0, atol=100 * RTOL)
+    else:
+        np.testing.assert_allclose(float(rew[b]), r_rew, rtol=RTOL, atol=1e-7)
+    assert bool(done[b]) == r_done
+
+
+def test_config2_full_batch_sampled_envs_vs_oracle():
+    """configs[1] — what bench.py times: device-synthesised von Karman screens (r0 = 0.2, 16x oversampled), N(0, 0.5 I) actions."""
+    torch = _torch()
+    from adaptive_optics_gym_amd import BatchedAOEnv
+    from oracle.ao_env_oracle import AOEnvOracle
+
+    B, N, A, o, T = 1024, 256, 64, 2, 3
+    kw = dict(atm_type="quasi_static", atm_fried=0.2, act_type="num_actuators", act_dim=A, obs_dim=o, rew_type="strehl_ratio",
+              timesteps_per_episode=T)
+    env = BatchedAOEnv(B, "cuda:0", num_pupil_pixels=N, seed=1234, screen_source="device", verbose=False, **kw)
+    g = torch.Generator("cuda").manual_seed(10)
+    acts = torch.randn((T, B, A), device="cuda", generator=g) * 0.5 ** 0.5
+    ids = _sample_ids(B)
+    refs = {b: AOEnvOracle(num_pupil_pixels=N, screen=env.get_screens(b, 1)[0].cpu().numpy().ravel(), verbose=False, **kw) for b in ids}
+    env.reset()
+    for b in ids:
+        refs[b].reset()
+        _assert_obs_close(env.last_obs_raw[b].double().cpu().numpy(), refs[b].last_obs_raw)
+    for t in range(T):
+        obs, rew, done, _, info = env.step(acts[t])
+        assert float(info["strehl"].min()) >= 0 and float(info["strehl"].max()) <= 1 and bool(torch.isfinite(info["obs_raw"]).all())
+        assert bool(done.all()) == (t == T - 1) and bool(done.any()) == (t == T - 1)
+        for b in ids:
+            _, r_rew, r_done, _, r_info = refs[b].step(acts[t, b].cpu().numpy())
+            _check_step(info, rew, done, refs[b], r_rew, r_done, r_info, b, True)
+    env.close()
+
+
+def test_config3_one_episode_with_resets_sampled_envs_vs_oracle():
+    """configs[2]: 4096 envs, semi_dynamic (atm_vel=10 is coerced to 0 with the reference's message, AO_env.py:200-203), r0 = 0.15,
+    o = 5 — reset (new screens), the 20 steps of the episode, reset again (new screens).  The oracle's ``layer.reset()`` installs
+    the screen the device drew for that env (device synthesis is statistical parity only)."""
+    torch = _torch()
+    from adaptive_optics_gym_amd import BatchedAOEnv
+    from oracle.ao_env_oracle import AOEnvOracle
+
+    B, N, A, o, T = 4096, 256, 64, 5, 20
+    kw = dict(atm_type="semi_dynamic", atm_vel=10, atm_fried=0.15, act_type="num_actuators", act_dim=A, obs_dim=o, rew_type="strehl_ratio",
+              timesteps_per_episode=T)
+    env = BatchedAOEnv(B, "cuda:0", num_pupil_pixels=N, seed=7, screen_source="device", verbose=False, **kw)
+    assert env.velocity == 0
+    g = torch.Generator("cuda").manual_seed(10)
+    acts = torch.randn((T, B, A), device="cuda", generator=g) * 0.5 ** 0.5
+    ids = _sample_ids(B)
+    first_screens = env.get_screens(0, 1).clone()
+    refs = {}
+    for b in ids:
+        ref = AOEnvOracle(num_pupil_pixels=N, screen=np.zeros(N * N), verbose=False, **kw)
+        ref.layer.reset = (lambda r=ref, bb=b: setattr(r.layer, "_achromatic_screen", env.get_screens(bb, 1)[0].cpu().numpy().ravel()))
+        refs[b] = ref
+    for episode in range(2):
+        env.reset()                                     # layer.reset() for every env (AO_env.py:76-77)
+        for b in ids:
+            refs[b].reset()
+            _assert_obs_close(env.last_obs_raw[b].double().cpu().numpy(), refs[b].last_obs_raw)
+        if episode == 1:
+            break
+        assert not torch.equal(env.get_screens(0, 1), first_screens)      # the construction screen was replaced
+        ep_screen = env.get_screens(0, 1).clone()
+        for t in range(T):
+            obs, rew, done, _, info = env.step(acts[t])
+            for b in ids:
+                _, r_rew, r_done, _, r_info = refs[b].step(acts[t, b].cpu().numpy())
+                _check_step(info, rew, done, refs[b], r_rew, r_done, r_info, b, True)
+            assert bool(done.all()) == (t == T - 1) and bool(done.any()) == (t == T - 1)
+            assert float(info["strehl"].min()) >= 0 and float(info["strehl"].max()) <= 1 and bool(torch.isfinite(info["obs_raw"]).all())
+            assert torch.equal(obs, info["obs_raw"].to(torch.float16)) or \
+                int((obs.view(torch.int16).int() - info["obs_raw"].to(torch.float16).view(torch.int16).int()).abs().max()) <= 1
+        assert torch.equal(env.get_screens(0, 1), ep_screen)              # fixed within the episode
+    assert not torch.equal(env.get_screens(0, 1), ep_screen)              # and regenerated by the second reset
+    # the batch holds 4096 DIFFERENT atmospheres with the right statistics: phase variance over the aperture within 25 % of the mean
+    v = torch.stack([env.get_screens(s, 64).flatten(1).var(dim=1) for s in range(0, B, 64)]).flatten()
+    assert float(v.min()) > 0 and float(v.std() / v.mean()) > 0.1 and len(torch.unique(v)) == B
+    env.close()
+
+
+def test_config4_dynamic_rollout_shard_sampled_envs_vs_oracle():
+    """configs[3], one GPU's shard of the 8192-env batch (global envs 1024 .. 2047): dynamic atmosphere v = 10 m/s, random wind direction
+    per env, policy query by the fused actor kernel, 30-step episode.
+    Episode 1 hands the extrusion normals to the library (set_extrusion_noise) so that the oracle's InfiniteAtmosphericLayer can replay
+    them for the sampled envs: screens (float64, rtol 1e-9) and observations / Strehl / power every step.  Episode 2 is the product
+    default — rollout() on the device Philox stream — checked through its properties.  No inter-workgroup wait timed out."""
+    torch = _torch()
+    from adaptive_optics_gym_amd import BatchedAOEnv
+    from adaptive_optics_gym_amd.atmosphere_host import integer_shifts
+    from adaptive_optics_gym_amd.rollout import DeviceActor, make_actor, rollout
+    from oracle.ao_env_oracle import AOEnvOracle
+
+    B, N, A, o, T, total, offset, seed = 1024, 256, 64, 2, 30, 8192, 1024, 1234
+    kw = dict(atm_type="dynamic", atm_vel=10, atm_fried=0.15, act_type="num_actuators", act_dim=A, obs_dim=o, rew_type="strehl_ratio",
+              timesteps_per_episode=T)
+    env = BatchedAOEnv(B, "cuda:0", num_pupil_pixels=N, seed=seed, screen_source="device", verbose=False, global_env_offset=offset,
+                       total_envs=total, **kw)
+    torch.manual_seed(10)
+    actor = make_actor(o * o, A, 150, device="cuda:0")            # SAC actor: hidden 150 (main.py:170)
+    dev_actor = DeviceActor(actor, seed=10, env_id_base=offset)
+    ids = _sample_ids(B)
+    geo = device_mode_stencil_draws(seed, total, N)
+    refs = {}
+    for b in ids:
+        rng = ScriptedRNG(env.wind_u[b], [g.copy() for g in geo])
+        refs[b] = AOEnvOracle(num_pupil_pixels=N, screen=env.get_screens(b, 1)[0].cpu().numpy().ravel(), rng=rng, verbose=False, **kw)
+        np.testing.assert_allclose(refs[b].layer.velocity, env.velocity_vectors[b], rtol=1e-14)
+    obs, _ = env.reset()
+    for b in ids:
+        refs[b].reset()
+        _assert_obs_close(env.last_obs_raw[b].double().cpu().numpy(), refs[b].last_obs_raw)
+    gen = torch.Generator("cuda").manual_seed(99)
+    moved = 0
+    for t in range(T):
+        a, _, _ = dev_actor(obs, 0.5)
+        shifts = integer_shifts(env.velocity_vectors, env.timestep * env.delta_t, (env.timestep + 1) * env.delta_t, env.params.pupil_pixel)
+        counts = np.abs(shifts).sum(axis=1)
+        max_ext = int(counts.max())
+        assert 5 <= max_ext <= 9                                   # v dt / pitch = 5.12 px per step along the wind
+        noise = torch.randn((B, max_ext, N), device="cuda", dtype=torch.float64, generator=gen)
+        env.set_extrusion_noise(noise)
+        obs, rew, done, _, info = env.step(a)
+        for b in ids:
+            refs[b].rng.normals.extend(noise[b, :int(counts[b])].cpu().numpy())
+            before = refs[b].layer._achromatic_screen.copy()
+            _, r_rew, r_done, _, r_info = refs[b].step(a[b].cpu().numpy())
+            assert not refs[b].rng.normals
+            moved += int(not np.array_equal(before, refs[b].layer._achromatic_screen))
+            _check_step(info, rew, done, refs[b], r_rew, r_done, r_info, b, True)
+            if t in (0, T - 1):
+                scr = env.get_screens(b, 1)[0].cpu().numpy().ravel()
+                np.testing.assert_allclose(scr, refs[b].layer._achromatic_screen, rtol=1e-9, atol=1e-12 * np.abs(before).max())
+        assert float(info["strehl"].min()) >= 0 and float(info["strehl"].max()) <= 1 and bool(torch.isfinite(info["obs_raw"]).all())
+        assert bool(done.all()) == (t == T - 1)
+    assert moved == 3 * T
+    assert env.device_status() == 0
+    # episode 2: the rollout harness on the device Philox stream
+    prev = env.get_screens(0, 8).cpu().numpy()
+    sh = sum(integer_shifts(env.velocity_vectors[:8], (env.timestep + k) * env.delta_t, (env.timestep + k + 1) * env.delta_t, env.params.pupil_pixel)
+             for k in range(T))
+    out = rollout(env, actor, episodes=1, dev_actor=dev_actor)
+    assert out["obs"].shape == (T, B, o * o) and out["act"].shape == (T, B, A) and bool(torch.isfinite(out["rew"]).all())
+    assert bool(out["done"][T - 1].all()) and not bool(out["done"][:T - 1].any())
+    assert -100.0 <= out["avg_ep_rew"] <= 0.0
+    cur = env.get_screens(0, 8).cpu().numpy()
+    for b in range(8):                                             # interior pixels are copies of the screen 30 steps (~150 px) ago
+        dx, dy = int(sh[b, 0]), int(sh[b, 1])
+        shifted = np.roll(prev[b], shift=(-dy if dy > 0 else abs(dy), -dx if dx > 0 else abs(dx)), axis=(0, 1))
+        ys = slice(abs(dy), N) if dy < 0 else slice(0, N - abs(dy))
+        xs = slice(abs(dx), N) if dx < 0 else slice(0, N - abs(dx))
+        np.testing.assert_array_equal(cur[b][ys, xs], shifted[ys, xs])
+        assert 0.2 < cur[b].var() / prev[b].var() < 5.0
+    assert env.device_status() == 0
+    env.close()
+
+
+def test_config5_shack_hartmann_ssim_sampled_envs_vs_oracle():
+    """configs[4]: 2048 envs, 512 x 512 pupil, 20 Zernike modes, o = 5, smf_ssim reward, SH_operation=True.  Stage by stage for the
+    sampled envs, like the reference's loop (algorithm.py:253,262): noise-free sensor image; estimator + reconstructor + leaky integrator
+    fed with the ORACLE's photon-noisy image; the env step that applies the raw actuators (AO_env.py:115-116) and its SSIM reward.  Then the
+    whole batch closes the loop on the device photon-noise stream."""
+    torch = _torch()
+    from adaptive_optics_gym_amd import BatchedAOEnv
+    from oracle.ao_env_oracle import AOEnvOracle
+
+    B, N, A, o, T = 2048, 512, 20, 5, 20
+    kw = dict(atm_type="quasi_static", atm_fried=0.15, act_type="zernike", act_dim=A, obs_dim=o, rew_type="smf_ssim", timesteps_per_episode=T,
+              SH_operation=True)
+    env = BatchedAOEnv(B, "cuda:0", num_pupil_pixels=N, seed=21, screen_source="device", verbose=False, **kw)
+    ids = _sample_ids(B)
+    refs = {b: AOEnvOracle(num_pupil_pixels=N, screen=env.get_screens(b, 1)[0].cpu().numpy().ravel(), rng=np.random.RandomState(40 + b),
+                           verbose=False, **kw) for b in ids}
+    env.reset()
+    for b in ids:
+        refs[b].reset()
+        _assert_obs_close(env.last_obs_raw[b].double().cpu().numpy(), refs[b].last_obs_raw)
+    for t in range(3):
+        img = env.sh_image()                                       # [B, N*N] float64, noise-free
+        r_act = {}
+        for b in ids:
+            r_act[b], _ = refs[b].SH_step()
+            clean = refs[b].last_sh_image_noiseless
+            np.testing.assert_allclose(img[b].cpu().numpy(), clean, rtol=1e-5, atol=1e-7 * clean.max())
+            img[b] = torch.from_numpy(np.round(refs[b].last_sh_noisy)).to(img.device)   # replay the oracle's photon noise exactly
+        a = env.sh_update(img)
+        for b in ids:
+            np.testing.assert_allclose(a[b].cpu().numpy(), r_act[b], rtol=1e-6, atol=1e-6 * np.abs(r_act[b]).max())
+        obs, rew, done, _, info = env.step(a)
+        for b in ids:
+            _, r_rew, r_done, _, r_info = refs[b].step(r_act[b])
+            _check_step(info, rew, done, refs[b], r_rew, r_done, r_info, b, False)
+        assert bool(torch.isfinite(rew).all()) and not bool(done.any())
+    first = info["strehl"].clone()
+    for t in range(8):                                             # product path: photon noise from the handle's Philox stream
+        a, one = env.SH_step()
+        assert a.shape == (B, A) and a.dtype == torch.float64 and one.tolist() == [1]
+        obs, rew, done, _, info = env.step(a)
+    assert bool(torch.isfinite(rew).all()) and float(info["strehl"].max()) <= 1
+    assert float(info["strehl"].mean()) > float(first.mean())     # the leaky integrator keeps closing the loop
+    env.close()
+
+
+@pytest.mark.parametrize("r0", [0.4, 1.0])
+def test_weak_turbulence_five_by_five_observation_tolerance(r0):
+    """Strehl near 1: the outer pixels of the 5 x 5 observation sit 1e-5 .. 1e-6 below the peak.  Elements above 1e-3 of the peak hold
+    1e-5 relative; the deep nulls below that are held to the absolute error 2e-8 x peak (= 2x the general deep-null rule): they are
+    differences of O(1) sums, and the fp32 phases (2^-24 relative on u ~ 3 revolutions = 1e-6 rad) move them by that much — the
+    float64 oracle itself moves by more under a 1e-7 rad perturbation.  DESIGN.md section 2 states this bound."""
+    torch = _torch()
+    from adaptive_optics_gym_amd import BatchedAOEnv
+    from oracle.ao_env_oracle import AOEnvOracle
+
+    B, N, A, o = 64, 256, 64, 5
+    kw = dict(atm_type="quasi_static", atm_fried=r0, act_type="num_actuators", act_dim=A, obs_dim=o, rew_type="smf_ssim", timesteps_per_episode=5)
+    env = BatchedAOEnv(B, "cuda:0", num_pupil_pixels=N, seed=3, screen_source="device", verbose=False, **kw)
+    g = torch.Generator("cuda").manual_seed(1)
+    a = torch.randn((B, A), device="cuda", generator=g) * 0.5 ** 0.5
+    env.reset()
+    _, rew, _, _, info = env.step(a)
+    worst_rel, worst_null = 0.0, 0.0
+    for b in (0, 1, 31, 32, 63):
+        ref = AOEnvOracle(num_pupil_pixels=N, screen=env.get_screens(b, 1)[0].cpu().numpy().ravel(), verbose=False, **kw)
+        ref.reset()
+        _, r_rew, _, _, r_info = ref.step(a[b].cpu().numpy())
+        got, exp = info["obs_raw"][b].double().cpu().numpy(), ref.last_obs_raw
+        peak = exp.max()
+        big = exp >= 1e-3 * peak
+        worst_rel = max(worst_rel, float(np.max(np.abs(got[big] / exp[big] - 1))))
+        if (~big).any():
+            worst_null = max(worst_null, float(np.max(np.abs(got[~big] - exp[~big])) / peak))
+        np.testing.assert_allclose(float(info["power"][b]), r_info["power"], rtol=RTOL)
+        np.testing.assert_allclose(float(rew[b]), r_rew, rtol=RTOL, atol=1e-7)
+    assert worst_rel < RTOL, worst_rel
+    assert worst_null < 2e-8, worst_null
+    env.close()

@@ -249,36 +249,6 @@ def test_full_size_many_table_variants_vs_float64_kernel(N, A, o, rew):
     ref.close(); env.close()
 
 
-def test_sixteen_wide_tile_variant_vs_float64_kernel(monkeypatch):
-    """k_fused_t16 (opt-in, AOG_FUSED_T16=1): the same contractions on 16 x 16 x 16 matrix tiles at four waves per SIMD, reading
-    k_fused_tab's operand arrays through a different lane map.  130 envs = 5 env tiles: the last workgroup's second tile is padding."""
-    torch = _torch()
-    from adaptive_optics_gym_amd import BatchedAOEnv
-    from adaptive_optics_gym_amd.atmosphere_host import cn_squared_from_fried_parameter, screens_torch
-
-    N, B, A, o = 128, 130, 64, 2
-    dev = torch.device("cuda:0")
-    g = torch.Generator(dev).manual_seed(78)
-    scr = screens_torch(B, N, 0.5 / N, cn_squared_from_fried_parameter(0.15, 2.2e-6), 10.0, dev, g, oversampling=4)
-    a = torch.randn((B, A), device=dev, generator=g) * 0.7071
-    kw = dict(act_dim=A, obs_dim=o, rew_type="strehl_ratio", act_type="num_actuators", atm_fried=0.15, timesteps_per_episode=3,
-              num_pupil_pixels=N, verbose=False)
-    monkeypatch.delenv("AOG_FUSED_T16", raising=False)
-    ref = BatchedAOEnv(B, dev, screens=scr, precision="fp64", **kw)
-    tab = BatchedAOEnv(B, dev, screens=scr, kernel="mfma", **kw)
-    monkeypatch.setenv("AOG_FUSED_T16", "1")
-    env = BatchedAOEnv(B, dev, screens=scr, kernel="mfma", **kw)
-    ref.reset(); tab.reset(); env.reset()
-    _, _, _, _, r_info = ref.step(a)
-    _, _, _, _, t_info = tab.step(a)
-    _, _, _, _, info = env.step(a)
-    _assert_obs_close(info["obs_raw"].cpu().numpy(), r_info["obs_raw"].cpu().numpy())
-    assert torch.max(torch.abs(info["strehl"].double() / r_info["strehl"].double() - 1)) < RTOL
-    assert torch.max(torch.abs(info["power"].double() / r_info["power"].double() - 1)) < RTOL
-    assert not torch.equal(info["obs_raw"], t_info["obs_raw"])     # (a different kernel did run: other summation order)
-    ref.close(); tab.close(); env.close()
-
-
 @pytest.mark.parametrize("o", [2, 5])
 def test_fast_kernel_is_repeatable_at_full_size(o):
     """Identical launches give identical bits (B = 1024, N = 256: two workgroups per CU, skewed start).  Regression test for a
@@ -676,34 +646,6 @@ def test_dynamic_extrusion_kernel_variants_agree(monkeypatch):
             s_split = s_other
         elif mode == "AOG_EXTRUDE_NOSPLIT":
             np.testing.assert_allclose(s_other, s_split, rtol=1e-12, atol=1e-14 * np.abs(s_split).max())
-
-
-@pytest.mark.parametrize("precision", ["fast", "fp64"])
-def test_focal_image_matches_literal_propagation(precision):
-    """K4: the materialised 128x128 focal field == the oracle's propagator_fiber output (AO_env.py:138), and projecting it
-    on the LP modes (the reference's literal fiber path, AO_env.py:471-474) == the power the fused kernel reports."""
-    torch = _torch()
-    from adaptive_optics_gym_amd import BatchedAOEnv
-    from oracle.ao_env_oracle import AOEnvOracle
-
-    N, B, A = 64, 2, 16
-    scr = smooth_screens(B, N, 8)
-    a = actions_for(B, A, 2)
-    kw = dict(act_dim=A, obs_dim=2, timesteps_per_episode=5)
-    env = BatchedAOEnv(B, "cuda:0", num_pupil_pixels=N, screens=scr, precision=precision, verbose=False, **kw)
-    env.reset()
-    _, _, _, _, info = env.step(torch.from_numpy(a).cuda())
-    for b in range(B):
-        ref = AOEnvOracle(num_pupil_pixels=N, screen=scr[b].ravel(), verbose=False, **kw)
-        ref.reset()
-        ref.step(a[b])
-        F = env.focal_image(b).cpu().numpy().astype(np.complex128)
-        power = np.abs(F) ** 2 * env.tables.focal_pixel_area
-        ref_power = ref.wf_wfs_after_foc.power.reshape(128, 128)
-        np.testing.assert_allclose(power, ref_power, rtol=1e-4, atol=1e-6 * ref_power.max())
-        coef = (env.tables.lp_modes * F[None]).sum(axis=(1, 2)) * env.tables.focal_pixel_area
-        np.testing.assert_allclose(np.sum(np.abs(coef) ** 2), float(info["power"][b]), rtol=2e-5)
-    env.close()
 
 
 def test_dynamic_round_kernel_equals_per_env_kernel(monkeypatch):

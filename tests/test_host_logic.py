@@ -108,8 +108,12 @@ def test_cabi_exports_every_declared_symbol(repo_root):
         assert hasattr(lib, name), name
     assert lib.aog_abi_version() == _lib.ABI_VERSION
     assert re.search(r"#define AOG_ABI_VERSION\s+%d" % _lib.ABI_VERSION, header)
-    assert ctypes.sizeof(_lib.AogConfig) == 18 * 4 + 6 * 8
+    assert ctypes.sizeof(_lib.AogConfig) == 20 * 4 + 6 * 8
     assert ctypes.sizeof(_lib.AogInfo) == 10 * 4 + 8
+    # every struct of the header has the size the library was compiled with (the loader checks the same at import)
+    for which, cls in enumerate((_lib.AogConfig, _lib.AogTables, _lib.AogLayerTables, _lib.AogShTables, _lib.AogActor, _lib.AogInfo)):
+        assert lib.aog_struct_size(which) == ctypes.sizeof(cls), cls.__name__
+    assert lib.aog_struct_size(99) == -1
 
 
 def test_device_path_fails_loudly_without_gpu():
