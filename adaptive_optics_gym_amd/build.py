@@ -35,13 +35,17 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in DEPS)
 
 
-def build(force: bool = False, verbose: bool = True, fast: bool = False) -> str:
-    """fast=True builds only the 8-table kernels (developer iteration); the default builds everything."""
+def build(force: bool = False, verbose: bool = True, fast: bool = False, dev: bool = False) -> str:
+    """fast=True builds only the 8-table kernels (developer iteration); dev=True (or AOG_DEV=1 in the environment at build time)
+    compiles the developer switches in (-DAOG_DEV: placement / skew overrides read from the environment, timing read-outs); the
+    default product build has none of them."""
     if not force and not needs_build():
         return OUT
     hipcc = hipcc_path()
     os.makedirs(OBJ, exist_ok=True)
     extra = ["-DAOG_FAST_BUILD"] if fast else []
+    if dev or os.environ.get("AOG_DEV") == "1":
+        extra.append("-DAOG_DEV")
     jobs = [([hipcc, *FLAGS, *extra, "-c", os.path.join(CSRC, "aogym.hip"), "-o", os.path.join(OBJ, "aogym.o")])]
     for a in APADS:
         jobs.append([hipcc, *FLAGS, *extra, f"-DAOG_INST_APAD={a}", "-c", os.path.join(CSRC, "fused_inst.hip"), "-o",
@@ -60,5 +64,5 @@ def build(force: bool = False, verbose: bool = True, fast: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    build(force=True, fast="--fast" in sys.argv)
+    build(force=True, fast="--fast" in sys.argv, dev="--dev" in sys.argv)
     print(OUT)

@@ -48,6 +48,14 @@ struct DevBuf {
 }  // namespace
 
 
+#ifdef AOG_DEV
+namespace aog_host { long long* dev_timeline = nullptr; }
+extern "C" int aog_dev_read_timeline(void* dst, size_t nbytes) {   // developer builds only: not in include/aogym.h
+  if (!aog_host::dev_timeline) return -1;
+  if (hipDeviceSynchronize() != hipSuccess) return -2;
+  return hipMemcpy(dst, aog_host::dev_timeline, nbytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+}
+#endif
 namespace aog_host {
 int ensure_dynamic_lds(const void* fn, size_t bytes, int device) {
   if (bytes <= 64 * 1024) return AOG_OK;   // the default limit
@@ -430,11 +438,16 @@ int aog_create(const aog_config* cfg, int device, aog_env** out) {
     e->valu_qpc = qpc;
     e->valu_chunks = (e->n_quads + qpc - 1) / qpc;
     e->mfma_we = e->n_etiles >= 4 ? 4 : (e->n_etiles >= 2 ? 2 : 1);
-    const int wp = 4 / e->mfma_we;
+    // Asymmetric wave pairs (see k_fused_tab): the float64-flush variant with at least 4 env tiles runs 8-wave workgroups, one per
+    // CU, whose two pixel sub-chunks split a chunk about 2 : 1 with the priority on the larger share; the many-table variants keep the
+    // 4-wave interleaved form (their chunks are short and come in many rounds, which balances itself).
+    const bool asym = e->kernel == AOG_KERNEL_MFMA && e->MRW <= 8 && e->n_etiles >= 4;
+    e->mfma_waves = asym ? 8 : 4;
+    e->mfma_heavy = asym ? 672 : 0;
+    const int wp = e->mfma_waves / e->mfma_we;
     const int wg_y = (e->n_etiles + e->mfma_we - 1) / e->mfma_we;
-    // P pixel chunks (proportional split of the tiles), 2 workgroups per CU when the batch allows; the table stage of a
-    // chunk must fit 60 KiB of LDS
-    int Pm = cfg->pixel_chunks > 0 ? cfg->pixel_chunks : std::max(1, (256 * 2) / wg_y);
+    // P pixel chunks (proportional split of the tiles), 8 waves per CU when the batch allows
+    int Pm = cfg->pixel_chunks > 0 ? cfg->pixel_chunks : std::max(1, (asym ? 256 : 256 * 2) / wg_y);
     const int max_tpc = e->MRW > 8 ? aog::kTabF32Tiles * wp : 4096;   // fp32-only sums (many-table variants): bounded chunks
     Pm = std::max(Pm, (e->n_ptiles + max_tpc - 1) / max_tpc);
     Pm = std::min(Pm, e->n_ptiles);

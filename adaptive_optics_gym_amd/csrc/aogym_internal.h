@@ -22,6 +22,8 @@ struct aog_env {
   // launch geometry
   int valu_chunks = 0, valu_qpc = 0;
   int mfma_we = 1, mfma_chunks_x = 0, mfma_tpc = 0;
+  int mfma_waves = 4;            // waves per workgroup of k_fused_tab (8 with asymmetric pairs)
+  int mfma_heavy = 0;            // asymmetric wave pairs: share (x / 1024) of a chunk's tiles that the prioritised sub-chunk takes; 0 = off
   int n_chunks = 0;              // partial slabs the epilogue sums
   int64_t dev_bytes = 0;
   // constant tables
@@ -132,6 +134,9 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 // hipFuncAttributeMaxDynamicSharedMemorySize belongs to the FUNCTION (per device), not to a handle: remember the largest request
 // made for each (function, device) in this process and only ever raise it, so that handles of different shapes coexist.
 int ensure_dynamic_lds(const void* fn, size_t bytes, int device);
+#ifdef AOG_DEV
+extern long long* dev_timeline;   // per-wave time stamps of the last fused launch (AOG_DEV_TIMELINE=1)
+#endif
 // Fused-kernel launchers, one translation unit per padded mode count so the build parallelises
 // (fused_inst.hip compiled with -DAOG_INST_APAD=16|32|64|128).
 void launch_fused_apad16(aog_env* e, hipStream_t s);

@@ -49,7 +49,7 @@ __device__ __forceinline__ void sincos_rev(float u, float& s, float& c) {
 // K0  pack_screens: achromatic screens [count][N][N] (T = double|float) -> internal layouts.
 //   psi_rev   fp32, revolutions at lambda_wfs, aperture mean removed, layout [quad q][env][4]
 //             (lane = env reads one float4 = 4 consecutive packed pixels; 1 KiB per wave instruction)
-//   psi_tile  fp32, same values in MFMA accumulator order (see k_fused_mfma)
+//   psi_tile  fp32, same values in MFMA accumulator order (see k_fused_tab)
 //   psi64     (validation mode) float64 [env][n_ap], aperture mean removed, hcipy units
 // One workgroup per env.
 // ------------------------------------------------------------------------------------------------
@@ -118,13 +118,13 @@ __global__ __launch_bounds__(256) void k_pack_screens(const T* __restrict__ psi,
   }
 }
 
-// one actuator value (revolutions) -> the hi/lo f16 B-operand layout of k_fused_mfma:
+// one actuator value (revolutions) -> the hi/lo f16 B-operand layout of k_fused_tab:
 //   act16[env tile][s = i/16][hi|lo][lane = 32*((i/8)&1) + env%32][i%8]   (A_pad is a multiple of 16 for this layout)
 __device__ __forceinline__ void store_act16(_Float16* __restrict__ act16, int env, int i, int A_pad, float ar) {
   if (act16 == nullptr || (A_pad & 15)) return;
   const float sc = ar * 256.0f;  // kActScale
   const _Float16 hi = (_Float16)sc;
-  const _Float16 lo = (_Float16)((sc - (float)hi) * 2048.0f);
+  const _Float16 lo = (_Float16)(sc - (float)hi);   // unscaled low half (see split_f16)
   const int s = i >> 4, h = (i >> 3) & 1, e = i & 7, nstep = A_pad >> 4;
   const size_t base = (((size_t)(env >> 5) * nstep + s) * 2) * 64 + (h * 32 + (env & 31));
   act16[base * 8 + e] = hi;
@@ -292,48 +292,69 @@ __global__ __launch_bounds__(256) void k_fused_valu(const float* __restrict__ mo
 }
 
 // ------------------------------------------------------------------------------------------------
-// K3b  fused pupil pass, MFMA form.  One wave owns a 32-env tile and walks 32-pixel tiles:
-//     D[pixel i][env j] = psi[i][j] + sum_k Mt[i][k] * a[k][j]                         (K = A_PAD modes)
+// K3b  fused pupil pass on the f16 matrix cores.  One wave owns a 32-env tile and walks 32-pixel tiles:
+//     u[pixel i][env j] = psi[i][j] + sum_k Mt[i][k] * a[k][j]                         (K = A_PAD modes)
 // The contraction runs on the f16 matrix cores with BOTH operands split in two halves that together carry
-// fp32 precision:   x = x_hi + 2^-11 x_lo,  x_hi = half(x),  x_lo = half((x - x_hi) * 2^11)   (|x - x_hi - 2^-11 x_lo| <= 2^-24 |x|)
-//     D1 = Mh.ah           D2 = Mh.al + Ml.ah           u = psi + c1 D1 + c2 D2        (the 2^-22 Ml.al term is dropped)
+// fp32 precision:   x = x_hi + x_lo,  x_hi = half(x),  x_lo = half(x - x_hi)   (the matrix pipe keeps f16 subnormals, measured:
+// tools/microbench/mfma_f16_denorm.hip — so the low halves need no scale of their own and ALL products share one accumulator)
+//     D = Mh.ah + Mh.al + Ml.ah           u = psi + 2^-22 D                      (the 2^-22-relative Ml.al term is dropped)
 // = 3 x v_mfma_f32_32x32x16_f16 per 16 modes, products exact in fp32, fp32 accumulation.  Unlike v_mfma_f32_32x32x2_f32
 // (which was measured NOT to overlap with vector instructions: fused = vector-only + matrix-only time, profiles/r01), the
-// f16 matrix pipe co-executes with the VALU, so the kernel is bounded by its sincos/accumulate vector work.
+// f16 matrix pipe co-executes with the VALU.
 // C/D register map: lane l holds env j = l&31 and pixels i = (r&3) + 8*(r>>2) + 4*(l>>5), r < 16.
 //   psi_tile   [env tile][pixel tile][g=r>>2][lane][r&3]        one float4 per lane per g, 1 KiB per instruction
 //   modes16    [pixel tile][s][hi|lo][lane][8 halfs]: lane (pixel i = l&31, h = l>>5), element e <-> mode 16 s + 8 h + e
 //   act16      [env tile][s][hi|lo][lane][8 halfs]:   lane (env j = l&31, h),          element e <-> mode 16 s + 8 h + e
-//   tabs_tile  [pixel tile][g][h][MRW+MRS][4]: per-pixel tables, identical for the 32 lanes of a half wave;
-//              staged in LDS once per workgroup and read back with broadcast ds_read_b128.
 // ------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-// Operands are pre-scaled into the middle of the f16 range so that neither half is ever subnormal for values that matter:
-//   modes (|M| <= 1) by 2^14, actuators in revolutions (|a| < 255) by 2^8;  u = psi + 2^-22 D1 + 2^-33 D2.
-constexpr float kLoScale = 2048.0f;                  // 2^11
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// Operands are pre-scaled into the middle of the f16 range: modes (|M| <= 1) by 2^14, actuators in revolutions (|a| < 255) by 2^8;
+// a low half is half(x - hi) at the same scale (<= 2^-11 |hi|, subnormal below 2^-14: absolute error <= 2^-25 there, i.e. <= 2^-39 of
+// a unit mode value and <= 2^-33 revolutions of an actuator).  u = psi + 2^-22 D.
 constexpr float kModeScale = 16384.0f;               // 2^14
 constexpr float kActScale = 256.0f;                  // 2^8
-constexpr float kD1Unscale = 1.0f / (16384.0f * 256.0f);           // 2^-22
-constexpr float kD2Unscale = 1.0f / (16384.0f * 256.0f * 2048.0f); // 2^-33
+constexpr float kPhaseUnscale = 1.0f / (16384.0f * 256.0f);        // 2^-22
 
-// x (already multiplied by its operand scale) -> hi + 2^-11 lo
+// x (already multiplied by its operand scale) -> hi + lo
 __device__ __host__ inline void split_f16(float x, _Float16& hi, _Float16& lo) {
   hi = (_Float16)x;
-  lo = (_Float16)((x - (float)hi) * kLoScale);
+  lo = (_Float16)(x - (float)hi);
 }
 
-// Launch geometry of k_fused_mfma (host side fills it; see aog_create):
+// Launch geometry of k_fused_tab (host side fills it; see aog_create):
 //   1-D grid of 8 * ceil(P/8) * wg_y workgroups.  Workgroup L runs on XCD L % 8 (round-robin dispatch, speed only):
 //   xcd = L & 7, j = L >> 3, env group = j % wg_y, pixel chunk c = (j / wg_y) * 8 + xcd, so the wg_y workgroups that
 //   share a pixel chunk (= the same mode-matrix and table tiles) sit on ONE XCD back to back and each XCD's L2 only ever
 //   sees 1/8 of the mode matrix.  Chunk c owns pixel tiles [c*n_ptiles/P, (c+1)*n_ptiles/P).
 struct MfmaGeom {
   int n_ptiles, n_etiles, Bp, P, wg_y, we, max_tiles;
-  int skew;   // start-up skew of every second workgroup, x 16 cycles (kSkewNops unless the developer override AOG_SKEW_NOPS is set)
+  int skew;   // start-up skew of every second workgroup, x 16 cycles
+  int pair;   // 1: the two workgroups that share a CU walk the SAME pixel chunk (different env groups), see fused_wg_map
+  int heavy;  // > 0: asymmetric wave pairs, sub-chunk 0 takes heavy / 1024 of a chunk's tiles (see k_fused_tab); 0: interleaved
+  int dev;    // developer experiments (AOG_DEV builds only; 0 in the product)
+  long long* timeline;   // AOG_DEV builds: per-wave time stamps (wall_clock64, 10 ns ticks) [wave][8], or null
 };
+
+// workgroup L -> (pixel chunk c, env group eg).  Workgroup L runs on XCD L % 8; inside an XCD workgroups j = L >> 3 fill the 32 CUs
+// round-robin, two per CU (j and j + 32 share a CU).  pair = 0: eg = j % wg_y, c = (j / wg_y) * 8 + xcd (the wg_y workgroups of a
+// chunk sit on wg_y different CUs).  pair = 1 (wg_y even and a divisor of 64): the two workgroups of a CU take the same chunk, so the
+// eight waves of a CU pull one copy of the chunk's mode / table operands through the CU's L1 instead of two.  Placement is a speed
+// matter only: every (chunk, env group) pair is covered exactly once either way.
+__device__ __forceinline__ void fused_wg_map(const MfmaGeom& geo, int L, int& c, int& eg) {
+  const int j = L >> 3, xcd = L & 7;
+  if (geo.pair) {
+    const int cpr = 64 / geo.wg_y;            // chunks per round of 64 workgroups (32 CUs x 2)
+    const int r = j >> 6, k = j & 31, half = (j >> 5) & 1;
+    c = (r * cpr + k % cpr) * 8 + xcd;
+    eg = k / cpr + (geo.wg_y >> 1) * half;
+  } else {
+    c = (j / geo.wg_y) * 8 + xcd;
+    eg = j % geo.wg_y;
+  }
+}
 
 // compile-time loops (indices usable as template arguments)
 template <int K>
@@ -349,13 +370,15 @@ constexpr int kFlushTiles = 4;
 constexpr int kTabF32Tiles = 13;
 constexpr int kSkewNops = 150;   // x 16 cycles: start-up skew of the second workgroup of a CU (about half a stage)
 
-// ---- K3b'  fused pupil pass with BOTH contractions on the f16 matrix cores ("table-MFMA" form) ---------------------------------
-// The phase stage is the K3b contraction above.  The table reduction  Z_m(env) = sum_p G_m(p) (cos, sin)(u_p,env)  is a second MFMA:
-//   A = table rows (m < 32) x 16 pixels, f16 hi + lo (unscaled: v_mfma keeps f16 subnormals, measured), pre-arranged on the host
-//       in the pixel order in which the phase accumulator hands its 16 values per lane to the B operand (tab16);
+// ---- the fused kernel: BOTH contractions on the f16 matrix cores --------------------------------------------------------------
+// Phase stage as above.  The table reduction  Z_m(env) = sum_p G_m(p) (cos, sin)(u_p,env)  is a second MFMA:
+//   A = table rows (m < 32) x 16 pixels, f16 hi + lo (unscaled), pre-arranged on the host in the pixel order in which the phase
+//       accumulator hands its 16 values per lane to the B operand (tab16);
 //   B = cos / sin of this lane's 8 pixels of the step, f16 hi + lo;  Gh Eh + Gh El + Gl Eh accumulate into ONE fp32 accumulator.
-// Per (pixel, env) the vector unit only does the 4 sin/cos, the hi/lo split (6 ops) and the two science-table FMAs, instead of
-// 2 (MRW + 1) FMAs; the matrix pipe (idle 85 % of the time in k_fused_mfma) takes 12 more instructions per tile.
+// Vector work per (pixel, env): u = fma(D, 2^-22, psi), u_sci = u * ratio, 4 hardware sin/cos (they take revolutions), the two
+// science-table FMAs, and the hi/lo split of cos and sin as  hi = x & 0xffffe000 (an fp32 with 11 significant bits: exact in f16),
+// lo = x - hi, two values packed per v_cvt_pkrtz_f16_f32 — 3 ops per component instead of the 5 of convert / convert back /
+// subtract / convert / pack.
 // Sums: tables m < MRW in the 32x32 accumulators (lane (env, h) holds rows (a & 3) + 8 (a >> 2) + 4 h); the 8-table variant
 // folds its (few) live rows into float64 every kFlushTiles tiles, the others run fp32 over a chunk of bounded length.
 template <int MRW>
@@ -363,8 +386,11 @@ struct TabGeom {
   static constexpr int kLiveRegs = MRW <= 8 ? 4 : (MRW <= 16 ? 8 : (MRW <= 24 ? 12 : 16));   // accumulator registers a < kLiveRegs hold real tables
   static constexpr bool kF64 = MRW <= 8;
 };
+__device__ __forceinline__ uint32_t pk_f16(float a, float b) {   // (half(a), half(b)) in one register; callers pass values exact in f16
+  return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a, b));
+}
 template <int A_PAD, int MRW>
-__global__ __launch_bounds__(256, 2) void k_fused_tab(const f16x8* __restrict__ modes16, const f16x8* __restrict__ tab16,
+__global__ __launch_bounds__(512, 2) void k_fused_tab(const f16x8* __restrict__ modes16, const f16x8* __restrict__ tab16,
                                                       const f32x4* __restrict__ sci_tile, const f32x4* __restrict__ psi_tile,
                                                       const f16x8* __restrict__ act16, double* __restrict__ partials, MfmaGeom geo, float ratio) {
   constexpr int NSTEP = A_PAD / 16, NM = 3 * NSTEP, NS = 2 * (MRW + 1);
@@ -373,18 +399,30 @@ __global__ __launch_bounds__(256, 2) void k_fused_tab(const f16x8* __restrict__ 
   extern __shared__ f32x4 lds_sci[];   // [tile in chunk][h][4] float4 = the science table in accumulator order
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int L = blockIdx.x, j = L >> 3;
-  const int c = (j / geo.wg_y) * 8 + (L & 7);
+#ifdef AOG_DEV
+  long long tl[5] = {geo.timeline ? (long long)wall_clock64() : 0, 0, 0, 0, 0};
+#endif
+  int c, eg;
+  fused_wg_map(geo, L, c, eg);
   if (c >= geo.P) return;
-  const int we = geo.we, wp = 4 / we;
+  const int we = geo.we, wp = (int)(blockDim.x >> 6) / we;   // env tiles x pixel sub-chunks = the waves of the workgroup
   const int w_e = wave % we, w_p = wave / we;
-  const int etile = (j % geo.wg_y) * we + w_e;
+  const int etile = eg * we + w_e;
   const int t0 = (int)(((long long)c * geo.n_ptiles) / geo.P);
   const int t1 = (int)(((long long)(c + 1) * geo.n_ptiles) / geo.P);
   const int h = lane >> 5;
   const int etile_c = min(etile, geo.n_etiles - 1);
-  const int first = t0 + w_p;
-  const int n = first < t1 ? (t1 - first + wp - 1) / wp : 0;
-  const int last = n > 0 ? first + (n - 1) * wp : min(t0, geo.n_ptiles - 1);
+  // This wave's tiles: first, first + stride, ... (n of them).  Interleaved sub-chunks by default.  Asymmetric pairs (geo.heavy > 0,
+  // 8 waves, wp = 2): the workgroup's waves sit two per SIMD, and of two co-resident waves the one with priority runs at ~1.3x the
+  // rate of the other (vector issue is arbitrated by priority, then age: MI355X_MICROARCH.md, "Two waves per SIMD") — so sub-chunk 0
+  // takes geo.heavy / 1024 of the chunk's tiles AND the priority, sub-chunk 1 the rest, and the two finish together instead of
+  // leaving every SIMD to a single wave (which fills ~40 % of its issue slots) for the last third of the launch.
+  const int nt_c = t1 - t0;
+  const int n_heavy = geo.heavy > 0 ? min(nt_c, (nt_c * geo.heavy + 512) >> 10) : 0;
+  const int stride = geo.heavy > 0 ? 1 : wp;
+  const int first = geo.heavy > 0 ? (w_p == 0 ? t0 : t0 + n_heavy) : t0 + w_p;
+  const int n = geo.heavy > 0 ? (w_p == 0 ? n_heavy : nt_c - n_heavy) : (first < t1 ? (t1 - first + wp - 1) / wp : 0);
+  const int last = n > 0 ? first + (n - 1) * stride : min(t0, geo.n_ptiles - 1);
   f16x8 bh[NSTEP], bl[NSTEP];
   {
     const f16x8* asrc = act16 + ((size_t)etile_c * NSTEP * 2) * 64 + lane;
@@ -394,9 +432,9 @@ __global__ __launch_bounds__(256, 2) void k_fused_tab(const f16x8* __restrict__ 
       bl[s] = asrc[(2 * s + 1) * 64];
     }
   }
-  // The float64-flush variant (few tables) and the 128-mode variants are out of registers: their actuator operands live in LDS (this wave's own 2 NSTEP KB,
-  // behind the science rows) and are read back right before each phase MFMA.
-  constexpr bool BLDS = F64 || A_PAD > 64;
+  // The float64-flush variant (few tables) and the 128-mode variants are short of registers: their actuator operands live in LDS (this
+  // wave's own 2 NSTEP KB, behind the science rows) and are read back right before each phase MFMA.
+  constexpr bool BLDS = A_PAD > 64;
   f16x8* lds_b = reinterpret_cast<f16x8*>(lds_sci + (size_t)geo.max_tiles * 8) + (size_t)wave * NSTEP * 2 * 64 + lane;
   if constexpr (BLDS) {
 #pragma unroll
@@ -407,6 +445,9 @@ __global__ __launch_bounds__(256, 2) void k_fused_tab(const f16x8* __restrict__ 
   }
   const size_t psi_base = (size_t)etile_c * geo.n_ptiles;
   auto load_modes = [&](f16x8 (&mh)[NSTEP], f16x8 (&ml)[NSTEP], int t) {
+#ifdef AOG_DEV
+    if (geo.dev & 16) t = first;   // timing experiment: every tile's operands come from the same (cache-hot) addresses
+#endif
     const f16x8* ms = modes16 + ((size_t)min(t, last) * NSTEP * 2) * 64 + lane;
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) {
@@ -414,40 +455,56 @@ __global__ __launch_bounds__(256, 2) void k_fused_tab(const f16x8* __restrict__ 
       ml[s] = ms[(2 * s + 1) * 64];
     }
   };
-  auto load_psi = [&](int t) {
+  // screen values of tile t, register groups [G0, G0 + NG) (4 registers = one 16-byte load each)
+  auto load_psi = [&](auto g0c, auto ngc, f32x16& d, int t) {
+    constexpr int G0 = decltype(g0c)::v, NG = decltype(ngc)::v;
+#ifdef AOG_DEV
+    if (geo.dev & 32) t = first;
+#endif
     const f32x4* ps = psi_tile + ((psi_base + min(t, last)) * 4) * 64 + lane;
-    f32x16 d;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
+    for (int g = G0; g < G0 + NG; ++g) {
+#ifdef AOG_DEV
+      const f32x4 v = (geo.dev & 1) ? __builtin_nontemporal_load(ps + g * 64) : ps[g * 64];
+#else
       const f32x4 v = ps[g * 64];
+#endif
       d[4 * g + 0] = v[0]; d[4 * g + 1] = v[1]; d[4 * g + 2] = v[2]; d[4 * g + 3] = v[3];
     }
-    return d;
   };
   // Table rows m >= MRW are zero: the lanes that would fetch them all read ONE zero entry (row 31 of the first half) instead, so a
-  // variant with few tables pulls 2-3 cache lines per operand through L1 instead of 8 (the kernel is bound by that fill rate).
+  // variant with few tables pulls 2-3 cache lines per operand through L1 instead of 8.
   const int tlane = (lane & 31) <= MRW ? lane : 31;
   auto load_tab = [&](f16x8 (&ta)[4], int t) {   // [step][hi|lo]
     const f16x8* ts = tab16 + ((size_t)min(t, last) * 4) * 64 + tlane;
 #pragma unroll
     for (int q = 0; q < 4; ++q) ta[q] = ts[q * 64];
   };
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   f16x8 mh[NSTEP], ml[NSTEP], ta[4];
+  f32x16 Pa = zero16, Pb = zero16;   // screens: Pa = tile being reduced, Pb = the tile after it (two tiles of the HBM stream in flight)
   load_modes(mh, ml, first);
-  f32x16 p_first = load_psi(first);
+  load_psi(IC<0>{}, IC<4>{}, Pa, first);
   load_tab(ta, first);
   __builtin_amdgcn_sched_barrier(0);
   {
     const int n4 = (t1 - t0) * 8;
     const f32x4* src = sci_tile + (size_t)t0 * 8;
-    for (int i = threadIdx.x; i < n4; i += 256) lds_sci[i] = src[i];
+    for (int i = threadIdx.x; i < n4; i += blockDim.x) lds_sci[i] = src[i];
   }
   __syncthreads();
   if (etile >= geo.n_etiles) return;
-  if ((j & 32) != 0) {
-    for (int q = 0; q < geo.skew; ++q) asm volatile("s_nop 15");
+  if (geo.heavy > 0) {
+    if (w_p == 0) __builtin_amdgcn_s_setprio(1);
+  } else if ((j & 32) != 0) {
+    // 4-wave workgroups, two per CU: the second one dispatched to a CU (j and j + 32 share it) is the younger and would lose every
+    // arbitration, starting its loop ~8 us late; with the priority it starts on time and the older one fills the gaps (measured at
+    // B = 4096, o = 5: 266 against 287 us per launch)
+    __builtin_amdgcn_s_setprio(1);
   }
-  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#ifdef AOG_DEV
+  if (geo.timeline) tl[1] = wall_clock64();
+#endif
   f32x16 Dc = zero16, Ds = zero16;          // table sums (cos, sin), rows by register
   float sc_c = 0.f, sc_s = 0.f;             // science-table sums of this lane's pixels
   double acc_t[F64 ? 2 * LIVE : 1];
@@ -455,7 +512,8 @@ __global__ __launch_bounds__(256, 2) void k_fused_tab(const f16x8* __restrict__ 
 #pragma unroll
   for (int i = 0; i < (F64 ? 2 * LIVE : 1); ++i) acc_t[i] = 0.0;
   if (n > 0) {
-    auto mfma_q = [&](auto qc, f32x16& d1, f32x16& d2) {
+    // phase MFMA q of a tile into `acc`: s = q / 3; Mh.ah, Mh.al, Ml.ah.  The first one of a tile starts the sum (C = 0).
+    auto mfma_q = [&](auto qc, f32x16& acc) {
       constexpr int q = decltype(qc)::v, s = q / 3, w = q % 3;
       f16x8 xh, xl;
       if constexpr (BLDS) {
@@ -465,53 +523,66 @@ __global__ __launch_bounds__(256, 2) void k_fused_tab(const f16x8* __restrict__ 
         xh = bh[s];
         xl = bl[s];
       }
-      if constexpr (w == 0) d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[s], xh, d1, 0, 0, 0);
-      else if constexpr (w == 1) d2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[s], xl, d2, 0, 0, 0);
-      else d2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ml[s], xh, d2, 0, 0, 0);
+      if constexpr (q == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[s], xh, zero16, 0, 0, 0);
+      else if constexpr (w == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[s], xh, acc, 0, 0, 0);
+      else if constexpr (w == 1) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[s], xl, acc, 0, 0, 0);
+      else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ml[s], xh, acc, 0, 0, 0);
     };
-    f32x16 d;
-    {
-      f32x16 d1 = zero16, d2 = zero16;
-      static_for<NM>([&](auto qc) { mfma_q(qc, d1, d2); });
-      d = d1 * kD1Unscale + (p_first + d2 * kD2Unscale);
-    }
+    f32x16 X, Y = zero16;   // phase accumulators (scaled by 2^22): X = tile being reduced, Y = the next tile's contraction in flight
+    static_for<NM>([&](auto qc) { mfma_q(qc, X); });
     // Registers are refilled just in time: the mode halves and the step-0 table operands of the NEXT stage are requested right
-    // after the matrix ops that read the current ones have been issued (middle of the stage), the step-1 table operands and the
-    // screen of the tile after next at the end of the stage — every load has most of a stage to land, with no second register set.
-    f32x16 pA = F64 ? zero16 : load_psi(first + wp), pB_store = zero16;
-    f32x16& pB = F64 ? pA : pB_store;   // single screen register set in the float64-flush variant
+    // after the matrix ops that read the current ones have been issued (middle of the stage), the step-1 table operands at the end;
+    // a screen register group is re-requested (for the tile after next) as soon as its four pixels have been reduced.
+    load_psi(IC<0>{}, IC<4>{}, Pb, first + stride);
     __builtin_amdgcn_sched_barrier(0);
-    load_modes(mh, ml, first + wp);
+    load_modes(mh, ml, first + stride);
     // Matrix instructions are dealt BETWEEN the pixels of a vector step (one wave issues in order: a block of 18 MFMAs would keep
     // it from issuing vector work for ~600 cycles, and both waves of a SIMD tend to be in the same phase).  The queue of a stage:
-    //   during step 0 of tile t : the 12 phase MFMAs of tile t + wp  and  the 6 step-1 table MFMAs of tile t - wp (operands kept)
+    //   during step 0 of tile t : the 12 phase MFMAs of the next tile  and  the 6 step-1 table MFMAs of the previous tile (operands kept)
     //   during step 1 of tile t : the 6 step-0 table MFMAs of tile t
-    f16x8 c0, l0, s0, m0;   // step-0 B operands of the current tile (cos hi, cos lo, sin hi, sin lo)
-    f16x8 c1, l1, s1, m1;   // step-1 B operands, consumed during the NEXT stage's step 0
-    auto tab_one = [&](auto kc, const f16x8& tah, const f16x8& tal, const f16x8& ch, const f16x8& cl, const f16x8& sh, const f16x8& sl) {
+    u32x4 c0, l0, s0, m0;   // step-0 B operands of the current tile (cos hi, cos lo, sin hi, sin lo), two f16 per register
+    u32x4 c1, l1, s1, m1;   // step-1 B operands, consumed during the NEXT stage's step 0
+    auto tab_one = [&](auto kc, const f16x8& tah, const f16x8& tal, const u32x4& ch, const u32x4& cl, const u32x4& sh, const u32x4& sl) {
       constexpr int k = decltype(kc)::v;   // 0..5
-      if constexpr (k == 0) Dc = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, ch, Dc, 0, 0, 0);
-      else if constexpr (k == 1) Ds = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, sh, Ds, 0, 0, 0);
-      else if constexpr (k == 2) Dc = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, cl, Dc, 0, 0, 0);
-      else if constexpr (k == 3) Ds = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, sl, Ds, 0, 0, 0);
-      else if constexpr (k == 4) Dc = __builtin_amdgcn_mfma_f32_32x32x16_f16(tal, ch, Dc, 0, 0, 0);
-      else Ds = __builtin_amdgcn_mfma_f32_32x32x16_f16(tal, sh, Ds, 0, 0, 0);
+      if constexpr (k == 0) Dc = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, __builtin_bit_cast(f16x8, ch), Dc, 0, 0, 0);
+      else if constexpr (k == 1) Ds = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, __builtin_bit_cast(f16x8, sh), Ds, 0, 0, 0);
+      else if constexpr (k == 2) Dc = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, __builtin_bit_cast(f16x8, cl), Dc, 0, 0, 0);
+      else if constexpr (k == 3) Ds = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, __builtin_bit_cast(f16x8, sl), Ds, 0, 0, 0);
+      else if constexpr (k == 4) Dc = __builtin_amdgcn_mfma_f32_32x32x16_f16(tal, __builtin_bit_cast(f16x8, ch), Dc, 0, 0, 0);
+      else Ds = __builtin_amdgcn_mfma_f32_32x32x16_f16(tal, __builtin_bit_cast(f16x8, sh), Ds, 0, 0, 0);
     };
-    // one pixel e of step s: sin/cos, science sums, hi/lo split into element e of the four B operands
-    auto vec_pixel = [&](auto sc, auto ec, const f32x4& g0, const f32x4& g1, f16x8& ch, f16x8& cl, f16x8& sh, f16x8& sl) {
+    // one pixel e of step s: phase, sin/cos, science sums, hi/lo split; the halves of an even pixel wait in `st` for their odd
+    // neighbour and the pair goes into element pair e >> 1 of the four B operands
+    float st[4];
+    f32x2 uw2 = {0.f, 0.f}, us2 = {0.f, 0.f};
+    auto vec_pixel = [&](auto sc, auto ec, const f32x16& D, const f32x16& P, const f32x4& g0, const f32x4& g1, u32x4& ch, u32x4& cl, u32x4& sh,
+                         u32x4& sl) {
       constexpr int s = decltype(sc)::v, e = decltype(ec)::v;
-      const float u = d[8 * s + e];
+      // phases of a pixel pair with one packed FMA and one packed multiply (their inputs are matrix-pipe results and loaded screen
+      // values, never fresh transcendental results: the packed-read hazard of DESIGN.md section 5 does not apply)
+      if constexpr ((e & 1) == 0) {
+        const f32x2 d2 = {D[8 * s + e], D[8 * s + e + 1]}, p2 = {P[8 * s + e], P[8 * s + e + 1]};
+        const f32x2 k2 = {kPhaseUnscale, kPhaseUnscale}, r2 = {ratio, ratio};
+        uw2 = __builtin_elementwise_fma(d2, k2, p2);
+        us2 = uw2 * r2;
+      }
+      const float u = uw2[e & 1];
       const float cw = __builtin_amdgcn_cosf(u), sw = __builtin_amdgcn_sinf(u);
-      const float us = u * ratio;
+      const float us = us2[e & 1];
       const float cs = __builtin_amdgcn_cosf(us), ss = __builtin_amdgcn_sinf(us);
       const float g = e < 4 ? g0[e & 3] : g1[e & 3];
       sc_c = fmaf(cs, g, sc_c);
       sc_s = fmaf(ss, g, sc_s);
-      const _Float16 chh = (_Float16)cw, shh = (_Float16)sw;
-      ch[e] = chh;
-      sh[e] = shh;
-      cl[e] = (_Float16)(cw - (float)chh);
-      sl[e] = (_Float16)(sw - (float)shh);
+      const float chf = __uint_as_float(__float_as_uint(cw) & 0xffffe000u), shf = __uint_as_float(__float_as_uint(sw) & 0xffffe000u);
+      const float clf = cw - chf, slf = sw - shf;
+      if constexpr ((e & 1) == 0) {
+        st[0] = chf; st[1] = clf; st[2] = shf; st[3] = slf;
+      } else {
+        ch[e >> 1] = pk_f16(st[0], chf);
+        cl[e >> 1] = pk_f16(st[1], clf);
+        sh[e >> 1] = pk_f16(st[2], shf);
+        sl[e >> 1] = pk_f16(st[3], slf);
+      }
     };
     auto flush = [&] {
       acc_sc += (double)sc_c; acc_ss += (double)sc_s;
@@ -526,29 +597,29 @@ __global__ __launch_bounds__(256, 2) void k_fused_tab(const f16x8* __restrict__ 
         });
       }
     };
-    // stage: vector work of tile t; PREV: tile t - wp still owes its step-1 table MFMAs; NEXT: tile t + wp gets its phase
-    auto stage = [&](auto prevc, auto nextc, int i, int t, f32x16& p_use, f32x16& p_load) {
+    // stage: vector work of tile t (accumulator D, screen P); PREV: the previous tile still owes its step-1 table MFMAs; NEXT: the next tile
+    // gets its phase contraction into Dn (its screen is already in the other screen set)
+    auto stage = [&](auto prevc, auto nextc, int i, int t, f32x16& D, f32x16& Dn, f32x16& P) {
       constexpr bool PREV = decltype(prevc)::v != 0, NEXT = decltype(nextc)::v != 0;
       constexpr int NQ0 = (NEXT ? NM : 0) + (PREV ? 6 : 0);   // matrix ops dealt over the 8 pixels of step 0
-      f32x16 d1 = zero16, d2 = zero16;
-      if constexpr (F64 && NEXT) p_use = load_psi(t + wp);   // (this variant keeps one screen register set: one tile ahead)
       const f32x4* gs = lds_sci + (size_t)(t - t0) * 8 + h * 4;
       {
         const f32x4 g0 = gs[0], g1 = gs[1];
         static_for<8>([&](auto ec) {
           constexpr int e = decltype(ec)::v;
-          vec_pixel(IC<0>{}, ec, g0, g1, c0, l0, s0, m0);
+          vec_pixel(IC<0>{}, ec, D, P, g0, g1, c0, l0, s0, m0);
           constexpr int qa = NQ0 * e / 8, qb = NQ0 * (e + 1) / 8;
           static_for<qb - qa>([&](auto kc) {
             constexpr int q = qa + decltype(kc)::v;
             if constexpr (PREV && q < 6) tab_one(IC<q>{}, ta[2], ta[3], c1, l1, s1, m1);
-            else mfma_q(IC<q - (PREV ? 6 : 0)>{}, d1, d2);
+            else mfma_q(IC<q - (PREV ? 6 : 0)>{}, Dn);
           });
           __builtin_amdgcn_sched_barrier(0);
         });
       }
       if constexpr (NEXT) {   // the operands those matrix ops read are free again: request the next stage's
-        load_modes(mh, ml, t + 2 * wp);
+        load_modes(mh, ml, t + 2 * stride);
+        load_psi(IC<0>{}, IC<2>{}, P, t + 2 * stride);   // (pixels of register groups 0 and 1 are done)
       }
       {
         const f16x8* ts = tab16 + ((size_t)t * 4) * 64 + tlane;   // this tile's step-1 table operands (consumed next stage)
@@ -560,41 +631,46 @@ __global__ __launch_bounds__(256, 2) void k_fused_tab(const f16x8* __restrict__ 
         const f32x4 g0 = gs[2], g1 = gs[3];
         static_for<8>([&](auto ec) {
           constexpr int e = decltype(ec)::v;
-          vec_pixel(IC<1>{}, ec, g0, g1, c1, l1, s1, m1);
+          vec_pixel(IC<1>{}, ec, D, P, g0, g1, c1, l1, s1, m1);
           constexpr int qa = 6 * e / 8, qb = 6 * (e + 1) / 8;
           static_for<qb - qa>([&](auto kc) { tab_one(IC<qa + decltype(kc)::v>{}, ta[0], ta[1], c0, l0, s0, m0); });
           __builtin_amdgcn_sched_barrier(0);
         });
       }
       if constexpr (NEXT) {
-        d = d1 * kD1Unscale + (p_use + d2 * kD2Unscale);
-        const f16x8* ts = tab16 + ((size_t)min(t + wp, last) * 4) * 64 + tlane;   // next tile's step-0 table operands
+        const f16x8* ts = tab16 + ((size_t)min(t + stride, last) * 4) * 64 + tlane;   // next tile's step-0 table operands
         ta[0] = ts[0];
         ta[1] = ts[64];
-        if constexpr (!F64) p_load = load_psi(t + 2 * wp);
+        load_psi(IC<2>{}, IC<2>{}, P, t + 2 * stride);
       }
       if ((i % kFlushTiles) == kFlushTiles - 1) flush();
     };
     if (n == 1) {
-      stage(IC<0>{}, IC<0>{}, 0, first, pA, pB);
+      stage(IC<0>{}, IC<0>{}, 0, first, X, Y, Pa);
     } else {
-      stage(IC<0>{}, IC<1>{}, 0, first, pA, pB);
-      int i = 1, t = first + wp;
-      for (; i + 2 < n; i += 2, t += 2 * wp) {
-        stage(IC<1>{}, IC<1>{}, i, t, pB, pA);
-        stage(IC<1>{}, IC<1>{}, i + 1, t + wp, pA, pB);
+      stage(IC<0>{}, IC<1>{}, 0, first, X, Y, Pa);
+#ifdef AOG_DEV
+      if (geo.timeline) { asm volatile("" ::"v"(X[0]), "v"(Y[0])); tl[2] = wall_clock64(); }
+#endif
+      int i = 1, t = first + stride;
+      for (; i + 2 < n; i += 2, t += 2 * stride) {
+        stage(IC<1>{}, IC<1>{}, i, t, Y, X, Pb);
+        stage(IC<1>{}, IC<1>{}, i + 1, t + stride, X, Y, Pa);
       }
       if (i + 1 < n) {
-        stage(IC<1>{}, IC<1>{}, i, t, pB, pA);
-        stage(IC<1>{}, IC<0>{}, i + 1, t + wp, pA, pB);
+        stage(IC<1>{}, IC<1>{}, i, t, Y, X, Pb);
+        stage(IC<1>{}, IC<0>{}, i + 1, t + stride, X, Y, Pa);
       } else {
-        stage(IC<1>{}, IC<0>{}, i, t, pB, pA);
+        stage(IC<1>{}, IC<0>{}, i, t, Y, X, Pb);
       }
     }
     // the last tile's step-1 table MFMAs
     static_for<6>([&](auto kc) { tab_one(kc, ta[2], ta[3], c1, l1, s1, m1); });
     flush();
   }
+#ifdef AOG_DEV
+  if (geo.timeline) { asm volatile("" ::"v"(acc_sc)); tl[3] = wall_clock64(); }
+#endif
   const int chunk = c * wp + w_p;
   if constexpr (F64) {
     double* out = partials + (size_t)chunk * NS * geo.Bp + (size_t)etile * 32 + (lane & 31);
@@ -628,6 +704,12 @@ __global__ __launch_bounds__(256, 2) void k_fused_tab(const f16x8* __restrict__ 
       out[(size_t)(2 * MRW + 1) * geo.Bp] = (float)vs;
     }
   }
+#ifdef AOG_DEV
+  if (geo.timeline && (threadIdx.x & 63) == 0) {
+    long long* rec = geo.timeline + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8;
+    rec[0] = tl[0]; rec[1] = tl[1]; rec[2] = tl[2]; rec[3] = tl[3]; rec[4] = wall_clock64(); rec[5] = n;
+  }
+#endif
 }
 
 // Phase-only form of the contraction: u = psi + Mt a for every (pixel, env), written back in the psi_tile layout.  Used by the
@@ -643,13 +725,13 @@ __global__ __launch_bounds__(256) void k_phase_mfma(const f16x8* __restrict__ mo
   if (t >= n_ptiles || etile >= n_etiles) return;
   const f16x8* asrc = act16 + ((size_t)etile * NSTEP * 2) * 64 + lane;
   const f16x8* ms = modes16 + ((size_t)t * NSTEP * 2) * 64 + lane;
-  f32x16 d1 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, d2 = d1;
+  f32x16 d = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int s = 0; s < NSTEP; ++s) {
     const f16x8 mh = ms[(2 * s) * 64], ml = ms[(2 * s + 1) * 64], bh = asrc[(2 * s) * 64], bl = asrc[(2 * s + 1) * 64];
-    d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh, bh, d1, 0, 0, 0);
-    d2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh, bl, d2, 0, 0, 0);
-    d2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ml, bh, d2, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh, bh, d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh, bl, d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_32x32x16_f16(ml, bh, d, 0, 0, 0);
   }
   const size_t base = (((size_t)etile * n_ptiles + t) * 4) * 64 + lane;
 #pragma unroll
@@ -657,7 +739,7 @@ __global__ __launch_bounds__(256) void k_phase_mfma(const f16x8* __restrict__ mo
     const f32x4 p = psi_tile[base + g * 64];
     f32x4 o;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) o[r] = d1[4 * g + r] * kD1Unscale + (p[r] + d2[4 * g + r] * kD2Unscale);
+    for (int r = 0; r < 4; ++r) o[r] = fmaf(d[4 * g + r], kPhaseUnscale, p[r]);
     out_tile[base + g * 64] = o;
   }
 }

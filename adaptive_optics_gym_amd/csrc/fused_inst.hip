@@ -30,11 +30,30 @@ void launch_tab(aog_env* e, hipStream_t s) {
   g.wg_y = (e->n_etiles + e->mfma_we - 1) / e->mfma_we;
   g.max_tiles = e->mfma_tpc;
   g.skew = aog::kSkewNops;
-  dim3 grid(round_up(g.P, 8) * g.wg_y);
+  g.heavy = e->mfma_heavy;
+  const int threads = 64 * e->mfma_waves;
+  g.pair = (e->mfma_waves == 4 && g.wg_y % 2 == 0 && 64 % g.wg_y == 0 && g.wg_y >= 2) ? 1 : 0;
+  g.dev = 0;
+  g.timeline = nullptr;
+#ifdef AOG_DEV
+  if (getenv("AOG_DEV_TIMELINE")) {
+    static long long* buf = nullptr;
+    if (!buf) (void)hipMalloc(&buf, sizeof(long long) * 8 * 4 * 8192);
+    g.timeline = buf;
+    aog_host::dev_timeline = buf;
+  }
+  if (const char* v = getenv("AOG_DEV_FLAGS")) g.dev = atoi(v);
+  if (const char* v = getenv("AOG_DEV_PAIR")) g.pair = g.pair && atoi(v);
+  if (const char* v = getenv("AOG_DEV_SKEW")) g.skew = atoi(v);
+  if (const char* v = getenv("AOG_DEV_HEAVY")) g.heavy = g.heavy ? atoi(v) : 0;
+#endif
+  const int chunks_per_xcd = round_up(g.P, 8) / 8;
+  const int wgs_per_xcd = g.pair ? round_up(chunks_per_xcd, 64 / g.wg_y) * g.wg_y : chunks_per_xcd * g.wg_y;
+  dim3 grid(8 * wgs_per_xcd);
   const float ratio = (float)(e->cfg.wavelength_wfs / e->cfg.wavelength_sci);
-  const size_t lds_t = (size_t)e->mfma_tpc * 8 * 16 + ((MRW <= 8 || A_PAD > 64) ? (size_t)4 * (A_PAD / 16) * 2 * 64 * 16 : 0);   // science rows (+ actuator operands)
+  const size_t lds_t = (size_t)e->mfma_tpc * 8 * 16 + (A_PAD > 64 ? (size_t)e->mfma_waves * (A_PAD / 16) * 2 * 64 * 16 : 0);   // science rows (+ actuator operands)
   aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_fused_tab<A_PAD, MRW>), lds_t, e->device);
-  hipLaunchKernelGGL((aog::k_fused_tab<A_PAD, MRW>), grid, dim3(256), lds_t, s, reinterpret_cast<const aog::f16x8*>(e->modes16),
+  hipLaunchKernelGGL((aog::k_fused_tab<A_PAD, MRW>), grid, dim3(threads), lds_t, s, reinterpret_cast<const aog::f16x8*>(e->modes16),
                      reinterpret_cast<const aog::f16x8*>(e->tab16), reinterpret_cast<const aog::f32x4*>(e->sci_tile),
                      reinterpret_cast<const aog::f32x4*>(e->psi_tile), reinterpret_cast<const aog::f16x8*>(e->act16), e->partials, g, ratio);
 }
