@@ -41,7 +41,7 @@ class AogLayerTables(C.Structure):
 class AogShTables(C.Structure):
     _fields_ = [("n_sub", C.c_int32), ("sub_slot", C.POINTER(C.c_int32))] + [(n, C.POINTER(C.c_double)) for n in (
         "centres", "slopes_ref", "reconstruction", "mla_phase", "transfer", "x_det")] + [(n, C.c_double) for n in (
-        "field_amplitude", "image_scale", "gain", "leakage")]
+        "field_amplitude", "image_scale", "gain", "leakage")] + [("fft_double", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class AogActor(C.Structure):  # mirrors aog_actor in include/aogym.h
@@ -90,6 +90,7 @@ SYMBOLS = {
     "aog_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "aog_step": (C.c_int, [C.c_void_p] * 9),
     "aog_focal_image": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "aog_focal_images": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "aog_selftest_sincos": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "aog_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "aog_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),

@@ -38,6 +38,9 @@ class BatchedAOEnv:
                         Every per-env random stream (wind direction, device screen synthesis, extrusion normals, photon noise,
                         numpy per-env seeds) is keyed by the GLOBAL env id, so a batch split over several instances / GPUs
                         gives bit-identical screens to one instance holding all of it
+    sh_fft_precision    'single' (default: complex64 Fresnel transforms in the Shack-Hartmann chain; error ~1e-6 of the image peak, far
+                        below the photon noise added before the image is read) | 'double' (complex128, for comparing the noise-free
+                        sensor image with a float64 oracle)
     precision           'fast' (fp32 data, float64 accumulators) | 'fp64' (validation kernel)
     kernel              'auto' | 'mfma' | 'valu'
     """
@@ -47,7 +50,7 @@ class BatchedAOEnv:
                  timesteps_per_episode=20, flat_mirror_start_per_episode=True, SH_operation=False, *,
                  num_pupil_pixels=240, seed=None, screen_source="device", screen_oversampling=16, screens=None,
                  precision="fast", kernel="auto", pixel_chunks=0, rng=None, verbose=True, params=None,
-                 global_env_offset=0, total_envs=None):
+                 global_env_offset=0, total_envs=None, sh_fft_precision="single"):
         import torch
 
         self._torch = torch
@@ -74,6 +77,9 @@ class BatchedAOEnv:
         self.flat_mirror_start_per_episode = bool(flat_mirror_start_per_episode)
         self.rew_threshold = rew_threshold
         self.SH_operation = bool(SH_operation)
+        if sh_fft_precision not in ("single", "double"):
+            raise ValueError("sh_fft_precision must be 'single' or 'double'")
+        self.sh_fft_precision = sh_fft_precision
         self.velocity = coerce_velocity(atm_type, atm_vel, verbose)
         self.fried_parameter = atm_fried
         self.params = params if params is not None else OpticalParams(num_pupil_pixels=int(num_pupil_pixels))
@@ -268,7 +274,8 @@ class BatchedAOEnv:
                     tf=c(np.stack([sh.transfer.real, sh.transfer.imag], axis=-1), dtype=np.float64), xd=c(sh.x_det, dtype=np.float64))
         t = _lib.AogShTables(int(sh.n_sub), _dptr(keep["slot"], C.c_int32), _dptr(keep["cen"], C.c_double), _dptr(keep["ref"], C.c_double),
                              _dptr(keep["rec"], C.c_double), _dptr(keep["mla"], C.c_double), _dptr(keep["tf"], C.c_double),
-                             _dptr(keep["xd"], C.c_double), float(sh.amp_wfs / sh.mag), float(sh.pitch ** 2 * self.params.delta_t), 0.3, 0.01)
+                             _dptr(keep["xd"], C.c_double), float(sh.amp_wfs / sh.mag), float(sh.pitch ** 2 * self.params.delta_t), 0.3, 0.01,
+                             int(self.sh_fft_precision == "double"), 0)
         _lib.check(self.lib.aog_upload_sh(self._handle, C.byref(t)))
 
     def SH_step(self):
@@ -472,6 +479,16 @@ class BatchedAOEnv:
         nf = int(self.tables.focal_m1.shape[0])
         out = torch.empty((nf, nf, 2), dtype=torch.float32, device=self.device)
         _lib.check(self.lib.aog_focal_image(self._handle, int(env_index), C.c_void_p(out.data_ptr()), self._stream()))
+        return torch.view_as_complex(out)
+
+    def focal_images(self, first=0, count=None):
+        """``wf_wfs_after_foc.electric_field`` (AO_env.py:138) of envs [first, first + count), default all: complex64
+        [count, n_focal, n_focal] — the batched form of ``focal_image`` (matrix-core complex GEMM pair, fast precision only)."""
+        torch = self._torch
+        nf = int(self.tables.focal_m1.shape[0])
+        count = self.num_envs - first if count is None else int(count)
+        out = torch.empty((count, nf, nf, 2), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.aog_focal_images(self._handle, int(first), count, C.c_void_p(out.data_ptr()), self._stream()))
         return torch.view_as_complex(out)
 
     def phase_screen(self, env_index=0):

@@ -107,17 +107,17 @@ void launch_fast(aog_env* e, hipStream_t s) {
 
 namespace aog_host {
 template <int A_PAD>
-static void launch_sh_phase_t(aog_env* e, hipStream_t s) {
+static void launch_phase_t(aog_env* e, hipStream_t s, const _Float16* act16, float* out_tile) {
   hipLaunchKernelGGL((aog::k_phase_mfma<A_PAD>), dim3((e->n_ptiles + 3) / 4, e->n_etiles), dim3(256), 0, s,
                      reinterpret_cast<const aog::f16x8*>(e->modes16), reinterpret_cast<const aog::f32x4*>(e->psi_tile),
-                     reinterpret_cast<const aog::f16x8*>(e->sh_act16), reinterpret_cast<aog::f32x4*>(e->sh_phase), e->n_ptiles, e->n_etiles);
+                     reinterpret_cast<const aog::f16x8*>(act16), reinterpret_cast<aog::f32x4*>(out_tile), e->n_ptiles, e->n_etiles);
 }
-void launch_sh_phase(aog_env* e, hipStream_t s) {
+void launch_phase(aog_env* e, hipStream_t s, const _Float16* act16, float* out_tile) {
   switch (e->A_pad) {
-    case 16: launch_sh_phase_t<16>(e, s); break;
-    case 32: launch_sh_phase_t<32>(e, s); break;
-    case 64: launch_sh_phase_t<64>(e, s); break;
-    default: launch_sh_phase_t<128>(e, s); break;
+    case 16: launch_phase_t<16>(e, s, act16, out_tile); break;
+    case 32: launch_phase_t<32>(e, s, act16, out_tile); break;
+    case 64: launch_phase_t<64>(e, s, act16, out_tile); break;
+    default: launch_phase_t<128>(e, s, act16, out_tile); break;
   }
 }
 }  // namespace aog_host
@@ -648,6 +648,17 @@ int aog_upload_tables(aog_env* e, const aog_tables* t) {
     if ((rc = dev_alloc(e, &e->focal_T, (size_t)nf * N * 2)) != AOG_OK) return rc;
     HIP_TRY(hipMemcpy(e->focal_m1, t->focal_m1, sizeof(double) * nf * N * 2, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->focal_m2, t->focal_m2, sizeof(double) * nf * N * 2, hipMemcpyHostToDevice));
+    if (e->cfg.precision == AOG_PRECISION_FAST) {   // complex64 copies for the batched matrix-core path
+      std::vector<float> f1((size_t)nf * N * 2), f2((size_t)nf * N * 2);
+      for (size_t i = 0; i < f1.size(); ++i) {
+        f1[i] = (float)t->focal_m1[i];
+        f2[i] = (float)t->focal_m2[i];
+      }
+      if ((rc = dev_alloc(e, &e->focal_m1f, f1.size(), false)) != AOG_OK) return rc;
+      if ((rc = dev_alloc(e, &e->focal_m2f, f2.size(), false)) != AOG_OK) return rc;
+      HIP_TRY(hipMemcpy(e->focal_m1f, f1.data(), sizeof(float) * f1.size(), hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(e->focal_m2f, f2.data(), sizeof(float) * f2.size(), hipMemcpyHostToDevice));
+    }
     e->n_focal = nf;
   }
   e->tables_ready = true;
@@ -946,16 +957,29 @@ int aog_upload_sh(aog_env* e, const aog_sh_tables* t) {
   if ((rc = dev_alloc(e, &e->sh_act, (size_t)e->B * e->A)) != AOG_OK) return rc;
   if ((rc = dev_alloc(e, &e->sh_act16, (size_t)e->n_etiles * e->A_pad * 32 * 2)) != AOG_OK) return rc;
   if ((rc = dev_alloc(e, &e->sh_phase, (size_t)e->n_etiles * e->n_ptiles * 1024)) != AOG_OK) return rc;
-  if ((rc = dev_alloc(e, &e->sh_pad, (size_t)e->B * N2 * 4 * 2, false)) != AOG_OK) return rc;
-  // zero-padded INPUT of the forward transform: only aperture pixels are ever written (k_sh_field), the padding stays zero because
-  // the forward FFT runs out of place into sh_pad — no memset per call
-  if ((rc = dev_alloc(e, &e->sh_in, (size_t)e->B * N2 * 4 * 2, true)) != AOG_OK) return rc;
+  e->sh_double = t->fft_double != 0;
+  {
+    const size_t cbytes = e->sh_double ? sizeof(double) * 2 : sizeof(float) * 2;
+    char* p1 = nullptr;
+    char* p2 = nullptr;
+    if ((rc = dev_alloc(e, &p1, (size_t)e->B * N2 * 4 * cbytes, false)) != AOG_OK) return rc;
+    // zero-padded INPUT of the forward transform: only aperture pixels are ever written (k_sh_field), the padding stays zero because
+    // the forward FFT runs out of place into sh_pad — no memset per call
+    if ((rc = dev_alloc(e, &p2, (size_t)e->B * N2 * 4 * cbytes, true)) != AOG_OK) return rc;
+    e->sh_pad = p1;
+    e->sh_in = p2;
+  }
+  if (!e->sh_double) {
+    std::vector<float> tf32(N2 * 4 * 2);
+    for (size_t i = 0; i < tf32.size(); ++i) tf32[i] = (float)t->transfer[i];
+    if ((rc = up(&e->sh_tf32, tf32.data(), tf32.size())) != AOG_OK) return rc;
+  }
   if ((rc = dev_alloc(e, &e->sh_image, (size_t)e->B * N2, false)) != AOG_OK) return rc;
   if ((rc = dev_alloc(e, &e->sh_noisy, (size_t)e->B * N2, false)) != AOG_OK) return rc;
   hipfftHandle plan;
   int dims[2] = {2 * N, 2 * N};
-  if (hipfftPlanMany(&plan, 2, dims, nullptr, 1, 4 * N * N, nullptr, 1, 4 * N * N, HIPFFT_Z2Z, e->B) != HIPFFT_SUCCESS)
-    return fail(AOG_ERR_HIP, "hipfftPlanMany(Z2Z %d x %d, batch %d) failed", 2 * N, 2 * N, e->B);
+  if (hipfftPlanMany(&plan, 2, dims, nullptr, 1, 4 * N * N, nullptr, 1, 4 * N * N, e->sh_double ? HIPFFT_Z2Z : HIPFFT_C2C, e->B) != HIPFFT_SUCCESS)
+    return fail(AOG_ERR_HIP, "hipfftPlanMany(%s %d x %d, batch %d) failed", e->sh_double ? "Z2Z" : "C2C", 2 * N, 2 * N, e->B);
   e->sh_plan = (void*)(uintptr_t)plan;
   e->sh_amp = t->field_amplitude;
   e->sh_scale = t->image_scale;
@@ -978,20 +1002,35 @@ int aog_sh_image(aog_env* e, double* image_dev, void* stream) {
     const int n = e->B * e->A_pad;
     hipLaunchKernelGGL(aog::k_sh_act16, dim3((n + 255) / 256), dim3(256), 0, s, e->sh_act, e->sh_act16, e->B, e->A, e->A_pad,
                        2.0 / e->cfg.wavelength_wfs);
-    aog_host::launch_sh_phase(e, s);
+    aog_host::launch_phase(e, s, e->sh_act16, e->sh_phase);
   }
-  hipLaunchKernelGGL(aog::k_sh_field, dim3((e->n_ap + 255) / 256, e->B), dim3(256), 0, s, e->sh_phase, e->ap_index,
-                     reinterpret_cast<const double2*>(e->sh_mla), reinterpret_cast<double2*>(e->sh_in), e->n_ap, e->n_ptiles, N, e->sh_amp);
-  HIP_TRY(hipGetLastError());
-  hipfftDoubleComplex* buf = reinterpret_cast<hipfftDoubleComplex*>(e->sh_pad);
-  if (hipfftExecZ2Z(plan, reinterpret_cast<hipfftDoubleComplex*>(e->sh_in), buf, HIPFFT_FORWARD) != HIPFFT_SUCCESS)
-    return fail(AOG_ERR_HIP, "hipfftExecZ2Z forward failed");
-  hipLaunchKernelGGL(aog::k_sh_transfer, dim3((unsigned)((per + 255) / 256), e->B), dim3(256), 0, s, reinterpret_cast<double2*>(e->sh_pad),
-                     reinterpret_cast<const double2*>(e->sh_tf), per);
-  if (hipfftExecZ2Z(plan, buf, buf, HIPFFT_BACKWARD) != HIPFFT_SUCCESS) return fail(AOG_ERR_HIP, "hipfftExecZ2Z backward failed");
   const double norm = 1.0 / (double)per;  // hipFFT's inverse is un-normalised
-  hipLaunchKernelGGL(aog::k_sh_intensity, dim3((N * N + 255) / 256, e->B), dim3(256), 0, s, reinterpret_cast<const double2*>(e->sh_pad), e->sh_image,
-                     N, e->sh_scale * norm * norm);
+  const dim3 g_ap((e->n_ap + 255) / 256, e->B), g_per((unsigned)((per + 255) / 256), e->B), g_img((N * N + 255) / 256, e->B);
+  if (e->sh_double) {
+    double2* in = static_cast<double2*>(e->sh_in);
+    double2* pad = static_cast<double2*>(e->sh_pad);
+    hipLaunchKernelGGL(aog::k_sh_field<double2>, g_ap, dim3(256), 0, s, e->sh_phase, e->ap_index, reinterpret_cast<const double2*>(e->sh_mla), in, e->n_ap,
+                       e->n_ptiles, N, e->sh_amp);
+    HIP_TRY(hipGetLastError());
+    hipfftDoubleComplex* buf = reinterpret_cast<hipfftDoubleComplex*>(pad);
+    if (hipfftExecZ2Z(plan, reinterpret_cast<hipfftDoubleComplex*>(in), buf, HIPFFT_FORWARD) != HIPFFT_SUCCESS)
+      return fail(AOG_ERR_HIP, "hipfftExecZ2Z forward failed");
+    hipLaunchKernelGGL(aog::k_sh_transfer<double2>, g_per, dim3(256), 0, s, pad, reinterpret_cast<const double2*>(e->sh_tf), per);
+    if (hipfftExecZ2Z(plan, buf, buf, HIPFFT_BACKWARD) != HIPFFT_SUCCESS) return fail(AOG_ERR_HIP, "hipfftExecZ2Z backward failed");
+    hipLaunchKernelGGL(aog::k_sh_intensity<double2>, g_img, dim3(256), 0, s, pad, e->sh_image, N, e->sh_scale * norm * norm);
+  } else {
+    float2* in = static_cast<float2*>(e->sh_in);
+    float2* pad = static_cast<float2*>(e->sh_pad);
+    hipLaunchKernelGGL(aog::k_sh_field<float2>, g_ap, dim3(256), 0, s, e->sh_phase, e->ap_index, reinterpret_cast<const double2*>(e->sh_mla), in, e->n_ap,
+                       e->n_ptiles, N, e->sh_amp);
+    HIP_TRY(hipGetLastError());
+    hipfftComplex* buf = reinterpret_cast<hipfftComplex*>(pad);
+    if (hipfftExecC2C(plan, reinterpret_cast<hipfftComplex*>(in), buf, HIPFFT_FORWARD) != HIPFFT_SUCCESS)
+      return fail(AOG_ERR_HIP, "hipfftExecC2C forward failed");
+    hipLaunchKernelGGL(aog::k_sh_transfer<float2>, g_per, dim3(256), 0, s, pad, reinterpret_cast<const float2*>(e->sh_tf32), per);
+    if (hipfftExecC2C(plan, buf, buf, HIPFFT_BACKWARD) != HIPFFT_SUCCESS) return fail(AOG_ERR_HIP, "hipfftExecC2C backward failed");
+    hipLaunchKernelGGL(aog::k_sh_intensity<float2>, g_img, dim3(256), 0, s, pad, e->sh_image, N, e->sh_scale * norm * norm);
+  }
   HIP_TRY(hipGetLastError());
   if (image_dev) HIP_TRY(hipMemcpyAsync(image_dev, e->sh_image, sizeof(double) * (size_t)e->B * N * N, hipMemcpyDeviceToDevice, s));
   return AOG_OK;
@@ -1225,9 +1264,7 @@ int aog_focal_image(aog_env* e, int env_index, float* field_dev, void* stream) {
   if (!e->n_focal) return fail(AOG_ERR_STATE, "aog_focal_image: focal_m1/focal_m2 were not uploaded");
   if (env_index < 0 || env_index >= e->B) return fail(AOG_ERR_INVALID, "aog_focal_image: env %d outside [0,%d)", env_index, e->B);
   const bool fast = e->cfg.precision == AOG_PRECISION_FAST;
-  if (fast && e->kernel != AOG_KERNEL_MFMA && !e->cfg.atm_dynamic) {
-    // psi_tile is always written by aog_set_screens in non-dynamic handles, whatever kernel steps them
-  }
+  if (fast && e->focal_m1f) return aog_focal_images(e, env_index, 1, field_dev, stream);   // the batched matrix-core path
   HIP_TRY(hipSetDevice(e->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int N = e->cfg.n_pupil, nf = e->n_focal;
@@ -1240,6 +1277,53 @@ int aog_focal_image(aog_env* e, int env_index, float* field_dev, void* stream) {
   hipLaunchKernelGGL(aog::k_cgemm_small, dim3((nf * nf + 255) / 256), dim3(256), 0, s, reinterpret_cast<const double2*>(e->focal_T),
                      reinterpret_cast<const double2*>(e->focal_m2), (double2*)nullptr, reinterpret_cast<float2*>(field_dev), nf, N, nf);
   HIP_TRY(hipGetLastError());
+  return AOG_OK;
+}
+
+int aog_focal_images(aog_env* e, int first, int count, float* field_dev, void* stream) {
+  if (!e || !field_dev) return fail(AOG_ERR_INVALID, "aog_focal_images: null argument");
+  if (!e->tables_ready || !e->screens_ready) return fail(AOG_ERR_STATE, "aog_focal_images before aog_upload_tables/aog_set_screens");
+  if (!e->n_focal) return fail(AOG_ERR_STATE, "aog_focal_images: focal_m1/focal_m2 were not uploaded");
+  if (first < 0 || count < 0 || first + count > e->B) return fail(AOG_ERR_INVALID, "aog_focal_images: env range outside [0,%d)", e->B);
+  if (e->cfg.precision != AOG_PRECISION_FAST || !e->focal_m1f)
+    return fail(AOG_ERR_UNSUPPORTED, "aog_focal_images: fast-precision handles only (use aog_focal_image on a float64 validation handle)");
+  if (count == 0) return AOG_OK;
+  HIP_TRY(hipSetDevice(e->device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int N = e->cfg.n_pupil, nf = e->n_focal;
+  const size_t N2 = (size_t)N * N;
+  int rc;
+  if (!e->focal_phase) {
+    // work buffers on first use: phases of the whole batch (the contraction runs on whole env tiles), E and T for a chunk of envs
+    e->focal_chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)e->B, ((size_t)256 << 20) / (N2 * 8)));
+    if ((rc = dev_alloc(e, &e->focal_phase, (size_t)e->n_etiles * e->n_ptiles * 1024, false)) != AOG_OK) return rc;
+    if ((rc = dev_alloc(e, &e->focal_Eb, (size_t)e->focal_chunk * N2 * 2, false)) != AOG_OK) return rc;
+    if ((rc = dev_alloc(e, &e->focal_Tb, (size_t)e->focal_chunk * nf * N * 2, false)) != AOG_OK) return rc;
+  }
+  if (e->cfg.atm_dynamic || e->kernel != AOG_KERNEL_MFMA) {
+    // (psi_tile is always current for quasi_static / semi_dynamic handles; dynamic handles refresh it every step for the MFMA kernel only)
+    if (e->cfg.atm_dynamic && (rc = pack_from_master(e, 0, e->B, s)) != AOG_OK) return rc;
+  }
+  // u = psi + Mt a with the CURRENT mirror state of every env (act16 is rewritten from act_dm: the VALU step kernel does not keep it)
+  {
+    const int n = e->B * e->A_pad;
+    hipLaunchKernelGGL(aog::k_load_actuators, dim3((n + 255) / 256), dim3(256), 0, s, e->act_dm, e->act_rev, e->act16, e->B, e->A, e->A_pad, e->Bp,
+                       2.0 / e->cfg.wavelength_wfs);
+  }
+  aog_host::launch_phase(e, s, e->act16, e->focal_phase);
+  for (int done = 0; done < count; done += e->focal_chunk) {
+    const int nb = std::min(e->focal_chunk, count - done);
+    HIP_TRY(hipMemsetAsync(e->focal_Eb, 0, sizeof(float) * 2 * N2 * nb, s));
+    hipLaunchKernelGGL(aog::k_focal_E_batched, dim3((e->n_ap + 255) / 256, nb), dim3(256), 0, s, e->focal_phase, e->ap_index,
+                       reinterpret_cast<float2*>(e->focal_Eb), first + done, e->n_ap, e->n_ptiles, (int)N2);
+    // T[b] = m1 (nf x N) . E[b] (N x N);   F[b] = T[b] (nf x N) . m2 (N x nf)
+    hipLaunchKernelGGL(aog::k_cgemm_mfma, dim3((N + 63) / 64, (nf + 63) / 64, nb), dim3(256), 0, s, reinterpret_cast<const float2*>(e->focal_m1f),
+                       reinterpret_cast<const float2*>(e->focal_Eb), reinterpret_cast<float2*>(e->focal_Tb), nf, N, N, (size_t)0, N2, (size_t)nf * N);
+    hipLaunchKernelGGL(aog::k_cgemm_mfma, dim3((nf + 63) / 64, (nf + 63) / 64, nb), dim3(256), 0, s, reinterpret_cast<const float2*>(e->focal_Tb),
+                       reinterpret_cast<const float2*>(e->focal_m2f), reinterpret_cast<float2*>(field_dev) + (size_t)done * nf * nf, nf, nf, N,
+                       (size_t)nf * N, (size_t)0, (size_t)nf * nf);
+    HIP_TRY(hipGetLastError());
+  }
   return AOG_OK;
 }
 

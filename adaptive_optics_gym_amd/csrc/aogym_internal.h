@@ -51,8 +51,10 @@ struct aog_env {
   double* sh_act = nullptr;       // [B][A] deformable_mirror_shack.actuators
   _Float16* sh_act16 = nullptr;   // same, B-operand layout
   float* sh_phase = nullptr;      // psi_tile layout: wfs phase (rev) through the shack mirror
-  double* sh_pad = nullptr;       // [B][2N][2N] complex work buffer
-  double* sh_in = nullptr;       // [B][2N][2N] complex128: zero-padded forward input (padding never written)
+  void* sh_pad = nullptr;         // [B][2N][2N] complex work buffer (complex64, or complex128 when sh_double)
+  void* sh_in = nullptr;          // [B][2N][2N] zero-padded forward input (padding never written)
+  float* sh_tf32 = nullptr;       // [2N][2N] complex64 copy of the transfer function
+  bool sh_double = false;         // complex128 transforms (aog_sh_tables.fft_double)
   double* sh_image = nullptr;     // [B][N*N]
   double* sh_noisy = nullptr;     // [B][N*N]
   void* sh_plan = nullptr;        // hipfftHandle (Z2Z, batch B)
@@ -73,6 +75,12 @@ struct aog_env {
   double* focal_m2 = nullptr;    // [N][n_focal] complex
   double* focal_E = nullptr;     // [N][N] complex scratch
   double* focal_T = nullptr;     // [n_focal][N] complex scratch
+  float* focal_m1f = nullptr;    // complex64 copies for the batched matrix-core path (aog_focal_images)
+  float* focal_m2f = nullptr;
+  float* focal_phase = nullptr;  // [n_etiles][n_ptiles][1024] phases (revolutions) of the whole batch, psi_tile layout
+  float* focal_Eb = nullptr;     // [focal_chunk][N][N] complex64
+  float* focal_Tb = nullptr;     // [focal_chunk][n_focal][N] complex64
+  int focal_chunk = 0;
   // state
   float* psi_rev = nullptr;      // [n_quads][Bp][4]
   float* psi_tile = nullptr;     // [Bp/32][n_ptiles][4][64][4]
@@ -143,6 +151,6 @@ void launch_fused_apad16(aog_env* e, hipStream_t s);
 void launch_fused_apad32(aog_env* e, hipStream_t s);
 void launch_fused_apad64(aog_env* e, hipStream_t s);
 void launch_fused_apad128(aog_env* e, hipStream_t s);
-// phase-only contraction with the Shack-Hartmann mirror's actuators (sh_act16 -> sh_phase)
-void launch_sh_phase(aog_env* e, hipStream_t s);
+// phase-only contraction u = psi + Mt a for every (pixel, env) with the actuator operands `act16`, written in the psi_tile layout
+void launch_phase(aog_env* e, hipStream_t s, const _Float16* act16, float* out_tile);
 }  // namespace aog_host

@@ -1882,6 +1882,80 @@ __global__ void k_focal_field(const float* __restrict__ psi_tile, const double* 
   E[ap_index[p]] = make_double2(cs, sn);
 }
 
+// K4, batched: E of a chunk of envs from the phase tiles k_phase_mfma wrote (u = psi + Mt a in revolutions, psi_tile layout), dense
+// [env in chunk][N*N] complex64, zero outside the aperture (the caller clears the buffer first)
+__global__ void k_focal_E_batched(const float* __restrict__ phase_tile, const int32_t* __restrict__ ap_index, float2* __restrict__ E, int first,
+                                  int n_ap, int n_ptiles, int N2) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_ap) return;
+  const float u = phase_tile[psi_tile_index(first + blockIdx.y, p, n_ptiles)];
+  E[(size_t)blockIdx.y * N2 + ap_index[p]] = make_float2(__builtin_amdgcn_cosf(u), __builtin_amdgcn_sinf(u));   // (the instructions take revolutions)
+}
+
+// Batched complex GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact fp32 products; fp32 accumulation inside a 16-deep
+// K slice, float64 accumulation across slices — the partial sums of a 256-term coherent sum would otherwise round at 6e-8 of the PEAK,
+// which is 1e-5 of a pixel 30 dB below it):
+//   C[b] (M x Nc) = A[b or shared] (M x K) . B[b or shared] (K x Nc), complex64 interleaved, row-major; strideA / strideB = 0 for a
+// matrix shared by the whole batch.  Workgroup = 64 x 64 output tile (4 waves, 32 x 32 each), K in slices of 16 through LDS;
+// a complex product is four real MFMAs per 2 k (Cr += Ar Br - Ai Bi, Ci += Ar Bi + Ai Br).  Any M, Nc, K (edges are zero-filled).
+__global__ __launch_bounds__(256) void k_cgemm_mfma(const float2* __restrict__ A, const float2* __restrict__ B, float2* __restrict__ C, int M, int Nc,
+                                                    int K, size_t strideA, size_t strideB, size_t strideC) {
+  constexpr int KC = 16, LDA = KC + 1, LDB = 64 + 1;
+  __shared__ float2 As[64 * LDA];
+  __shared__ float2 Bs[KC * LDB];
+  const int b = blockIdx.z;
+  const float2* Ab = A + (size_t)b * strideA;
+  const float2* Bb = B + (size_t)b * strideB;
+  const int row0 = blockIdx.y * 64, col0 = blockIdx.x * 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  const int li = lane & 31, lk = lane >> 5;
+  typedef float f32x16v __attribute__((ext_vector_type(16)));
+  const f32x16v zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  double dr[16], di[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dr[r] = 0.0; di[r] = 0.0; }
+  for (int k0 = 0; k0 < K; k0 += KC) {
+    f32x16v cr = zero, ci = zero;
+    // A slice: 64 rows x 16 k (4 threads per row, 4 consecutive k each); B slice: 16 k x 64 columns (16 threads per k row, 4 columns each)
+    {
+      const int r = threadIdx.x >> 2, kk = (threadIdx.x & 3) * 4;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int gr = row0 + r, gk = k0 + kk + u;
+        As[r * LDA + kk + u] = (gr < M && gk < K) ? Ab[(size_t)gr * K + gk] : make_float2(0.f, 0.f);
+      }
+      const int kr = threadIdx.x >> 4, cc = (threadIdx.x & 15) * 4;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int gk = k0 + kr, gc = col0 + cc + u;
+        Bs[kr * LDB + cc + u] = (gk < K && gc < Nc) ? Bb[(size_t)gk * Nc + gc] : make_float2(0.f, 0.f);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < KC; ks += 2) {
+      const float2 a = As[(wm + li) * LDA + ks + lk];
+      const float2 bb = Bs[(ks + lk) * LDB + wn + li];
+      cr = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bb.x, cr, 0, 0, 0);
+      cr = __builtin_amdgcn_mfma_f32_32x32x2f32(-a.y, bb.y, cr, 0, 0, 0);
+      ci = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bb.y, ci, 0, 0, 0);
+      ci = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bb.x, ci, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dr[r] += (double)cr[r]; di[r] += (double)ci[r]; }
+    __syncthreads();
+  }
+  // accumulator map: lane holds column li, rows (r & 3) + 8 (r >> 2) + 4 lk
+  float2* Cb = C + (size_t)b * strideC;
+  const int gc = col0 + wn + li;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int gr = row0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lk;
+    if (gr < M && gc < Nc) Cb[(size_t)gr * Nc + gc] = make_float2((float)dr[r], (float)di[r]);
+  }
+}
+
 // out[r][c] = sum_k a[r][k] * b[k][c]  (complex, row-major), one thread per output
 __global__ void k_cgemm_small(const double2* __restrict__ a, const double2* __restrict__ b, double2* __restrict__ out, float2* __restrict__ out32,
                               int R, int K, int Cn) {
@@ -2459,8 +2533,10 @@ __global__ __launch_bounds__(64 * kColsWaves) void k_screen_cols(ScreenSynthArgs
 // centre of gravity per selected lenslet -> reconstructor GEMV + leaky integrator.
 // ------------------------------------------------------------------------------------------------
 #ifdef AOG_MAIN_TU
+// CT = double2 (complex128 transforms) or float2 (complex64: the default — the detector image is photon-noise limited at 1e-3, see aog_sh_tables)
+template <typename CT>
 __global__ void k_sh_field(const float* __restrict__ phase_tile, const int32_t* __restrict__ ap_index, const double2* __restrict__ mla_phase,
-                           double2* __restrict__ pad, int n_ap, int n_ptiles, int N, double amplitude) {
+                           CT* __restrict__ pad, int n_ap, int n_ptiles, int N, double amplitude) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   const int env = blockIdx.y;
   if (p >= n_ap) return;
@@ -2471,7 +2547,10 @@ __global__ void k_sh_field(const float* __restrict__ phase_tile, const int32_t* 
   const int iy = flat / N, ix = flat - iy * N;
   const double2 m = mla_phase[flat];
   // E * mla: (cs + i sn) * (m.x + i m.y)
-  pad[(size_t)env * 4 * N * N + (size_t)iy * 2 * N + ix] = make_double2(amplitude * (cs * m.x - sn * m.y), amplitude * (cs * m.y + sn * m.x));
+  CT v;
+  v.x = (decltype(v.x))(amplitude * (cs * m.x - sn * m.y));
+  v.y = (decltype(v.y))(amplitude * (cs * m.y + sn * m.x));
+  pad[(size_t)env * 4 * N * N + (size_t)iy * 2 * N + ix] = v;
 }
 
 // deformable_mirror_shack.actuators (metres, float64) -> the f16 hi/lo B-operand layout
@@ -2482,21 +2561,26 @@ __global__ void k_sh_act16(const double* __restrict__ sh_act, _Float16* __restri
   store_act16(act16, env, i, A_pad, (i < A) ? (float)(sh_act[(size_t)env * A + i] * two_over_lambda) : 0.f);
 }
 
-__global__ void k_sh_transfer(double2* __restrict__ f, const double2* __restrict__ tf, size_t per_env) {
+template <typename CT>
+__global__ void k_sh_transfer(CT* __restrict__ f, const CT* __restrict__ tf, size_t per_env) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= per_env) return;
-  double2* v = f + (size_t)blockIdx.y * per_env + idx;
-  const double2 a = *v, b = tf[idx];
-  *v = make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+  CT* v = f + (size_t)blockIdx.y * per_env + idx;
+  const CT a = *v, b = tf[idx];
+  CT o;
+  o.x = a.x * b.x - a.y * b.y;
+  o.y = a.x * b.y + a.y * b.x;
+  *v = o;
 }
 
-__global__ void k_sh_intensity(const double2* __restrict__ f, double* __restrict__ image, int N, double scale) {
+template <typename CT>
+__global__ void k_sh_intensity(const CT* __restrict__ f, double* __restrict__ image, int N, double scale) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int env = blockIdx.y;
   if (idx >= N * N) return;
   const int iy = idx / N, ix = idx - iy * N;
-  const double2 v = f[(size_t)env * 4 * N * N + (size_t)iy * 2 * N + ix];
-  image[(size_t)env * N * N + idx] = (v.x * v.x + v.y * v.y) * scale;
+  const CT v = f[(size_t)env * 4 * N * N + (size_t)iy * 2 * N + ix];
+  image[(size_t)env * N * N + idx] = ((double)v.x * (double)v.x + (double)v.y * (double)v.y) * scale;
 }
 
 // hcipy.util.large_poisson with the handle's Philox stream: normal approximation above 1e6 (like hcipy), and below it exact

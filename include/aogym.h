@@ -184,6 +184,10 @@ typedef struct {
   double field_amplitude;       /* amplitude of wf_wfs on the aperture / magnification                              */
   double image_scale;           /* magnified pixel area x delta_t: image = |E|^2 * image_scale                      */
   double gain, leakage;         /* 0.3, 0.01 (AO_env.py:282-283)                                                    */
+  int32_t fft_double;           /* 0 (default): the Fresnel propagation runs complex64 transforms — relative error ~1e-6 of the image
+                                   peak, far below the photon noise (>= 1e-3) large_poisson adds before anything reads the image;
+                                   1: complex128 transforms (bit-for-bit comparisons of the noise-free image with a float64 oracle) */
+  int32_t reserved0;
 } aog_sh_tables;
 int aog_upload_sh(aog_env* env, const aog_sh_tables* sh);
 
@@ -242,6 +246,11 @@ int aog_step(aog_env* env, const float* action_dev, float* obs_raw_dev, uint16_t
  * arm with the current screen and mirror, as interleaved (re, im) float32, row-major (y, x), up to a global phase (the
  * library stores screens with their aperture mean removed).  Off the step() path; used for render()/fiber cross-checks. */
 int aog_focal_image(aog_env* env, int env_index, float* field_dev /* [n_focal][n_focal][2] */, void* stream);
+
+/* The same field for envs [first, first + count) in one call: field_dev [count][n_focal][n_focal][2] float32.  Fast-precision handles
+ * only.  E = exp(i phi) on the pupil grid from the split-f16 phase contraction of the step kernels, then the two matrices of the
+ * Fraunhofer matrix Fourier transform as batched complex GEMMs on the fp32 matrix cores (v_mfma_f32_32x32x2_f32). */
+int aog_focal_images(aog_env* env, int first, int count, float* field_dev, void* stream);
 
 /* ---- policy query of the rollout (Actor.forward + Actor.get_action, network.py:17-69; caller algorithm.py:216-296) ----
  * mean = W_o drop(relu(W_3 drop(relu(W_2 drop(relu(W_1 obs + b_1)) + b_2)) + b_3)) + b_o with nn.Dropout(dropout_p) ACTIVE

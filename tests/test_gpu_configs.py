@@ -210,7 +210,9 @@ def test_config5_shack_hartmann_ssim_sampled_envs_vs_oracle():
         for b in ids:
             r_act[b], _ = refs[b].SH_step()
             clean = refs[b].last_sh_image_noiseless
-            np.testing.assert_allclose(img[b].cpu().numpy(), clean, rtol=1e-5, atol=1e-7 * clean.max())
+            # default complex64 Fresnel transforms: ~1e-6 of the image peak (complex128 is held to 1e-5 relative at N = 96 in
+            # test_shack_hartmann_chain_matches_oracle and below at this shape); the photon noise added next is >= 1e-3
+            np.testing.assert_allclose(img[b].cpu().numpy(), clean, rtol=0, atol=5e-6 * clean.max())
             img[b] = torch.from_numpy(np.round(refs[b].last_sh_noisy)).to(img.device)   # replay the oracle's photon noise exactly
         a = env.sh_update(img)
         for b in ids:
@@ -227,6 +229,15 @@ def test_config5_shack_hartmann_ssim_sampled_envs_vs_oracle():
         obs, rew, done, _, info = env.step(a)
     assert bool(torch.isfinite(rew).all()) and float(info["strehl"].max()) <= 1
     assert float(info["strehl"].mean()) > float(first.mean())     # the leaky integrator keeps closing the loop
+    scr0 = env.get_screens(0, 2).cpu()
+    env.close()
+    # complex128 transforms at the same shape: the noise-free sensor image within 1e-5 relative of the oracle's
+    env = BatchedAOEnv(2, "cuda:0", num_pupil_pixels=N, screens=scr0, sh_fft_precision="double", verbose=False, **kw)
+    ref = AOEnvOracle(num_pupil_pixels=N, screen=scr0[0].numpy().ravel(), rng=np.random.RandomState(1), verbose=False, **kw)
+    env.reset(); ref.reset()
+    ref.SH_step()
+    clean = ref.last_sh_image_noiseless
+    np.testing.assert_allclose(env.sh_image()[0].cpu().numpy(), clean, rtol=1e-5, atol=1e-7 * clean.max())
     env.close()
 
 
