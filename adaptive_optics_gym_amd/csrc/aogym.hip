@@ -233,7 +233,7 @@ size_t ext16_lds(const aog_env* e) {
 
 size_t ext_split_lds(const aog_env* e) {
   return ((size_t)aog::kExt16G * (aog::ext_split_stride(std::max(e->nz_v, e->nz_h)) + aog::ext_split_stride(e->cfg.n_pupil)) +
-          (size_t)(aog::kExtKsMax - 1) * 4 * 256) * sizeof(double);
+          (size_t)(aog::kExtKsMax - 1) * 4 * 256) * sizeof(double) + (size_t)(e->nz_v + e->nz_h) * sizeof(int32_t);
 }
 
 int evolve_layer(aog_env* e, hipStream_t s) {
@@ -266,27 +266,10 @@ int evolve_layer(aog_env* e, hipStream_t s) {
   p.sqrt_cn2 = e->sqrt_cn2;
   p.seed = e->rng_seed;
   p.env_base = e->cfg.env_id_base;
-  // the lock-step round kernel (k_extrude_round) is correct but not yet faster than the per-group kernel: opt-in
-  const bool use_rounds = e->rounds_ok && e->B >= 64 && getenv("AOG_EXTRUDE_ROUNDS") != nullptr;
-  if (use_rounds) {
-    // per axis at most ceil(|v| dt / pitch) + 1 whole-pixel shifts in one step
-    const int R = (int)std::ceil(e->max_wind * e->delta_t / e->pitch) + 1;
-    aog::ExtrudeRoundArgs q{};
-    q.a = p;
-    q.B = e->B;
-    dim3 grid((e->cfg.n_pupil + 31) / 32, (e->B + 31) / 32);
-    for (int phase = 0; phase < 2; ++phase)
-      for (int r = 0; r < R; ++r) {
-        q.origin_in = e->origin;
-        q.origin_out = e->origin_alt;
-        q.phase = phase;
-        q.round = r;
-        hipLaunchKernelGGL(aog::k_extrude_round, grid, dim3(256), 0, s, q);
-        std::swap(e->origin, e->origin_alt);
-      }
-    hipLaunchKernelGGL(aog::k_extrude_finish, dim3((e->B + 255) / 256), dim3(256), 0, s, p, e->B);
-    HIP_TRY(hipGetLastError());
-  } else if (e->ext_bar && !getenv("AOG_EXTRUDE_SIMPLE") && !getenv("AOG_EXTRUDE_NOSPLIT") && ext_split_lds(e) <= kLdsBytes) {
+  p.ring = e->ring_direct ? e->psi_ring : nullptr;
+  p.ring_ref = e->psi_offset;
+  p.ring_inv = 1.0 / (2.0 * M_PI * e->cfg.wavelength_wfs);
+  if (e->ext_bar && !getenv("AOG_EXTRUDE_SIMPLE") && !getenv("AOG_EXTRUDE_NOSPLIT") && ext_split_lds(e) <= kLdsBytes) {
     // float64 matrix-core form with each 16-env group's rows split over four workgroups + group barrier
     const size_t lds = ext_split_lds(e);
     static const int ks = getenv("AOG_EXTRUDE_KS") ? atoi(getenv("AOG_EXTRUDE_KS")) : 2;
@@ -314,7 +297,32 @@ int evolve_layer(aog_env* e, hipStream_t s) {
   }
   e->next_noise = nullptr;
   e->next_noise_max_ext = 0;
+  if (e->ring_direct) {   // the extrusion kept the fp32 ring copy in step: nothing to repack
+    e->tiles_stale = true;
+    return AOG_OK;
+  }
   return pack_from_master(e, 0, e->B, s, true);
+}
+
+// psi_tile of a ring-direct handle is only refreshed when something other than the step kernel needs it
+int ensure_tiles(aog_env* e, hipStream_t s) {
+  if (!e->ring_direct || !e->tiles_stale) return AOG_OK;
+  const double inv = 1.0 / (2.0 * M_PI * e->cfg.wavelength_wfs);
+  const int N2 = e->cfg.n_pupil * e->cfg.n_pupil;
+  hipLaunchKernelGGL((aog::k_pack_screens<double>), dim3(e->B), dim3(256), 0, s, e->psi_master, e->ap_index, (float*)nullptr, e->psi_tile,
+                     (double*)nullptr, 0, N2, e->n_ap, e->n_ap_pad, e->Bp, inv, (const int32_t*)e->origin, e->cfg.n_pupil, (double*)nullptr,
+                     (double*)nullptr);
+  HIP_TRY(hipGetLastError());
+  e->tiles_stale = false;
+  return AOG_OK;
+}
+
+int ring_from_master(aog_env* e, int first, int count, int keep_ref, hipStream_t s) {
+  hipLaunchKernelGGL(aog::k_ring_from_master, dim3(count), dim3(256), 0, s, e->psi_master, e->origin, e->ap_index, e->psi_offset, e->psi_ring, first,
+                     e->cfg.n_pupil, e->n_ap, 1.0 / (2.0 * M_PI * e->cfg.wavelength_wfs), keep_ref);
+  HIP_TRY(hipGetLastError());
+  e->tiles_stale = true;
+  return AOG_OK;
 }
 
 // A bounded inter-workgroup wait of an earlier launch timed out (k_extrude16_split): every screen that launch touched is suspect.
@@ -342,7 +350,7 @@ int set_screens(aog_env* e, const T* psi, int first, int count, hipStream_t s) {
     hipLaunchKernelGGL((aog::k_store_master<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, psi, e->psi_master, e->origin,
                        e->ext_counter, first, count, N2);
     HIP_TRY(hipGetLastError());
-    int rc = pack_from_master(e, first, count, s);
+    int rc = e->ring_direct ? ring_from_master(e, first, count, 0, s) : pack_from_master(e, first, count, s);
     if (rc != AOG_OK) return rc;
   } else {
     hipLaunchKernelGGL((aog::k_pack_screens<T>), dim3(count), dim3(256), 0, s, psi, e->ap_index, e->psi_rev, e->psi_tile,
@@ -494,7 +502,6 @@ int aog_create(const aog_config* cfg, int device, aog_env** out) {
     const size_t N2 = (size_t)cfg->n_pupil * cfg->n_pupil;
     TRY_ALLOC(dev_alloc(e, &e->psi_master, (size_t)e->B * N2));
     TRY_ALLOC(dev_alloc(e, &e->origin, (size_t)e->B * 2));
-    TRY_ALLOC(dev_alloc(e, &e->origin_alt, (size_t)e->B * 2));
     e->n_ext_groups = (e->B + aog::kExt16G - 1) / aog::kExt16G;
     TRY_ALLOC(dev_alloc(e, &e->ext_bar, (size_t)round_up(e->n_ext_groups, 8)));
     TRY_ALLOC(dev_alloc(e, &e->ext_perm, (size_t)e->n_ext_groups * aog::kExt16G));
@@ -556,6 +563,7 @@ int aog_get_info(const aog_env* e, aog_info* out) {
   out->pixel_chunks = e->n_chunks;
   out->kernel = e->kernel;
   out->n_sums = 2 * (e->MRW + e->MRS);
+  out->reserved = e->ring_direct ? 1 : 0;
   out->device_bytes = e->dev_bytes;
   return AOG_OK;
 }
@@ -639,6 +647,44 @@ int aog_upload_tables(aog_env* e, const aog_tables* t) {
     HIP_TRY(hipMemcpy(e->modes16, m16.data(), sizeof(_Float16) * m16.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->tabs_f32, tf.data(), sizeof(float) * tf.size(), hipMemcpyHostToDevice));
   }
+  if (e->cfg.atm_dynamic && e->cfg.precision == AOG_PRECISION_FAST && e->kernel == AOG_KERNEL_MFMA && !e->psi_ring && !getenv("AOG_DYNAMIC_REPACK")) {
+    // ring-direct form: where every packed 4-pixel group of every tile starts on the pupil grid, and where it continues when the
+    // aperture's row ends inside it.  A group that would touch three rows (pupils of a dozen pixels) keeps the repack form.
+    const int N = e->cfg.n_pupil;
+    std::vector<uint32_t> desc((size_t)e->n_ptiles * 8, 4u), cont((size_t)e->n_ptiles * 8, 0u);
+    bool ok = N >= 8 && N < 16384;
+    for (int pt = 0; pt < e->n_ptiles && ok; ++pt)
+      for (int g = 0; g < 4; ++g) {
+        bool straddle = false;
+        for (int hh = 0; hh < 2; ++hh) {
+          const int p0 = 32 * pt + 8 * g + 4 * hh;
+          const size_t slot = ((size_t)pt * 2 + hh) * 4 + g;
+          if (p0 >= n_ap) continue;   // padding group: reads logical (0, 0), its table rows are zero
+          const int f0 = t->ap_index[p0], iy = f0 / N, ix = f0 % N;
+          int k = 1;
+          while (k < 4 && p0 + k < n_ap && t->ap_index[p0 + k] == f0 + k && ix + k < N) ++k;
+          if (k < 4 && p0 + k >= n_ap) k = 4;   // the batch of pixels ends here: the rest of the group is padding
+          desc[slot] = ((uint32_t)iy << 18) | ((uint32_t)ix << 4) | (uint32_t)k;
+          if (k < 4) {
+            const int f2 = t->ap_index[p0 + k], iy2 = f2 / N, ix2 = f2 % N;
+            for (int q = k + 1; q < 4 && p0 + q < n_ap; ++q) ok = ok && t->ap_index[p0 + q] == f2 + (q - k) && ix2 + (q - k) < N;
+            cont[slot] = ((uint32_t)iy2 << 18) | ((uint32_t)((ix2 - k + N) % N) << 4);
+            straddle = true;
+          }
+        }
+        if (straddle)
+          for (int hh = 0; hh < 2; ++hh) desc[((size_t)pt * 2 + hh) * 4 + g] |= 8u;
+      }
+    if (ok) {
+      int rc;
+      if ((rc = dev_alloc(e, &e->quad_desc, desc.size(), false)) != AOG_OK) return rc;
+      if ((rc = dev_alloc(e, &e->quad_cont, cont.size(), false)) != AOG_OK) return rc;
+      if ((rc = dev_alloc(e, &e->psi_ring, (size_t)e->B * N * (N + 4), true)) != AOG_OK) return rc;
+      HIP_TRY(hipMemcpy(e->quad_desc, desc.data(), sizeof(uint32_t) * desc.size(), hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(e->quad_cont, cont.data(), sizeof(uint32_t) * cont.size(), hipMemcpyHostToDevice));
+      e->ring_direct = true;
+    }
+  }
   if (t->focal_m1 && t->focal_m2 && t->n_focal > 0 && !e->focal_m1) {
     const int N = e->cfg.n_pupil, nf = t->n_focal;
     int rc;
@@ -691,7 +737,7 @@ int aog_upload_layer(aog_env* e, const aog_layer_tables* t) {
   bool safe = true;
   for (int k = 0; k < t->nz_vertical; ++k) safe &= t->stencil_vertical[k] / N != N - 1;
   for (int k = 0; k < t->nz_horizontal; ++k) safe &= t->stencil_horizontal[k] % N != N - 1;
-  e->rounds_ok = safe;
+  (void)safe;
   HIP_TRY(hipSetDevice(e->device));
   e->nz_v = t->nz_vertical;
   e->nz_h = t->nz_horizontal;
@@ -998,6 +1044,7 @@ int aog_sh_image(aog_env* e, double* image_dev, void* stream) {
   const size_t per = (size_t)4 * N * N;
   hipfftHandle plan = (hipfftHandle)(uintptr_t)e->sh_plan;
   if (hipfftSetStream(plan, s) != HIPFFT_SUCCESS) return fail(AOG_ERR_HIP, "hipfftSetStream failed");
+  if (int rct = ensure_tiles(e, s)) return rct;
   {
     const int n = e->B * e->A_pad;
     hipLaunchKernelGGL(aog::k_sh_act16, dim3((n + 255) / 256), dim3(256), 0, s, e->sh_act, e->sh_act16, e->B, e->A, e->A_pad,
@@ -1081,7 +1128,9 @@ std::vector<StatePart> state_parts(const aog_env* e) {
   add(e->act_dm, sizeof(double) * e->B * e->A);
   add(e->t_render, sizeof(int32_t) * e->B);
   add(e->screen_gen, sizeof(uint32_t) * e->B);
-  if (e->cfg.precision == AOG_PRECISION_FAST) {
+  if (e->ring_direct) {
+    // (the fp32 layouts of a ring-direct handle are functions of the master screens, origins and reference pistons saved below)
+  } else if (e->cfg.precision == AOG_PRECISION_FAST) {
     add(e->psi_tile, sizeof(float) * (size_t)e->n_etiles * e->n_ptiles * 1024);
     add(e->psi_rev, sizeof(float) * (size_t)e->n_quads * e->Bp * 4);
   } else {
@@ -1149,6 +1198,10 @@ int aog_set_state(aog_env* e, const void* blob_dev, int64_t timestep, void* stre
     HIP_TRY(hipMemset(e->dev_status, 0, sizeof(int)));
     *static_cast<volatile int*>(e->host_flag) = 0;
   }
+  if (e->ring_direct) {
+    int rc = ring_from_master(e, 0, e->B, 1, s);
+    if (rc != AOG_OK) return rc;
+  }
   // derived operand layouts follow the restored actuators
   const int n = e->B * e->A_pad;
   hipLaunchKernelGGL(aog::k_load_actuators, dim3((n + 255) / 256), dim3(256), 0, s, e->act_dm, e->act_rev, e->act16, e->B, e->A, e->A_pad, e->Bp,
@@ -1166,6 +1219,7 @@ int aog_get_phase_screen(aog_env* e, int env_index, float* phase_dev, void* stre
   HIP_TRY(hipSetDevice(e->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
   const size_t N2 = (size_t)e->cfg.n_pupil * e->cfg.n_pupil;
+  if (int rct = ensure_tiles(e, s)) return rct;
   HIP_TRY(hipMemsetAsync(phase_dev, 0, sizeof(float) * N2, s));
   hipLaunchKernelGGL(aog::k_phase_screen, dim3((e->n_ap + 255) / 256), dim3(256), 0, s, e->psi_tile, e->ap_index, phase_dev, env_index, e->n_ap,
                      e->n_ptiles);
@@ -1300,10 +1354,9 @@ int aog_focal_images(aog_env* e, int first, int count, float* field_dev, void* s
     if ((rc = dev_alloc(e, &e->focal_Eb, (size_t)e->focal_chunk * N2 * 2, false)) != AOG_OK) return rc;
     if ((rc = dev_alloc(e, &e->focal_Tb, (size_t)e->focal_chunk * nf * N * 2, false)) != AOG_OK) return rc;
   }
-  if (e->cfg.atm_dynamic || e->kernel != AOG_KERNEL_MFMA) {
-    // (psi_tile is always current for quasi_static / semi_dynamic handles; dynamic handles refresh it every step for the MFMA kernel only)
-    if (e->cfg.atm_dynamic && (rc = pack_from_master(e, 0, e->B, s)) != AOG_OK) return rc;
-  }
+  // psi_tile is always current for quasi_static / semi_dynamic handles; dynamic ones refresh it here when the step kernel does not use it
+  if ((rc = ensure_tiles(e, s)) != AOG_OK) return rc;
+  if (e->cfg.atm_dynamic && !e->ring_direct && e->kernel != AOG_KERNEL_MFMA && (rc = pack_from_master(e, 0, e->B, s)) != AOG_OK) return rc;
   // u = psi + Mt a with the CURRENT mirror state of every env (act16 is rewritten from act_dm: the VALU step kernel does not keep it)
   {
     const int n = e->B * e->A_pad;

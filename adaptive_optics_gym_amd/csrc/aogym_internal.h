@@ -91,8 +91,12 @@ struct aog_env {
   int32_t* t_render = nullptr;   // [B]
   // dynamic atmosphere (cfg.atm_dynamic)
   bool layer_ready = false;
-  bool rounds_ok = false;        // stencils never sample the dropped row/column -> lock-step round kernel is race-free
-  int32_t* origin_alt = nullptr; // second origin buffer (rounds ping-pong)
+  // ring-direct form (fast MFMA handles): the fused kernel reads the fp32 ring copy of the master screens itself, no per-step repack
+  bool ring_direct = false;
+  bool tiles_stale = false;      // psi_tile (used by the focal-field / Shack-Hartmann / phase-screen paths) is older than the master screens
+  float* psi_ring = nullptr;     // [B][N][N + 4] fp32, see aog::DynPsi
+  uint32_t* quad_desc = nullptr; // [n_ptiles * 2][4]
+  uint32_t* quad_cont = nullptr; // [n_ptiles * 2][4]
   unsigned* ext_bar = nullptr;   // group-barrier tickets of k_extrude16_split (zeroed before every launch)
   int* dev_status = nullptr;     // sticky device-side error word (1 = a bounded spin timed out)
   int* host_flag = nullptr;      // the same flag in pinned, device-mapped host memory: read by the host without a synchronisation

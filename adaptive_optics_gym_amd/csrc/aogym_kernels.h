@@ -381,6 +381,27 @@ constexpr int kSkewNops = 150;   // x 16 cycles: start-up skew of the second wor
 // subtract / convert / pack.
 // Sums: tables m < MRW in the 32x32 accumulators (lane (env, h) holds rows (a & 3) + 8 (a >> 2) + 4 h); the 8-table variant
 // folds its (few) live rows into float64 every kFlushTiles tiles, the others run fp32 over a chunk of bounded length.
+// Dynamic atmosphere: the fused kernel reads the screens STRAIGHT from the fp32 ring-buffer copy of the float64 master screens instead
+// of a per-step repack into psi_tile (which re-read 537 MB and re-wrote 211 MB per step to move ~29 KB of new samples per env):
+//   ring   [B][N][RS] fp32, RS = N + 4: revolutions at lambda_wfs minus the env's reference piston, stored at the master's physical
+//          (toroidal) position; columns 0..3 are duplicated at N..N+3 so that 4 consecutive x never wrap
+//   origin [B][2] (ox, oy): logical (iy, ix) lives at physical ((iy + oy) mod N, (ix + ox) mod N)
+//   desc   [n_ptiles * 2][4]: for pixel tile t, half-wave h, register group g: the packed 4-pixel group starts at logical
+//          (iy, ix) = (d >> 18, (d >> 4) & 0x3fff); d & 7 = k = how many of its pixels lie in that row (4 = all); bit 3 = some group
+//          of this (t, g) (either half-wave) continues in another row (wave-uniform)
+//   cont   [n_ptiles * 2][4]: for a group with k < 4, where its pixel k sits MINUS k columns, (iy2 << 18 | ((ix2 - k) mod N) << 4):
+//          a second 16-byte load from there has the right values in elements k..3
+// Each lane (env, h) makes its own 16-byte load per group (4-byte aligned); the 32 envs of a tile hit 32 different lines, each of
+// which holds this tile's 32 pixels of that env, so no byte is fetched twice.
+struct DynPsi {
+  const float* ring;
+  const int32_t* origin;
+  const uint4* desc;
+  const uint4* cont;
+  int N, RS, B;
+};
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
 template <int MRW>
 struct TabGeom {
   static constexpr int kLiveRegs = MRW <= 8 ? 4 : (MRW <= 16 ? 8 : (MRW <= 24 ? 12 : 16));   // accumulator registers a < kLiveRegs hold real tables
@@ -389,10 +410,11 @@ struct TabGeom {
 __device__ __forceinline__ uint32_t pk_f16(float a, float b) {   // (half(a), half(b)) in one register; callers pass values exact in f16
   return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a, b));
 }
-template <int A_PAD, int MRW>
+template <int A_PAD, int MRW, bool DYN>
 __global__ __launch_bounds__(512, 2) void k_fused_tab(const f16x8* __restrict__ modes16, const f16x8* __restrict__ tab16,
                                                       const f32x4* __restrict__ sci_tile, const f32x4* __restrict__ psi_tile,
-                                                      const f16x8* __restrict__ act16, double* __restrict__ partials, MfmaGeom geo, float ratio) {
+                                                      const f16x8* __restrict__ act16, double* __restrict__ partials, MfmaGeom geo, float ratio,
+                                                      DynPsi dyn) {
   constexpr int NSTEP = A_PAD / 16, NM = 3 * NSTEP, NS = 2 * (MRW + 1);
   constexpr int LIVE = TabGeom<MRW>::kLiveRegs;
   constexpr bool F64 = TabGeom<MRW>::kF64;
@@ -444,6 +466,15 @@ __global__ __launch_bounds__(512, 2) void k_fused_tab(const f16x8* __restrict__ 
     }
   }
   const size_t psi_base = (size_t)etile_c * geo.n_ptiles;
+  // ring-buffer addressing of this lane's env (DYN only)
+  const float* ring_env = nullptr;
+  int dyn_ox = 0, dyn_oy = 0;
+  if constexpr (DYN) {
+    const int env = min(etile_c * 32 + (lane & 31), dyn.B - 1);
+    ring_env = dyn.ring + (size_t)env * dyn.N * dyn.RS;
+    dyn_ox = dyn.origin[2 * env];
+    dyn_oy = dyn.origin[2 * env + 1];
+  }
   auto load_modes = [&](f16x8 (&mh)[NSTEP], f16x8 (&ml)[NSTEP], int t) {
 #ifdef AOG_DEV
     if (geo.dev & 16) t = first;   // timing experiment: every tile's operands come from the same (cache-hot) addresses
@@ -458,18 +489,39 @@ __global__ __launch_bounds__(512, 2) void k_fused_tab(const f16x8* __restrict__ 
   // screen values of tile t, register groups [G0, G0 + NG) (4 registers = one 16-byte load each)
   auto load_psi = [&](auto g0c, auto ngc, f32x16& d, int t) {
     constexpr int G0 = decltype(g0c)::v, NG = decltype(ngc)::v;
-#ifdef AOG_DEV
-    if (geo.dev & 32) t = first;
-#endif
-    const f32x4* ps = psi_tile + ((psi_base + min(t, last)) * 4) * 64 + lane;
+    if constexpr (DYN) {
+      const int tt = min(t, last);
+      const uint4 dsc = dyn.desc[tt * 2 + h];
+      const uint32_t dd[4] = {dsc.x, dsc.y, dsc.z, dsc.w};
+      auto fetch = [&](uint32_t code) {   // 4 consecutive x from logical (code >> 18, (code >> 4) & 0x3fff) of this lane's env
+        uint32_t py = (code >> 18) + (uint32_t)dyn_oy, px = ((code >> 4) & 0x3fffu) + (uint32_t)dyn_ox;
+        py = min(py, py - (uint32_t)dyn.N);   // (unsigned: the wrapped candidate is huge unless py >= N)
+        px = min(px, px - (uint32_t)dyn.N);
+        return *reinterpret_cast<const f32x4u*>(ring_env + (size_t)py * dyn.RS + px);
+      };
 #pragma unroll
-    for (int g = G0; g < G0 + NG; ++g) {
-#ifdef AOG_DEV
-      const f32x4 v = (geo.dev & 1) ? __builtin_nontemporal_load(ps + g * 64) : ps[g * 64];
-#else
-      const f32x4 v = ps[g * 64];
-#endif
-      d[4 * g + 0] = v[0]; d[4 * g + 1] = v[1]; d[4 * g + 2] = v[2]; d[4 * g + 3] = v[3];
+      for (int g = G0; g < G0 + NG; ++g) {
+        f32x4 v = fetch(dd[g]);
+        if (dd[g] & 8u) {   // wave-uniform: a group of this (tile, g) continues in another row
+          const uint4 cnt = dyn.cont[tt * 2 + h];
+          const uint32_t cc[4] = {cnt.x, cnt.y, cnt.z, cnt.w};
+          const int k = (int)(dd[g] & 7u);
+          if (k < 4) {
+            const f32x4 w = fetch(cc[g]);
+            v[1] = k <= 1 ? w[1] : v[1];
+            v[2] = k <= 2 ? w[2] : v[2];
+            v[3] = w[3];
+          }
+        }
+        d[4 * g + 0] = v[0]; d[4 * g + 1] = v[1]; d[4 * g + 2] = v[2]; d[4 * g + 3] = v[3];
+      }
+    } else {
+      const f32x4* ps = psi_tile + ((psi_base + min(t, last)) * 4) * 64 + lane;
+#pragma unroll
+      for (int g = G0; g < G0 + NG; ++g) {
+        const f32x4 v = ps[g * 64];
+        d[4 * g + 0] = v[0]; d[4 * g + 1] = v[1]; d[4 * g + 2] = v[2]; d[4 * g + 3] = v[3];
+      }
     }
   };
   // Table rows m >= MRW are zero: the lanes that would fetch them all read ONE zero entry (row 31 of the first half) instead, so a
@@ -619,7 +671,7 @@ __global__ __launch_bounds__(512, 2) void k_fused_tab(const f16x8* __restrict__ 
       }
       if constexpr (NEXT) {   // the operands those matrix ops read are free again: request the next stage's
         load_modes(mh, ml, t + 2 * stride);
-        load_psi(IC<0>{}, IC<2>{}, P, t + 2 * stride);   // (pixels of register groups 0 and 1 are done)
+        if constexpr (!DYN) load_psi(IC<0>{}, IC<2>{}, P, t + 2 * stride);   // (pixels of register groups 0 and 1 are done)
       }
       {
         const f16x8* ts = tab16 + ((size_t)t * 4) * 64 + tlane;   // this tile's step-1 table operands (consumed next stage)
@@ -641,7 +693,9 @@ __global__ __launch_bounds__(512, 2) void k_fused_tab(const f16x8* __restrict__ 
         const f16x8* ts = tab16 + ((size_t)min(t + stride, last) * 4) * 64 + tlane;   // next tile's step-0 table operands
         ta[0] = ts[0];
         ta[1] = ts[64];
-        load_psi(IC<2>{}, IC<2>{}, P, t + 2 * stride);
+        // ring-direct: the four 16-byte pieces a lane takes from its env's 128-byte line go out together, while the line is in the L1
+        if constexpr (DYN) load_psi(IC<0>{}, IC<4>{}, P, t + 2 * stride);
+        else load_psi(IC<2>{}, IC<2>{}, P, t + 2 * stride);
       }
       if ((i % kFlushTiles) == kFlushTiles - 1) flush();
     };
@@ -980,6 +1034,9 @@ __global__ __launch_bounds__(1024) void k_epilogue(EpilogueArgs p) {
 // Matrices are stored transposed (At [nz][N], Bt [N][N]) so the N threads of a row read contiguous memory.
 // ------------------------------------------------------------------------------------------------
 struct ExtrudeArgs {
+  float* ring;               // nullable: fp32 ring copy the fused kernel reads ([B][N][N + 4], see DynPsi); kept in step with master
+  const double* ring_ref;    // [B] reference piston of the ring copy (hcipy units)
+  double ring_inv;           // 1 / (2 pi lambda_wfs)
   double* master;            // [B][N*N]
   int32_t* origin;           // [B][2] (ox, oy)
   uint32_t* ext_counter;     // [B] extrusions done so far (RNG stream position)
@@ -1002,6 +1059,19 @@ struct ExtrudeArgs {
   unsigned long long seed;
   int env_base;              // global id of env 0 of this handle: the Philox streams are keyed by env_base + env
 };
+
+// one new sample of env's master screen at physical (py, px): the float64 master and, when present, the fp32 ring copy (+ its duplicate
+// of columns 0..3 beyond the row end)
+__device__ __forceinline__ void store_master(const ExtrudeArgs& p, int env, int py, int px, double v) {
+  p.master[(size_t)env * p.N * p.N + (size_t)py * p.N + px] = v;
+  if (p.ring) {
+    const int RS = p.N + 4;
+    const float f = (float)((v - p.ring_ref[env]) * p.ring_inv);
+    float* row = p.ring + ((size_t)env * p.N + py) * RS;
+    row[px] = f;
+    if (px < 4) row[p.N + px] = f;
+  }
+}
 
 __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
   const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0];
@@ -1162,7 +1232,7 @@ __global__ __launch_bounds__(512) void k_extrude(ExtrudeArgs p, int B) {
           int py = ly + noy, px = lx + nox;
           if (py >= N) py -= N;
           if (px >= N) px -= N;
-          p.master[(size_t)(env0 + g) * N * N + (size_t)py * N + px] = v;
+          store_master(p, env0 + g, py, px, v);
         }
       }
       __syncthreads();
@@ -1321,7 +1391,7 @@ __global__ __launch_bounds__(512) void k_extrude16(ExtrudeArgs p, int B) {
             int py = ly + noy, px = lx + nox;
             if (py >= N) py -= N;
             if (px >= N) px -= N;
-            p.master[(size_t)(env0 + g) * N * N + (size_t)py * N + px] = v;
+            store_master(p, env0 + g, py, px, v);
           }
         }
       }
@@ -1369,6 +1439,8 @@ __global__ __launch_bounds__(256 * KS) void k_extrude16_split(ExtrudeArgs p, int
   double* zb = lds;
   double* nb = lds + (size_t)G * zs;
   double* pb = nb + (size_t)G * ns;
+  int32_t* st_v = reinterpret_cast<int32_t*>(pb + (size_t)(KS - 1) * 4 * 256);   // stencil codes (sy << 16 | sx), staged once
+  int32_t* st_h = st_v + p.nz_v;
   __shared__ int s_ox[G], s_oy[G], s_dx[G], s_dy[G], s_env[G];
   const int L = blockIdx.x;
   const int part = (L >> 3) & (kExtParts - 1);
@@ -1378,6 +1450,8 @@ __global__ __launch_bounds__(256 * KS) void k_extrude16_split(ExtrudeArgs p, int
   const int group = (L & 7) * groups_per_xcd + (L >> 5);
   const int env0 = group * G;
   if (env0 >= B) return;   // whole groups only: no barrier partner is left waiting
+  for (int i = threadIdx.x; i < p.nz_v; i += blockDim.x) st_v[i] = p.stencil_v_yx[i];
+  for (int i = threadIdx.x; i < p.nz_h; i += blockDim.x) st_h[i] = p.stencil_h_yx[i];
   if (threadIdx.x < G) {
     const int env = perm[env0 + threadIdx.x];   // slot -> env id (envs of similar wind share a group); -1 = padding slot
     int dx = 0, dy = 0, ox = 0, oy = 0;
@@ -1402,33 +1476,37 @@ __global__ __launch_bounds__(256 * KS) void k_extrude16_split(ExtrudeArgs p, int
   for (int r = 0; r < rounds; ++r) {
     long long t0 = dbg ? wall_clock64() : 0;
     auto cls = [&](int g) { return r < abs(s_dx[g]) ? 1 : (r < abs(s_dx[g]) + abs(s_dy[g]) ? 2 : 0); };
-    for (int base = threadIdx.x; base < G * nzmax; base += 4 * blockDim.x) {
-      double v[4];
-      int dst[4];
+    // every load of a batch is issued before any is consumed: the samples come from HBM (the master screens do not fit the caches), and
+    // with 4 conditional loads per thread in flight the gather was six dependent round trips per round (14 us); 12 unconditional
+    // ones make it two (9 us; what is left is HBM sector traffic: 8 bytes used of every 64 fetched.  A transposed copy of the
+    // master screens for the column stencils was tried: its scattered writes cost more than the contiguous reads saved)
+    constexpr int GD = 12;
+    for (int base = threadIdx.x; base < G * nzmax; base += GD * blockDim.x) {
+      double v[GD];
+      int dst[GD];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int idx = base + u * blockDim.x;
+      for (int u = 0; u < GD; ++u) {
+        // branch-free: every thread issues a load from a valid address (a branch around the load makes the compiler wait for it
+        // before the next one goes out); the stencil codes come from LDS, so the chain per sample is ONE memory round trip
+        const int raw = base + u * blockDim.x;
+        const int idx = min(raw, G * nzmax - 1);
         const int g = idx / nzmax, k = idx - g * nzmax;
-        dst[u] = -1;
-        v[u] = 0.0;
-        if (idx < G * nzmax) {
-          const int c = cls(g);
-          const bool horizontal = c == 1;
-          const int nz = horizontal ? p.nz_h : p.nz_v;
-          if (c && k < nz) {
-            const uint32_t pk = (uint32_t)(horizontal ? p.stencil_h_yx : p.stencil_v_yx)[k];
-            int sy = (int)(pk >> 16), sx = (int)(pk & 0xFFFFu);
-            if (horizontal ? s_dx[g] > 0 : s_dy[g] > 0) { sy = N - 1 - sy; sx = N - 1 - sx; }
-            int py = sy + s_oy[g], px = sx + s_ox[g];
-            if (py >= N) py -= N;
-            if (px >= N) px -= N;
-            v[u] = p.master[(size_t)s_env[g] * N * N + (size_t)py * N + px];
-            dst[u] = g * zs + k;
-          }
-        }
+        const int c = cls(g);
+        const bool horizontal = c == 1;
+        const int nz = horizontal ? p.nz_h : p.nz_v;
+        const uint32_t pk = (uint32_t)(horizontal ? st_h : st_v)[min(k, nz - 1)];
+        int sy = (int)(pk >> 16), sx = (int)(pk & 0xFFFFu);
+        const bool flipped = horizontal ? s_dx[g] > 0 : s_dy[g] > 0;
+        sy = flipped ? N - 1 - sy : sy;
+        sx = flipped ? N - 1 - sx : sx;
+        int py = sy + s_oy[g], px = sx + s_ox[g];
+        py -= py >= N ? N : 0;
+        px -= px >= N ? N : 0;
+        v[u] = p.master[(size_t)s_env[g] * N * N + (size_t)py * N + px];
+        dst[u] = (raw < G * nzmax && c != 0 && k < nz) ? g * zs + k : -1;
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < GD; ++u)
         if (dst[u] >= 0) zb[dst[u]] = v[u];
     }
     __syncthreads();
@@ -1545,7 +1623,7 @@ __global__ __launch_bounds__(256 * KS) void k_extrude16_split(ExtrudeArgs p, int
             int py = ly + noy, px = lx + nox;
             if (py >= N) py -= N;
             if (px >= N) px -= N;
-            p.master[(size_t)s_env[g] * N * N + (size_t)py * N + px] = v;
+            store_master(p, s_env[g], py, px, v);
           }
         }
       }
@@ -1596,157 +1674,6 @@ __global__ __launch_bounds__(256 * KS) void k_extrude16_split(ExtrudeArgs p, int
 }
 #endif  // AOG_MAIN_TU
 
-// ---- lock-step rounds: one launch = the r-th x (phase 0) or y (phase 1) extrusion of EVERY env --------------------------
-// out[row][env] = sum_k At[k][row] z_env[k] + sqrt(Cn^2) sum_j Bt[j][row] n_env[j]  is a [N x (nz+N)] x [(nz+N) x B] float64 matrix
-// product per round, so the AR matrices are streamed once per 32-env tile instead of once per env.  A workgroup owns a
-// 32-row x 32-env tile (256 threads, 2 x 2 outputs each), gathers its z / noise chunks straight from the ring buffers and
-// writes its part of the new slice in place.  That is race-free across workgroups because the slot being overwritten (the
-// row / column that drops out) is never a stencil sample; the host checks that property of the stencil and otherwise uses
-// k_extrude above.  Origins are double-buffered (read origin_in, write origin_out).
-struct ExtrudeRoundArgs {
-  ExtrudeArgs a;
-  const int32_t* origin_in;
-  int32_t* origin_out;
-  int B, phase, round;
-};
-
-#ifdef AOG_MAIN_TU
-__global__ __launch_bounds__(256) void k_extrude_round(ExtrudeRoundArgs q) {
-  constexpr int KC = 32;
-  __shared__ double Ws[KC][32];
-  __shared__ double Zs[KC][34];
-  __shared__ int s_act[32], s_flip[32], s_ox[32], s_oy[32], s_ext[32];
-  const ExtrudeArgs& p = q.a;
-  const int N = p.N;
-  const int row0 = blockIdx.x * 32, env0 = blockIdx.y * 32;
-  const bool horizontal = q.phase == 0;
-  if (threadIdx.x < 32) {
-    const int env = env0 + threadIdx.x;
-    int act = 0, flip = 0, ox = 0, oy = 0, ext = 0;
-    if (env < q.B) {
-      const double vx = p.velocity[2 * env], vy = p.velocity[2 * env + 1];
-      const int dx = (int)rint(vx * p.t_new / p.pitch) - (int)rint(vx * p.t_prev / p.pitch);
-      const int dy = (int)rint(vy * p.t_new / p.pitch) - (int)rint(vy * p.t_prev / p.pitch);
-      const int d = horizontal ? dx : dy;
-      act = q.round < abs(d);
-      flip = d > 0;
-      ox = q.origin_in[2 * env];
-      oy = q.origin_in[2 * env + 1];
-      ext = (horizontal ? 0 : abs(dx)) + q.round;
-    }
-    s_act[threadIdx.x] = act; s_flip[threadIdx.x] = flip; s_ox[threadIdx.x] = ox; s_oy[threadIdx.x] = oy; s_ext[threadIdx.x] = ext;
-  }
-  __syncthreads();
-  // new origins (every workgroup needs them for the write-back; row block 0 publishes them)
-  auto new_origin = [&](int e, int& nox, int& noy) {
-    nox = s_ox[e]; noy = s_oy[e];
-    if (!s_act[e]) return;
-    if (horizontal) nox = s_flip[e] ? (nox + 1 == N ? 0 : nox + 1) : (nox == 0 ? N - 1 : nox - 1);
-    else noy = s_flip[e] ? (noy + 1 == N ? 0 : noy + 1) : (noy == 0 ? N - 1 : noy - 1);
-  };
-  if (blockIdx.x == 0 && threadIdx.x < 32 && env0 + threadIdx.x < q.B) {
-    int nox, noy;
-    new_origin(threadIdx.x, nox, noy);
-    q.origin_out[2 * (env0 + threadIdx.x)] = nox;
-    q.origin_out[2 * (env0 + threadIdx.x) + 1] = noy;
-  }
-  bool any = false;
-  for (int e = 0; e < 32; ++e) any |= s_act[e] != 0;
-  if (!any) return;
-
-  const int nz = horizontal ? p.nz_h : p.nz_v;
-  const int32_t* st = horizontal ? p.stencil_h : p.stencil_v;
-  const double* At = horizontal ? p.At_h : p.At_v;
-  const double* Bt = horizontal ? p.Bt_h : p.Bt_v;
-  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;   // rows 2ty, 2ty+1; envs 2tx, 2tx+1
-  const int ge = threadIdx.x >> 3, gk = (threadIdx.x & 7) * 4;  // gather role: env ge, 4 consecutive k
-  double a00 = 0, a01 = 0, a10 = 0, a11 = 0, b00 = 0, b01 = 0, b10 = 0, b11 = 0;
-  for (int part = 0; part < 2; ++part) {
-    const int K = part == 0 ? nz : N;
-    const double* Wt = part == 0 ? At : Bt;
-    for (int k0 = 0; k0 < K; k0 += KC) {
-      // W chunk: KC x 32 rows (4 elements per thread, 256-B coalesced segments)
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int idx = threadIdx.x + 256 * u, kk = idx >> 5, i = idx & 31;
-        Ws[kk][i] = (k0 + kk < K && row0 + i < N) ? Wt[(size_t)(k0 + kk) * N + row0 + i] : 0.0;
-      }
-      // z / noise chunk of the 32 envs
-      {
-        const int env = env0 + ge;
-        const bool on = s_act[ge] != 0;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int k = k0 + gk + u;
-          double v = 0.0;
-          if (on && k < K) {
-            if (part == 0) {
-              int sy = st[k] / N, sx = st[k] - sy * N;
-              if (s_flip[ge]) { sy = N - 1 - sy; sx = N - 1 - sx; }
-              int py = sy + s_oy[ge], px = sx + s_ox[ge];
-              if (py >= N) py -= N;
-              if (px >= N) px -= N;
-              v = p.master[(size_t)env * N * N + (size_t)py * N + px];
-            } else {
-              const int e = s_ext[ge];
-              v = (p.noise && e < p.max_ext) ? p.noise[((size_t)env * p.max_ext + e) * N + k]
-                                             : philox_normal(p.seed, (uint32_t)(p.env_base + env), p.ext_counter[env] + (uint32_t)e, (uint32_t)k);
-            }
-          }
-          Zs[gk + u][ge] = v;
-        }
-      }
-      __syncthreads();
-      if (part == 0) {
-#pragma unroll 8
-        for (int kk = 0; kk < KC; ++kk) {
-          const double w0 = Ws[kk][2 * ty], w1 = Ws[kk][2 * ty + 1], z0 = Zs[kk][2 * tx], z1 = Zs[kk][2 * tx + 1];
-          a00 = fma(w0, z0, a00); a01 = fma(w0, z1, a01); a10 = fma(w1, z0, a10); a11 = fma(w1, z1, a11);
-        }
-      } else {
-#pragma unroll 8
-        for (int kk = 0; kk < KC; ++kk) {
-          const double w0 = Ws[kk][2 * ty], w1 = Ws[kk][2 * ty + 1], z0 = Zs[kk][2 * tx], z1 = Zs[kk][2 * tx + 1];
-          b00 = fma(w0, z0, b00); b01 = fma(w0, z1, b01); b10 = fma(w1, z0, b10); b11 = fma(w1, z1, b11);
-        }
-      }
-      __syncthreads();
-    }
-  }
-  const double outv[2][2] = {{a00 + b00 * p.sqrt_cn2, a01 + b01 * p.sqrt_cn2}, {a10 + b10 * p.sqrt_cn2, a11 + b11 * p.sqrt_cn2}};
-#pragma unroll
-  for (int ee = 0; ee < 2; ++ee) {
-    const int e = 2 * tx + ee;
-    if (!s_act[e]) continue;
-    int nox, noy;
-    new_origin(e, nox, noy);
-    const bool flipped = s_flip[e] != 0;
-#pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-      const int i = row0 + 2 * ty + rr;
-      if (i >= N) continue;
-      int ly, lx;
-      if (horizontal) { ly = flipped ? N - 1 - i : i; lx = flipped ? N - 1 : 0; }
-      else { ly = flipped ? N - 1 : 0; lx = flipped ? N - 1 - i : i; }
-      int py = ly + noy, px = lx + nox;
-      if (py >= N) py -= N;
-      if (px >= N) px -= N;
-      p.master[(size_t)(env0 + e) * N * N + (size_t)py * N + px] = outv[rr][ee];
-    }
-  }
-}
-
-// after the rounds of a step: advance every env's RNG stream position by its extrusion count
-__global__ void k_extrude_finish(ExtrudeArgs p, int B) {
-  const int env = blockIdx.x * blockDim.x + threadIdx.x;
-  if (env >= B) return;
-  const double vx = p.velocity[2 * env], vy = p.velocity[2 * env + 1];
-  const int dx = (int)rint(vx * p.t_new / p.pitch) - (int)rint(vx * p.t_prev / p.pitch);
-  const int dy = (int)rint(vy * p.t_new / p.pitch) - (int)rint(vy * p.t_prev / p.pitch);
-  p.ext_counter[env] += (uint32_t)(abs(dx) + abs(dy));
-}
-#endif  // AOG_MAIN_TU
-
 // caller screens -> float64 master (origin 0)
 template <typename T>
 __global__ void k_store_master(const T* __restrict__ psi, double* __restrict__ master, int32_t* __restrict__ origin,
@@ -1759,6 +1686,40 @@ __global__ void k_store_master(const T* __restrict__ psi, double* __restrict__ m
     origin[2 * (first + e)] = 0;
     origin[2 * (first + e) + 1] = 0;
     ext_counter[first + e] = 0;
+  }
+}
+
+// float64 master screens of envs [first, first + gridDim.x) -> the fp32 ring copy the fused kernel reads (DynPsi): one workgroup per
+// env; keep_ref = 0: the env's reference piston becomes the aperture mean of the screen as it stands (installation), 1: the stored
+// reference is kept (state restore: the copy must come out bit-identical to the one the extrusions maintained)
+__global__ __launch_bounds__(256) void k_ring_from_master(const double* __restrict__ master, const int32_t* __restrict__ origin,
+                                                          const int32_t* __restrict__ ap_index, double* __restrict__ ring_ref,
+                                                          float* __restrict__ ring, int first, int N, int n_ap, double inv, int keep_ref) {
+  __shared__ double sm[8];
+  const int env = first + blockIdx.x;
+  const double* src = master + (size_t)env * N * N;
+  const int ox = origin[2 * env], oy = origin[2 * env + 1];
+  double ref;
+  if (keep_ref) {
+    ref = ring_ref[env];
+  } else {
+    double acc = 0;
+    for (int p = threadIdx.x; p < n_ap; p += blockDim.x) {
+      const int flat = ap_index[p], iy = flat / N, ix = flat - iy * N;
+      int py = iy + oy, px = ix + ox;
+      if (py >= N) py -= N;
+      if (px >= N) px -= N;
+      acc += src[(size_t)py * N + px];
+    }
+    ref = block_reduce_sum(acc, sm) / (double)n_ap;
+    if (threadIdx.x == 0) ring_ref[env] = ref;
+  }
+  const int RS = N + 4;
+  float* dst = ring + (size_t)env * N * RS;
+  for (int i = threadIdx.x; i < N * RS; i += blockDim.x) {
+    const int py = i / RS, c = i - py * RS;
+    const int px = c < N ? c : c - N;
+    dst[i] = (float)((src[(size_t)py * N + px] - ref) * inv);
   }
 }
 

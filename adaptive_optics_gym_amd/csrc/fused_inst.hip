@@ -52,10 +52,25 @@ void launch_tab(aog_env* e, hipStream_t s) {
   dim3 grid(8 * wgs_per_xcd);
   const float ratio = (float)(e->cfg.wavelength_wfs / e->cfg.wavelength_sci);
   const size_t lds_t = (size_t)e->mfma_tpc * 8 * 16 + (A_PAD > 64 ? (size_t)e->mfma_waves * (A_PAD / 16) * 2 * 64 * 16 : 0);   // science rows (+ actuator operands)
-  aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_fused_tab<A_PAD, MRW>), lds_t, e->device);
-  hipLaunchKernelGGL((aog::k_fused_tab<A_PAD, MRW>), grid, dim3(threads), lds_t, s, reinterpret_cast<const aog::f16x8*>(e->modes16),
+  aog::DynPsi dyn{};
+  if (e->ring_direct) {   // dynamic atmosphere: the screens come straight from the fp32 ring copy of the master screens
+    dyn.ring = e->psi_ring;
+    dyn.origin = e->origin;
+    dyn.desc = reinterpret_cast<const uint4*>(e->quad_desc);
+    dyn.cont = reinterpret_cast<const uint4*>(e->quad_cont);
+    dyn.N = e->cfg.n_pupil;
+    dyn.RS = e->cfg.n_pupil + 4;
+    dyn.B = e->B;
+    aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_fused_tab<A_PAD, MRW, true>), lds_t, e->device);
+    hipLaunchKernelGGL((aog::k_fused_tab<A_PAD, MRW, true>), grid, dim3(threads), lds_t, s, reinterpret_cast<const aog::f16x8*>(e->modes16),
+                       reinterpret_cast<const aog::f16x8*>(e->tab16), reinterpret_cast<const aog::f32x4*>(e->sci_tile),
+                       reinterpret_cast<const aog::f32x4*>(e->psi_tile), reinterpret_cast<const aog::f16x8*>(e->act16), e->partials, g, ratio, dyn);
+    return;
+  }
+  aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_fused_tab<A_PAD, MRW, false>), lds_t, e->device);
+  hipLaunchKernelGGL((aog::k_fused_tab<A_PAD, MRW, false>), grid, dim3(threads), lds_t, s, reinterpret_cast<const aog::f16x8*>(e->modes16),
                      reinterpret_cast<const aog::f16x8*>(e->tab16), reinterpret_cast<const aog::f32x4*>(e->sci_tile),
-                     reinterpret_cast<const aog::f32x4*>(e->psi_tile), reinterpret_cast<const aog::f16x8*>(e->act16), e->partials, g, ratio);
+                     reinterpret_cast<const aog::f32x4*>(e->psi_tile), reinterpret_cast<const aog::f16x8*>(e->act16), e->partials, g, ratio, dyn);
 }
 
 template <int A_PAD, int MRW>

@@ -653,69 +653,96 @@ def test_batched_focal_images_match_oracle_propagator(N, B, A, act_type):
 
 
 def test_dynamic_extrusion_kernel_variants_agree(monkeypatch):
-    """The four extrusion kernels — float64 matrix-core form with a group's rows split over four workgroups and a group barrier
-    (default), the same in one workgroup per group (AOG_EXTRUDE_NOSPLIT), per-group vector form (AOG_EXTRUDE_SIMPLE) and the
-    lock-step round form (AOG_EXTRUDE_ROUNDS) — give the same screens on the same Philox stream (only the float64 summation
-    order differs; the two matrix-core forms agree to 1e-12), and no inter-workgroup wait timed out."""
+    """The extrusion kernels — float64 matrix-core form with a group's rows split over four workgroups and a group barrier (default),
+    the same in one workgroup per group (AOG_EXTRUDE_NOSPLIT), per-group vector form (AOG_EXTRUDE_SIMPLE) — give the same screens on
+    the same Philox stream (only the float64 summation order differs; the two matrix-core forms agree to 1e-12), no inter-workgroup
+    wait timed out; and the step kernel reading the fp32 ring copy directly (default) gives the observations of the per-step repack
+    form (AOG_DYNAMIC_REPACK)."""
     torch = _torch()
     from adaptive_optics_gym_amd import BatchedAOEnv
 
     def run(mode):
-        monkeypatch.delenv("AOG_EXTRUDE_ROUNDS", raising=False)
-        monkeypatch.delenv("AOG_EXTRUDE_SIMPLE", raising=False)
-        monkeypatch.delenv("AOG_EXTRUDE_NOSPLIT", raising=False)
+        for k in ("AOG_EXTRUDE_SIMPLE", "AOG_EXTRUDE_NOSPLIT", "AOG_DYNAMIC_REPACK"):
+            monkeypatch.delenv(k, raising=False)
         if mode:
             monkeypatch.setenv(mode, "1")
         env = BatchedAOEnv(70, "cuda:0", atm_type="dynamic", atm_vel=35, atm_fried=0.15, act_dim=6, act_type="zernike", obs_dim=2,
                            num_pupil_pixels=32, timesteps_per_episode=100, seed=11, screen_oversampling=4, verbose=False)
+        assert env.info.reserved == (0 if mode == "AOG_DYNAMIC_REPACK" else 1)      # ring-direct unless asked otherwise
         env.reset()
         a = torch.ones(70, 6, device="cuda")
         obs = None
         for _ in range(7):
             obs = env.step(a)[4]["obs_raw"]
-        out = env.get_screens().cpu().numpy(), obs.cpu().numpy()
+        out = env.get_screens().cpu().numpy(), obs.cpu().numpy(), env.phase_screen(3).cpu().numpy(), env.focal_image(69).cpu().numpy()
         assert env.device_status() == 0
         env.close()
         return out
 
-    s_simple, o_simple = run("AOG_EXTRUDE_SIMPLE")
+    s_simple, o_simple, ph_simple, f_simple = run("AOG_EXTRUDE_SIMPLE")
     s_split = None
-    for mode in (None, "AOG_EXTRUDE_NOSPLIT", "AOG_EXTRUDE_ROUNDS"):
-        s_other, o_other = run(mode)
+    for mode in (None, "AOG_EXTRUDE_NOSPLIT", "AOG_DYNAMIC_REPACK"):
+        s_other, o_other, ph_other, f_other = run(mode)
         np.testing.assert_allclose(s_other, s_simple, rtol=1e-9, atol=1e-12 * np.abs(s_simple).max())
         _assert_obs_close(o_other, o_simple)
+        # radians (fp32 screens), up to the piston: the repack form subtracts the aperture mean measured one step earlier
+        ap = ph_simple != 0
+        np.testing.assert_allclose(ph_other[ap] - ph_other[ap].mean(), ph_simple[ap] - ph_simple[ap].mean(), rtol=0, atol=3e-5)
+        assert not ph_other[~ap].any()
+        np.testing.assert_allclose(np.abs(f_other), np.abs(f_simple), rtol=0, atol=1e-5 * np.abs(f_simple).max())   # (global phase = piston)
         if mode is None:
             s_split = s_other
         elif mode == "AOG_EXTRUDE_NOSPLIT":
             np.testing.assert_allclose(s_other, s_split, rtol=1e-12, atol=1e-14 * np.abs(s_split).max())
 
 
-def test_dynamic_round_kernel_equals_per_env_kernel(monkeypatch):
-    """The lock-step round extrusion (32 envs share every AR-matrix row, one launch per round) gives the same screens as
-    the per-env-group kernel on the same Philox stream (only the float64 summation order differs)."""
+@pytest.mark.parametrize("N,vel", [(64, 70.0), (96, 45.0), (240, 12.0)])
+def test_dynamic_ring_direct_matches_oracle(N, vel):
+    """The step kernel reading the screens straight from the toroidal fp32 ring (per-lane 16-byte loads through the origin offsets, groups
+    that straddle an aperture row end patched from the next row) against the oracle's InfiniteAtmosphericLayer fed the same normals:
+    several pupil sizes (row lengths not multiples of 4 -> straddling groups; 240 = the reference's size), winds that wrap the ring."""
     torch = _torch()
+    from helpers import ScriptedRNG, device_mode_stencil_draws
     from adaptive_optics_gym_amd import BatchedAOEnv
+    from adaptive_optics_gym_amd.atmosphere_host import integer_shifts
+    from oracle.ao_env_oracle import AOEnvOracle
 
-    def run(simple):
-        if simple:
-            monkeypatch.delenv("AOG_EXTRUDE_ROUNDS", raising=False)
-        else:
-            monkeypatch.setenv("AOG_EXTRUDE_ROUNDS", "1")
-        env = BatchedAOEnv(70, "cuda:0", atm_type="dynamic", atm_vel=35, atm_fried=0.15, act_dim=6, act_type="zernike", obs_dim=2,
-                           num_pupil_pixels=32, timesteps_per_episode=100, seed=11, screen_oversampling=4, verbose=False)
-        env.reset()
-        a = torch.ones(70, 6, device="cuda")
-        obs = None
-        for _ in range(7):
-            obs = env.step(a)[4]["obs_raw"]
-        out = env.get_screens().cpu().numpy(), obs.cpu().numpy()
-        env.close()
-        return out
-
-    s_simple, o_simple = run(True)
-    s_round, o_round = run(False)
-    np.testing.assert_allclose(s_round, s_simple, rtol=1e-9, atol=1e-12 * np.abs(s_simple).max())
-    _assert_obs_close(o_round, o_simple)
+    B, A, T, seed = 37, 16, 12, 4
+    kw = dict(atm_type="dynamic", atm_vel=vel, atm_fried=0.15, act_type="num_actuators", act_dim=A, obs_dim=2, timesteps_per_episode=T)
+    env = BatchedAOEnv(B, "cuda:0", num_pupil_pixels=N, seed=seed, screen_source="device", screen_oversampling=4, verbose=False, **kw)
+    assert env.info.reserved == 1
+    geo = device_mode_stencil_draws(seed, B, N)
+    ids = [0, 17, B - 1]
+    refs = {}
+    for b in ids:
+        refs[b] = AOEnvOracle(num_pupil_pixels=N, screen=env.get_screens(b, 1)[0].cpu().numpy().ravel(),
+                              rng=ScriptedRNG(env.wind_u[b], [g.copy() for g in geo]), verbose=False, **kw)
+    env.reset()
+    for b in ids:
+        refs[b].reset()
+        _assert_obs_close(env.last_obs_raw[b].double().cpu().numpy(), refs[b].last_obs_raw)
+    gen = torch.Generator("cuda").manual_seed(5)
+    for t in range(2 * T):                       # two episodes: the origins travel more than once around the ring at the fast winds
+        a = torch.randn((B, A), device="cuda", generator=gen)
+        counts = np.abs(integer_shifts(env.velocity_vectors, env.timestep * env.delta_t, (env.timestep + 1) * env.delta_t,
+                                       env.params.pupil_pixel)).sum(axis=1)
+        noise = torch.randn((B, max(int(counts.max()), 1), N), device="cuda", dtype=torch.float64, generator=gen)
+        env.set_extrusion_noise(noise)
+        obs, rew, done, _, info = env.step(a)
+        for b in ids:
+            refs[b].rng.normals.extend(noise[b, :int(counts[b])].cpu().numpy())
+            _, r_rew, r_done, _, r_info = refs[b].step(a[b].cpu().numpy())
+            _assert_obs_close(info["obs_raw"][b].double().cpu().numpy(), refs[b].last_obs_raw)
+            np.testing.assert_allclose(float(info["strehl"][b]), refs[b].last_strehl, rtol=RTOL)
+            np.testing.assert_allclose(float(info["power"][b]), r_info["power"], rtol=RTOL)
+            assert bool(done[b]) == r_done
+        if bool(done.all()):
+            env.reset()
+            for b in ids:
+                refs[b].reset()
+                _assert_obs_close(env.last_obs_raw[b].double().cpu().numpy(), refs[b].last_obs_raw)
+    assert env.device_status() == 0
+    env.close()
 
 
 def test_device_screen_synthesis_statistics():
