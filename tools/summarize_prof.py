@@ -12,7 +12,7 @@ so it is doubled: traffic = (2*FETCH_SIZE + WRITE_SIZE) * 1024.
 import argparse, collections, csv, glob, json, os
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--stats"); ap.add_argument("--pmc"); ap.add_argument("--tag", required=True)
+ap.add_argument("--stats"); ap.add_argument("--pmc"); ap.add_argument("--pmc-mem"); ap.add_argument("--tag", required=True)
 ap.add_argument("--bench-json"); ap.add_argument("--out", default="profiles")
 args = ap.parse_args()
 os.makedirs(args.out, exist_ok=True)
@@ -31,14 +31,17 @@ if args.stats:
                 lines.append(f"| `{n[:90]}` | {r['Calls']} | {float(r['AverageNs']):.0f} | {r['MinNs']} | {r['MaxNs']} | {float(r['Percentage']):.2f} |")
         lines.append("")
 traffic = None
+extra = {}
 if args.pmc:
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    for f in glob.glob(os.path.join(args.pmc, "**", "*counter_collection.csv"), recursive=True):
-        for r in csv.DictReader(open(f)):
-            agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    dirs = [args.pmc] + ([args.pmc_mem] if args.pmc_mem else [])
+    for d in dirs:
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     lines += ["## PMC (separate `--pmc` passes with `--kernel-trace` only; mean per dispatch)", ""]
     for k, v in agg.items():
-        if "aog::" not in k and "3aog" not in k:
+        if "k_fused" not in k and "k_prologue" not in k and "k_epilogue" not in k:   # the per-step kernels; set-up kernels are in the stats table
             continue
         lines.append(f"### `{k[:100]}`")
         lines.append("")
@@ -51,6 +54,9 @@ if args.pmc:
             fetch = sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"])
             write = sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"])
             traffic = (2 * fetch + write) * 1024
+            mean = lambda c: sum(v[c]) / len(v[c]) if c in v else None
+            extra = {"valu_insts_per_launch": mean("SQ_INSTS_VALU"), "mfma_insts_per_launch": mean("SQ_INSTS_MFMA"),
+                     "trans_insts_per_launch": mean("SQ_INSTS_VALU_TRANS_F32"), "l1_to_l2_read_requests_per_launch": mean("TCP_TCC_READ_REQ_sum")}
             lines.append(f"HBM traffic per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 = **{traffic / 1e6:.1f} MB** "
                          f"(FETCH_SIZE {fetch:.0f} KiB doubled per the gfx950 correction, WRITE_SIZE {write:.0f} KiB)")
             lines.append("")
@@ -62,5 +68,6 @@ if args.pmc:
                 lines.append("")
 open(os.path.join(args.out, args.tag + ".md"), "w").write("\n".join(lines) + "\n")
 if traffic is not None:
-    json.dump({"hbm_bytes_per_launch": traffic, "source": args.tag}, open(os.path.join(args.out, "traffic_latest.json"), "w"))
+    json.dump({"hbm_bytes_per_launch": traffic, "source": args.tag, **{k: x for k, x in extra.items() if x is not None}},
+              open(os.path.join(args.out, "traffic_latest.json"), "w"))
 print("\n".join(lines[:60]))
