@@ -4,9 +4,11 @@
 # Writes raw rocprofv3 output under gpurun_out/<tag>_* and the tracked summaries profiles/<tag>_config2.md (bench line, kernel stats,
 # PMC tables of the fused kernel, HBM traffic) and profiles/<tag>_next_rows.md (kernel stats of bench.py --config 3/4/5, the K4 and
 # Shack-Hartmann loops).  Counters are collected in their own passes with --kernel-trace only.
+# gpurun only brings gpurun_out/ back: run the collection on the box, then `bash tools/collect_profiles.sh r02 summarize` here.
 TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
+if [ "$2" != "summarize" ]; then
 cd /tmp && export TMPDIR=/tmp
 # 1. the bench line itself (un-profiled), then the same command under rocprofv3 --stats
 python3 $R/bench.py > $OUT/${TAG}_bench_c2.json 2> $OUT/${TAG}_bench_c2.err
@@ -23,8 +25,9 @@ done
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_k4 -- python3 $R/tools/k4_loop.py > $OUT/${TAG}_prof_k4.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_sh -- python3 $R/tools/sh_loop2.py 1024 256 64 single > $OUT/${TAG}_prof_sh.log 2>&1
 python3 $R/tools/single_env_latency.py > $OUT/${TAG}_single.log 2>&1
+fi
 cd $R
-# 4. summaries
+# 4. summaries (from the raw files under gpurun_out/)
 python3 tools/summarize_prof.py --stats gpurun_out/${TAG}_prof_c2 --pmc gpurun_out/${TAG}_pmc --pmc-mem gpurun_out/${TAG}_pmc_mem --tag ${TAG}_config2 \
         --bench-json gpurun_out/${TAG}_bench_c2.json > /dev/null
 {
