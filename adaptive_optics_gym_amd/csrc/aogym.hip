@@ -1304,7 +1304,8 @@ int aog_step(aog_env* e, const float* action, float* obs_raw, uint16_t* obs, flo
   }
   // each fused kernel reads one operand layout: write only that one (the float64 device kernel and the VALU kernel read act_rev)
   const bool mfma_fast = e->kernel == AOG_KERNEL_MFMA && e->cfg.precision == AOG_PRECISION_FAST && !e->sh_ready;
-  hipLaunchKernelGGL(aog::k_prologue, dim3(e->B), dim3(64), 0, s, action, e->gram, e->act_dm, mfma_fast ? nullptr : e->act_rev, e->act16, e->A,
+  hipLaunchKernelGGL(aog::k_prologue, dim3((e->B + aog::kProEnvs - 1) / aog::kProEnvs), dim3(64 * aog::kProEnvs), 0, s, action, e->gram, e->act_dm,
+                     mfma_fast ? nullptr : e->act_rev, e->act16, e->B, e->A,
                      e->A_pad, e->Bp, e->cfg.sh_operation, e->cfg.surface_rms_target, 2.0 / e->cfg.wavelength_wfs);
   HIP_TRY(hipGetLastError());
   int rc = launch_fused(e, s);

@@ -132,7 +132,7 @@ __device__ __forceinline__ void store_act16(_Float16* __restrict__ act16, int en
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1  prologue: action -> actuators (AO_env.py:115-120).  One wave per env.
+// K1  prologue: action -> actuators (AO_env.py:115-120).  One wave per env, four per workgroup.
 //   a'_i = action_i / (i + 10);  var = a'^T G a'  (G = centred Gram, float64);  a'' = a' * target / sqrt(var)
 //   act_dm  [B][A] float64 (metres)         — deformable_mirror.actuators
 //   act_rev [A_PAD][Bp] float32             — 2 a''/lambda_wfs (revolutions of wfs phase per unit mode)
@@ -140,35 +140,51 @@ __device__ __forceinline__ void store_act16(_Float16* __restrict__ act16, int en
 // A zero action gives 0/0 = NaN exactly like numpy (documented in DESIGN.md).
 // ------------------------------------------------------------------------------------------------
 #ifdef AOG_MAIN_TU
-__global__ __launch_bounds__(64) void k_prologue(const float* __restrict__ action, const double* __restrict__ gram,
-                                                 double* __restrict__ act_dm, float* __restrict__ act_rev,
-                                                 _Float16* __restrict__ act16, int A, int A_pad, int Bp,
-                                                 int sh_operation, double target, double two_over_lambda) {
-  const int env = blockIdx.x;
-  const int lane = threadIdx.x;
-  __shared__ double ap[256];
-  // A <= 64 (every fast-path config of the reference): this lane's Gram column is requested BEFORE the action is waited for, so the
-  // kernel has one memory round trip in front of its arithmetic instead of two (it is all latency: 4 K multiply-adds per env)
-  double gpre[64];
+constexpr int kProEnvs = 4;   // envs (= waves) per workgroup: they share one copy of the Gram matrix in LDS
+__global__ __launch_bounds__(64 * kProEnvs) void k_prologue(const float* __restrict__ action, const double* __restrict__ gram,
+                                                            double* __restrict__ act_dm, float* __restrict__ act_rev,
+                                                            _Float16* __restrict__ act16, int B, int A, int A_pad, int Bp,
+                                                            int sh_operation, double target, double two_over_lambda) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int env = blockIdx.x * kProEnvs + wave;
+  const bool live = env < B;
+  __shared__ double Gs[64 * 64];           // G[j][i] at j * 64 + i (A <= 64); lane i then reads a conflict-free row per j
+  __shared__ double aps[kProEnvs][256];
+  double* ap = aps[wave];
+  // A <= 64 (every fast-path config of the reference): the Gram matrix crosses L2 -> LDS ONCE per workgroup, every load of it in
+  // flight together with the action loads: one memory round trip in front of the arithmetic (4 K multiply-adds per env).  Round 1
+  // had every env pull its own 32 KB copy through L2 (33 MB per step at B = 1024).
   const bool pre = !sh_operation && A <= 64;
   if (pre) {
-    const double* gcol = gram + min(lane, A - 1);
+    constexpr int PER = 64 * 64 / (64 * kProEnvs);
+    double g[PER];
 #pragma unroll
-    for (int j = 0; j < 64; ++j) gpre[j] = gcol[(size_t)min(j, A - 1) * A];
-  }
-  for (int i = lane; i < A; i += 64) {
-    const double a = (double)action[(size_t)env * A + i];
-    ap[i] = sh_operation ? a : a / (double)(i + 10);
+    for (int u = 0; u < PER; ++u) {
+      const int idx = threadIdx.x + 64 * kProEnvs * u;
+      const int j = idx >> 6, i = idx & 63;
+      g[u] = gram[(size_t)min(j, A - 1) * A + min(i, A - 1)];
+    }
+    for (int i = lane; i < A; i += 64) {
+      const double a = live ? (double)action[(size_t)env * A + i] : 1.0;
+      ap[i] = a / (double)(i + 10);
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) Gs[threadIdx.x + 64 * kProEnvs * u] = g[u];
+  } else {
+    for (int i = lane; i < A; i += 64) {
+      const double a = live ? (double)action[(size_t)env * A + i] : 1.0;
+      ap[i] = sh_operation ? a : a / (double)(i + 10);
+    }
   }
   __syncthreads();
+  if (!live) return;
   double scale = 1.0;
   if (!sh_operation) {
     double part = 0;
     if (pre) {
       if (lane < A) {
         double r = 0;
-#pragma unroll
-        for (int j = 0; j < 64; ++j) r = fma(gpre[j], j < A ? ap[j] : 0.0, r);
+        for (int j = 0; j < A; ++j) r = fma(Gs[j * 64 + lane], ap[j], r);
         part = ap[lane] * r;
       }
     } else {
@@ -921,12 +937,12 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(const float* __restrict__ 
 }
 #endif  // AOG_MAIN_TU
 
-// block = 4 envs x 16 sum slots x 16 chunk groups (1024 threads, grid = ceil(Bp / 4): 256 workgroups at B = 1024, one per CU):
+// block = 16 envs x 16 sum slots x 4 chunk groups (1024 threads, grid = Bp / 16: 64 workgroups at B = 1024):
 // thread (e, q, cq) adds sums s = q, q + 16, ... over chunks cq, cq + 16, ... (independent loads in flight); the chunk groups meet
 // in LDS; then one thread per (env, output) forms |coef . sums|^2, and one thread per env finishes reward / done / power.
 // dynamic LDS: see epilogue_lds_bytes().
-constexpr int kEpiEnvs = 4;
-constexpr int kEpiGroups = 16;
+constexpr int kEpiEnvs = 16;     // 16 envs x 8 B = one 128-byte line of a slab row per (chunk, sum): round 1's 4 envs fetched 32-byte pieces
+constexpr int kEpiGroups = 4;
 constexpr int kEpiOutSlots = 16;   // threads per env in the output phase
 __host__ __device__ inline size_t epilogue_lds_bytes(int NS, int n_obs, int n_fiber, int MRW_used, int MRS_used) {
   return ((size_t)kEpiGroups * NS * kEpiEnvs + (size_t)NS * kEpiEnvs + (size_t)(n_obs + n_fiber + 1) * kEpiEnvs +
