@@ -1614,11 +1614,56 @@ __global__ __launch_bounds__(256 * KS) void k_extrude16_split(ExtrudeArgs p, int
             __builtin_amdgcn_sched_barrier(0);
           }
         };
+        // Fast form when every K slice is a whole number of 64-deep chunks (N a multiple of 64 KS, 3 N stencil samples): no index
+        // clamps, no masks — a column of the product belongs to ONE env, so whatever a lane of an env outside this class feeds
+        // (stale LDS) only reaches columns that are never stored.  The masked form spent ~12 vector instructions per matrix
+        // instruction on clamps and 64-bit masks: as much issue time as the fp64 matrix pipe itself (PMC: 96 us of vector work
+        // against 55 us of matrix work per SIMD and launch).
+        auto run_fast = [&](const double2* __restrict__ W, const double* __restrict__ vec, int kbeg, int kend, f64x4& acc) {
+          double a0[8], b0[8], a1[8], b1[8];
+          f64x4 acc2 = {0.0, 0.0, 0.0, 0.0};   // two accumulation chains: consecutive matrix ops do not wait for each other's result
+          auto load_fast = [&](int k0, double (&av)[8], double (&bv)[8]) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const double2 w = W[(size_t)((k0 >> 3) + u) * 64 + lane];
+              av[2 * u] = w.x;
+              av[2 * u + 1] = w.y;
+              bv[2 * u] = vec[k0 + 8 * u + lk];
+              bv[2 * u + 1] = vec[k0 + 8 * u + lk + 4];
+            }
+          };
+          load_fast(kbeg, a0, b0);
+          for (int k0 = kbeg; k0 < kend; k0 += 64) {
+            load_fast(k0 + 32, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) {
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[u], acc, 0, 0, 0);
+              acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u + 1], b0[u + 1], acc2, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            load_fast(min(k0 + 64, kend - 32), a0, b0);   // (the last pass re-reads its own second half: in range, never used)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) {
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b1[u], acc, 0, 0, 0);
+              acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u + 1], b1[u + 1], acc2, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[q] += acc2[q];
+        };
         {
           const int ka = ((nz + 32 * KS - 1) / (32 * KS)) * 32, kb = ((N + 32 * KS - 1) / (32 * KS)) * 32;
           const int a0 = min(ks * ka, nz), a1 = min(a0 + ka, nz), b0 = min(ks * kb, N), b1 = min(b0 + kb, N);
-          if (a1 > a0) run(WA + (size_t)rbc * nz8 * 64, nz8, zrow, nz, a0, a1, accA);
-          if (b1 > b0) run(WB + (size_t)rbc * n8 * 64, n8, nrow, N, b0, b1, accB);
+          if (nz % (64 * KS) == 0 && N % (64 * KS) == 0) {
+            run_fast(WA + (size_t)rbc * nz8 * 64, zrow, a0, a1, accA);
+            run_fast(WB + (size_t)rbc * n8 * 64, nrow, b0, b1, accB);
+          } else {
+            if (a1 > a0) run(WA + (size_t)rbc * nz8 * 64, nz8, zrow, nz, a0, a1, accA);
+            if (b1 > b0) run(WB + (size_t)rbc * n8 * 64, n8, nrow, N, b0, b1, accB);
+          }
         }
         double part_v[4];
 #pragma unroll

@@ -11,7 +11,7 @@ env.reset()
 for _ in range(30): env.step(a)
 env.device_status()   # (AOG_EXTRUDE_TIMING=1: switches the phase clocks of the extrusion kernel on)
 torch.cuda.synchronize()
-n, t0 = 200, time.perf_counter()
+n, t0 = (200 if len(sys.argv) < 3 else int(sys.argv[2])), time.perf_counter()
 for _ in range(n): env.step(a)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / n
