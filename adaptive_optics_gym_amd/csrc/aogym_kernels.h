@@ -495,14 +495,24 @@ __global__ __launch_bounds__(512, 2) void k_fused_tab(const f16x8* __restrict__ 
     }
   }
   const size_t psi_base = (size_t)etile_c * geo.n_ptiles;
-  // ring-buffer addressing of this lane's env (DYN only)
-  const float* ring_env = nullptr;
-  int dyn_ox = 0, dyn_oy = 0;
+  // Ring-direct loads (DYN only).  A tile is 32 envs x 32 pixels = one 128-byte line per env; load instruction i (of four) covers
+  // envs 8 i .. 8 i + 7 with EIGHT LANES PER LINE: lane l fetches the 16-byte piece l & 7 (register group g = piece >> 1 of half-wave
+  // piece & 1) of env 8 i + (l >> 3), so an instruction touches 8 lines (per-lane loads in the accumulator layout touched 32 and ran
+  // the launch at 100 us against 51).  The pieces reach the accumulator layout (lane = env, 16 pixels) through this wave's private
+  // [32][36] float tile in LDS right before the tile is reduced.
+  const float* ring_env[4] = {nullptr, nullptr, nullptr, nullptr};
+  int dyn_ox[4] = {0, 0, 0, 0}, dyn_oy[4] = {0, 0, 0, 0};
+  float* dyn_x = nullptr;
+  const int dyn_piece = lane & 7;
   if constexpr (DYN) {
-    const int env = min(etile_c * 32 + (lane & 31), dyn.B - 1);
-    ring_env = dyn.ring + (size_t)env * dyn.N * dyn.RS;
-    dyn_ox = dyn.origin[2 * env];
-    dyn_oy = dyn.origin[2 * env + 1];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int env = min(etile_c * 32 + 8 * i + (lane >> 3), dyn.B - 1);
+      ring_env[i] = dyn.ring + (size_t)env * dyn.N * dyn.RS;
+      dyn_ox[i] = dyn.origin[2 * env];
+      dyn_oy[i] = dyn.origin[2 * env + 1];
+    }
+    dyn_x = reinterpret_cast<float*>(lds_b - lane + (size_t)((int)(blockDim.x >> 6) - wave) * NSTEP * 2 * 64) + (size_t)wave * 32 * 36;
   }
   auto load_modes = [&](f16x8 (&mh)[NSTEP], f16x8 (&ml)[NSTEP], int t) {
 #ifdef AOG_DEV
@@ -519,30 +529,31 @@ __global__ __launch_bounds__(512, 2) void k_fused_tab(const f16x8* __restrict__ 
   auto load_psi = [&](auto g0c, auto ngc, f32x16& d, int t) {
     constexpr int G0 = decltype(g0c)::v, NG = decltype(ngc)::v;
     if constexpr (DYN) {
+      static_assert(G0 == 0 && NG == 4, "ring-direct tiles are requested whole");
       const int tt = min(t, last);
-      const uint4 dsc = dyn.desc[tt * 2 + h];
-      const uint32_t dd[4] = {dsc.x, dsc.y, dsc.z, dsc.w};
-      auto fetch = [&](uint32_t code) {   // 4 consecutive x from logical (code >> 18, (code >> 4) & 0x3fff) of this lane's env
-        uint32_t py = (code >> 18) + (uint32_t)dyn_oy, px = ((code >> 4) & 0x3fffu) + (uint32_t)dyn_ox;
-        py = min(py, py - (uint32_t)dyn.N);   // (unsigned: the wrapped candidate is huge unless py >= N)
-        px = min(px, px - (uint32_t)dyn.N);
-        return *reinterpret_cast<const f32x4u*>(ring_env + (size_t)py * dyn.RS + px);
-      };
+      // this lane's piece of the tile: register group g = piece >> 1 of half-wave piece & 1
+      const uint32_t* dsc = reinterpret_cast<const uint32_t*>(dyn.desc) + ((size_t)tt * 2 + (dyn_piece & 1)) * 4 + (dyn_piece >> 1);
+      const uint32_t code = *dsc;
+      const bool straddle = __any((code & 7u) < 4u ? 1 : 0);   // some piece of this tile continues in another aperture row
+      uint32_t ccode = 0;
+      if (straddle) ccode = *(reinterpret_cast<const uint32_t*>(dyn.cont) + (dsc - reinterpret_cast<const uint32_t*>(dyn.desc)));
 #pragma unroll
-      for (int g = G0; g < G0 + NG; ++g) {
-        f32x4 v = fetch(dd[g]);
-        if (dd[g] & 8u) {   // wave-uniform: a group of this (tile, g) continues in another row
-          const uint4 cnt = dyn.cont[tt * 2 + h];
-          const uint32_t cc[4] = {cnt.x, cnt.y, cnt.z, cnt.w};
-          const int k = (int)(dd[g] & 7u);
-          if (k < 4) {
-            const f32x4 w = fetch(cc[g]);
-            v[1] = k <= 1 ? w[1] : v[1];
-            v[2] = k <= 2 ? w[2] : v[2];
-            v[3] = w[3];
-          }
+      for (int i = 0; i < 4; ++i) {
+        auto fetch = [&](uint32_t cd) {   // 4 consecutive x from logical (cd >> 18, (cd >> 4) & 0x3fff) of env 8 i + (lane >> 3)
+          uint32_t py = (cd >> 18) + (uint32_t)dyn_oy[i], px = ((cd >> 4) & 0x3fffu) + (uint32_t)dyn_ox[i];
+          py = min(py, py - (uint32_t)dyn.N);   // (unsigned: the wrapped candidate is huge unless py >= N)
+          px = min(px, px - (uint32_t)dyn.N);
+          return *reinterpret_cast<const f32x4u*>(ring_env[i] + (size_t)py * dyn.RS + px);
+        };
+        f32x4 v = fetch(code);
+        if (straddle) {
+          const int k = (int)(code & 7u);
+          const f32x4 w = fetch(k < 4 ? ccode : code);
+          v[1] = k <= 1 ? w[1] : v[1];
+          v[2] = k <= 2 ? w[2] : v[2];
+          v[3] = k <= 3 ? w[3] : v[3];
         }
-        d[4 * g + 0] = v[0]; d[4 * g + 1] = v[1]; d[4 * g + 2] = v[2]; d[4 * g + 3] = v[3];
+        d[4 * i + 0] = v[0]; d[4 * i + 1] = v[1]; d[4 * i + 2] = v[2]; d[4 * i + 3] = v[3];
       }
     } else {
       const f32x4* ps = psi_tile + ((psi_base + min(t, last)) * 4) * 64 + lane;
@@ -551,6 +562,25 @@ __global__ __launch_bounds__(512, 2) void k_fused_tab(const f16x8* __restrict__ 
         const f32x4 v = ps[g * 64];
         d[4 * g + 0] = v[0]; d[4 * g + 1] = v[1]; d[4 * g + 2] = v[2]; d[4 * g + 3] = v[3];
       }
+    }
+  };
+  // ring-direct: pieces (lane = env-of-eight x piece, register group = load instruction) -> accumulator layout (lane = env, 16 pixels)
+  auto dyn_transpose = [&](f32x16& d) {
+    if constexpr (DYN) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f32x4 v = {d[4 * i], d[4 * i + 1], d[4 * i + 2], d[4 * i + 3]};
+        *reinterpret_cast<f32x4*>(dyn_x + (size_t)(8 * i + (lane >> 3)) * 36 + 4 * dyn_piece) = v;
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the tile is private to this wave
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(dyn_x + (size_t)(lane & 31) * 36 + 8 * g + 4 * h);
+        d[4 * g] = v[0]; d[4 * g + 1] = v[1]; d[4 * g + 2] = v[2]; d[4 * g + 3] = v[3];
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
     }
   };
   // Table rows m >= MRW are zero: the lanes that would fetch them all read ONE zero entry (row 31 of the first half) instead, so a
@@ -685,6 +715,7 @@ __global__ __launch_bounds__(512, 2) void k_fused_tab(const f16x8* __restrict__ 
     auto stage = [&](auto prevc, auto nextc, int i, int t, f32x16& D, f32x16& Dn, f32x16& P) {
       constexpr bool PREV = decltype(prevc)::v != 0, NEXT = decltype(nextc)::v != 0;
       constexpr int NQ0 = (NEXT ? NM : 0) + (PREV ? 6 : 0);   // matrix ops dealt over the 8 pixels of step 0
+      dyn_transpose(P);
       const f32x4* gs = lds_sci + (size_t)(t - t0) * 8 + h * 4;
       {
         const f32x4 g0 = gs[0], g1 = gs[1];
@@ -725,6 +756,9 @@ __global__ __launch_bounds__(512, 2) void k_fused_tab(const f16x8* __restrict__ 
         ta[0] = ts[0];
         ta[1] = ts[64];
         // ring-direct: the four 16-byte pieces a lane takes from its env's 128-byte line go out together, while the line is in the L1
+        // (ring-direct: the lines come from HBM — the 0.8 GB of master screens and ring copy the extrusion rewrites every step do not
+        // stay in the Infinity Cache — and the waves wait on memory for half their cycles; touching the lines of tile t + 4 with a
+        // throw-away dword load made it worse, 175 against 96 us: the touches retire in order in front of the real loads)
         if constexpr (DYN) load_psi(IC<0>{}, IC<4>{}, P, t + 2 * stride);
         else load_psi(IC<2>{}, IC<2>{}, P, t + 2 * stride);
       }

@@ -51,7 +51,8 @@ void launch_tab(aog_env* e, hipStream_t s) {
   const int wgs_per_xcd = g.pair ? round_up(chunks_per_xcd, 64 / g.wg_y) * g.wg_y : chunks_per_xcd * g.wg_y;
   dim3 grid(8 * wgs_per_xcd);
   const float ratio = (float)(e->cfg.wavelength_wfs / e->cfg.wavelength_sci);
-  const size_t lds_t = (size_t)e->mfma_tpc * 8 * 16 + ((A_PAD > 64 || e->ring_direct) ? (size_t)e->mfma_waves * (A_PAD / 16) * 2 * 64 * 16 : 0);   // science rows (+ actuator operands)
+  const size_t lds_t = (size_t)e->mfma_tpc * 8 * 16 + ((A_PAD > 64 || e->ring_direct) ? (size_t)e->mfma_waves * (A_PAD / 16) * 2 * 64 * 16 : 0) +   // science rows (+ actuator operands)
+                       (e->ring_direct ? (size_t)e->mfma_waves * 32 * 36 * 4 : 0);                                             // (+ ring-direct transpose tiles)
   aog::DynPsi dyn{};
   if (e->ring_direct) {   // dynamic atmosphere: the screens come straight from the fp32 ring copy of the master screens
     dyn.ring = e->psi_ring;

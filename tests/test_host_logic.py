@@ -190,3 +190,23 @@ def test_shack_hartmann_host_tables_match_oracle():
     np.testing.assert_allclose(sh.reconstruction, ref.reconstruction_matrix, rtol=1e-5,
                                atol=1e-5 * np.abs(ref.reconstruction_matrix).max())
     np.testing.assert_allclose(sh.amp_wfs ** 2 * sh.n_ap * sh.pix_area_pupil, ref.wf_wfs.total_power, rtol=1e-12)
+
+
+def test_gym_registration_through_the_gymnasium_stand_in(repo_root):
+    """``import gym_AO`` registers 'AO-v0' with the entry point of the drop-in (gym_AO/__init__.py:9-12 in the reference) when a
+    ``gymnasium`` is importable — here the test stand-in, in a child process so that this process's modules are untouched — and the
+    spaces become that package's Box (algorithm.py:32-35 asserts the type).  The env itself needs a GPU: tests/test_gpu_gym_make.py."""
+    import subprocess
+    import sys
+
+    code = ("import sys; sys.path[:0] = [%r, %r]\n"
+            "import gymnasium as gym, gym_AO\n"
+            "from adaptive_optics_gym_amd import spaces\n"
+            "spec = gym.envs.registration.registry['AO-v0']\n"
+            "assert gym_AO.registered and spec.entry_point == 'adaptive_optics_gym_amd.envs:AOEnv'\n"
+            "assert type(spaces.make_box(-1, 1, (4,), 'float16')) == gym.spaces.Box\n"
+            "from adaptive_optics_gym_amd.envs import AOEnv\n"
+            "assert issubclass(AOEnv, gym.Env)\n"
+            "print('ok')\n") % (repo_root, os.path.join(repo_root, "tests", "fake_gymnasium"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
