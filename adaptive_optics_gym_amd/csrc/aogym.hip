@@ -233,7 +233,7 @@ size_t ext16_lds(const aog_env* e) {
 
 size_t ext_split_lds(const aog_env* e) {
   return ((size_t)aog::kExt16G * (aog::ext_split_stride(std::max(e->nz_v, e->nz_h)) + aog::ext_split_stride(e->cfg.n_pupil)) +
-          (size_t)(aog::kExtKsMax - 1) * 4 * 256) * sizeof(double) + (size_t)(e->nz_v + e->nz_h) * sizeof(int32_t);
+          (size_t)(aog::kExtKs - 1) * 4 * 256) * sizeof(double) + (size_t)(e->nz_v + e->nz_h) * sizeof(int32_t);
 }
 
 int evolve_layer(aog_env* e, hipStream_t s) {
@@ -272,13 +272,12 @@ int evolve_layer(aog_env* e, hipStream_t s) {
   if (e->ext_bar && !getenv("AOG_EXTRUDE_SIMPLE") && !getenv("AOG_EXTRUDE_NOSPLIT") && ext_split_lds(e) <= kLdsBytes) {
     // float64 matrix-core form with each 16-env group's rows split over four workgroups + group barrier
     const size_t lds = ext_split_lds(e);
-    static const int ks = getenv("AOG_EXTRUDE_KS") ? atoi(getenv("AOG_EXTRUDE_KS")) : 2;
-    auto kern = ks == 4 ? aog::k_extrude16_split<4> : ks == 1 ? aog::k_extrude16_split<1> : aog::k_extrude16_split<2>;
+    auto kern = aog::k_extrude16_split<aog::kExtKs>;
     if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, e->device)) return rc;
     HIP_TRY(hipMemsetAsync(e->ext_bar, 0, sizeof(unsigned) * round_up(e->n_ext_groups, 4), s));
     p.origin = e->origin;
     const int groups8 = round_up(e->n_ext_groups, 8);
-    hipLaunchKernelGGL(kern, dim3(groups8 * aog::kExtParts), dim3(256 * (ks == 4 ? 4 : ks == 1 ? 1 : 2)), lds, s, p, e->B, e->ext_perm, e->ext_bar, e->dev_status,
+    hipLaunchKernelGGL(kern, dim3(groups8 * aog::kExtParts), dim3(256 * aog::kExtKs), lds, s, p, e->B, e->ext_perm, e->ext_bar, e->dev_status,
                        e->host_flag_dev);
     HIP_TRY(hipGetLastError());
   } else if (!getenv("AOG_EXTRUDE_SIMPLE") && ext16_lds(e) <= kLdsBytes) {
@@ -1116,6 +1115,7 @@ int aog_sh_update(aog_env* e, const double* noisy_image_dev, double* action_dev,
   return AOG_OK;
 }
 
+extern "C++" {
 namespace {
 struct StatePart {
   void* ptr;
@@ -1147,6 +1147,7 @@ std::vector<StatePart> state_parts(const aog_env* e) {
   return v;
 }
 }  // namespace
+}  // extern "C++"
 
 namespace {
 struct StateTail {  // host-side counters that steer the device RNG streams; stored in the last 256 bytes of the blob
@@ -1241,7 +1242,7 @@ int aog_device_status(aog_env* e, int32_t* status_out) {
   HIP_TRY(hipMemcpy(v, e->dev_status, sizeof v, hipMemcpyDeviceToHost));
   *status_out = v[0] | *static_cast<volatile int*>(e->host_flag);
   if (getenv("AOG_EXTRUDE_TIMING")) {   // developer aid: phase clocks (10 ns ticks) of workgroup 0 of k_extrude16_split
-    if (v[1]) fprintf(stderr, "[aogym] extrude16_split WG0 ticks: gather %d noise %d compute %d (matrix passes %d, exchange %d) barrier %d rounds %d\n", v[4], v[5], v[6], v[9], v[10], v[7], v[8]);
+    if (v[1]) fprintf(stderr, "[aogym] extrude16_split WG0 ticks: gather %d noise %d compute %d (matrix passes %d, exchange %d) barrier %d rounds %d matrix passes run %d, shader clocks in them / 16: %d\n", v[4], v[5], v[6], v[9], v[10], v[7], v[8], v[11], v[12]);
     const int one = 1;
     HIP_TRY(hipMemcpy(e->dev_status + 1, &one, sizeof one, hipMemcpyHostToDevice));
   }

@@ -1489,7 +1489,7 @@ __global__ __launch_bounds__(512) void k_extrude16(ExtrudeArgs p, int B) {
 // library polls without synchronising) and the kernel still terminates; aog_step / aog_reset then fail with AOG_ERR_STATE.
 constexpr int kExtParts = 4;
 __host__ __device__ inline int ext_split_stride(int n) { return ((n + 27) / 32) * 32 + 4; }   // smallest s >= n, s = 4 mod 32
-constexpr int kExtKsMax = 4;   // slices of the contraction per row block (template parameter KS: 4 KS waves per workgroup)
+constexpr int kExtKs = 2;   // slices of the contraction per row block (template parameter KS: 4 KS waves per workgroup; 1 and 4 measured slower)
 #ifdef AOG_MAIN_TU
 template <int KS>
 __global__ __launch_bounds__(256 * KS) void k_extrude16_split(ExtrudeArgs p, int B, const int* __restrict__ perm, unsigned* __restrict__ bar, int* __restrict__ status,
@@ -1533,66 +1533,73 @@ __global__ __launch_bounds__(256 * KS) void k_extrude16_split(ExtrudeArgs p, int
   __syncthreads();
   int rounds = 0;
   for (int g = 0; g < G; ++g) rounds = max(rounds, abs(s_dx[g]) + abs(s_dy[g]));
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   const int rbl = wave & 3, ks = wave >> 2;   // 4 KS waves: 4 row blocks x KS slices of the contraction
   const int li = lane & 15, lk = lane >> 4;
   const bool dbg = status[1] != 0 && blockIdx.x == 0 && threadIdx.x == 0;
   long long tm[6] = {0, 0, 0, 0, 0, 0};
+  int n_pass = 0;
+  long long cyc = 0;
   for (int r = 0; r < rounds; ++r) {
     long long t0 = dbg ? wall_clock64() : 0;
     auto cls = [&](int g) { return r < abs(s_dx[g]) ? 1 : (r < abs(s_dx[g]) + abs(s_dy[g]) ? 2 : 0); };
-    // every load of a batch is issued before any is consumed: the samples come from HBM (the master screens do not fit the caches), and
-    // with 4 conditional loads per thread in flight the gather was six dependent round trips per round (14 us); 12 unconditional
-    // ones make it two (9 us; what is left is HBM sector traffic: 8 bytes used of every 64 fetched.  A transposed copy of the
-    // master screens for the column stencils was tried: its scattered writes cost more than the contiguous reads saved)
+    // One env per wave (wave w takes envs w, w + #waves, ...): class, shift sign, origin and screen base are wave-uniform (scalar
+    // registers), a sample costs ~15 vector instructions instead of ~80 (index division, per-sample class lookup): the gather was bound
+    // by vector issue as much as by memory (PMC: 22 vector instructions per matrix instruction over the launch).  Every load of a
+    // batch is issued before any is consumed: the samples come from HBM / L2 (the master screens do not fit the caches), one memory
+    // round trip per batch of 12.  (What is left is sector traffic: 8 bytes used of every 64 fetched.  A transposed copy of the master
+    // screens for the column stencils was tried: its scattered writes cost more than the contiguous reads saved.)
     constexpr int GD = 12;
-    for (int base = threadIdx.x; base < G * nzmax; base += GD * blockDim.x) {
-      double v[GD];
-      int dst[GD];
+    const int n_waves = (int)(blockDim.x >> 6);
+    for (int g = wave; g < G; g += n_waves) {
+      const int c = __builtin_amdgcn_readfirstlane(cls(g));
+      if (!c) continue;   // (rows of envs outside both classes keep stale samples: their product columns are never stored)
+      const bool horizontal = c == 1;
+      const int nz = horizontal ? p.nz_h : p.nz_v;
+      const int32_t* st = horizontal ? st_h : st_v;
+      const bool flipped = __builtin_amdgcn_readfirstlane(horizontal ? s_dx[g] : s_dy[g]) > 0;
+      const int oy = __builtin_amdgcn_readfirstlane(s_oy[g]), ox = __builtin_amdgcn_readfirstlane(s_ox[g]);
+      const double* __restrict__ src = p.master + (size_t)__builtin_amdgcn_readfirstlane(s_env[g]) * N * N;
+      double* zrow_g = zb + (size_t)g * zs;
+      for (int k0 = 0; k0 < nz; k0 += 64 * GD) {
+        double v[GD];
 #pragma unroll
-      for (int u = 0; u < GD; ++u) {
-        // branch-free: every thread issues a load from a valid address (a branch around the load makes the compiler wait for it
-        // before the next one goes out); the stencil codes come from LDS, so the chain per sample is ONE memory round trip
-        const int raw = base + u * blockDim.x;
-        const int idx = min(raw, G * nzmax - 1);
-        const int g = idx / nzmax, k = idx - g * nzmax;
-        const int c = cls(g);
-        const bool horizontal = c == 1;
-        const int nz = horizontal ? p.nz_h : p.nz_v;
-        const uint32_t pk = (uint32_t)(horizontal ? st_h : st_v)[min(k, nz - 1)];
-        int sy = (int)(pk >> 16), sx = (int)(pk & 0xFFFFu);
-        const bool flipped = horizontal ? s_dx[g] > 0 : s_dy[g] > 0;
-        sy = flipped ? N - 1 - sy : sy;
-        sx = flipped ? N - 1 - sx : sx;
-        int py = sy + s_oy[g], px = sx + s_ox[g];
-        py -= py >= N ? N : 0;
-        px -= px >= N ? N : 0;
-        v[u] = p.master[(size_t)s_env[g] * N * N + (size_t)py * N + px];
-        dst[u] = (raw < G * nzmax && c != 0 && k < nz) ? g * zs + k : -1;
+        for (int u = 0; u < GD; ++u) {
+          const int k = min(k0 + 64 * u + lane, nz - 1);   // branch-free: every lane loads from a valid address
+          const uint32_t pk = (uint32_t)st[k];
+          int sy = (int)(pk >> 16), sx = (int)(pk & 0xFFFFu);
+          sy = flipped ? N - 1 - sy : sy;
+          sx = flipped ? N - 1 - sx : sx;
+          int py = sy + oy, px = sx + ox;
+          py -= py >= N ? N : 0;
+          px -= px >= N ? N : 0;
+          v[u] = src[py * N + px];
+        }
+#pragma unroll
+        for (int u = 0; u < GD; ++u) {
+          const int k = k0 + 64 * u + lane;
+          if (k < nz) zrow_g[k] = v[u];
+        }
       }
-#pragma unroll
-      for (int u = 0; u < GD; ++u)
-        if (dst[u] >= 0) zb[dst[u]] = v[u];
     }
-    __syncthreads();
-    if (dbg) { long long t = wall_clock64(); tm[0] += t - t0; t0 = t; }
-    if (p.noise && r < p.max_ext) {
-      for (int idx = threadIdx.x; idx < G * N; idx += blockDim.x) {
-        const int g = idx / N, j = idx - g * N;
-        if (!cls(g)) continue;
-        nb[(size_t)g * ns + j] = p.noise[((size_t)s_env[g] * p.max_ext + r) * N + j];
-      }
-    } else {
-      const int n4 = (N + 3) >> 2;   // four normals per Philox call
-      for (int idx = threadIdx.x; idx < G * n4; idx += blockDim.x) {
-        const int g = idx / n4, j4 = idx - g * n4;
-        if (!cls(g)) continue;
-        const int env = s_env[g];
-        double v[4];
-        philox_normal4(p.seed, (uint32_t)(p.env_base + env), p.ext_counter[env] + (uint32_t)r, (uint32_t)j4, v);
+    if (dbg) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); long long t = wall_clock64(); tm[0] += t - t0; t0 = t; }
+    // normals of the same envs (no barrier in between: a wave fills the rows of its own envs)
+    for (int g = wave; g < G; g += n_waves) {
+      if (!__builtin_amdgcn_readfirstlane(cls(g))) continue;
+      const int env = __builtin_amdgcn_readfirstlane(s_env[g]);
+      double* nrow_g = nb + (size_t)g * ns;
+      if (p.noise && r < p.max_ext) {
+        const double* __restrict__ src = p.noise + ((size_t)env * p.max_ext + r) * N;
+        for (int j = lane; j < N; j += 64) nrow_g[j] = src[j];
+      } else {
+        const uint32_t ctr = p.ext_counter[env] + (uint32_t)r;
+        for (int j4 = lane; 4 * j4 < N; j4 += 64) {   // four normals per Philox call
+          double v[4];
+          philox_normal4(p.seed, (uint32_t)(p.env_base + env), ctr, (uint32_t)j4, v);
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (4 * j4 + u < N) nb[(size_t)g * ns + 4 * j4 + u] = v[u];
+          for (int u = 0; u < 4; ++u)
+            if (4 * j4 + u < N) nrow_g[4 * j4 + u] = v[u];
+        }
       }
     }
     __syncthreads();
@@ -1602,6 +1609,8 @@ __global__ __launch_bounds__(256 * KS) void k_extrude16_split(ExtrudeArgs p, int
       bool any = false;
       for (int g = 0; g < G; ++g) any |= cls(g) == c;
       if (!any) continue;
+      if (dbg) ++n_pass;
+      const long long c0 = dbg ? clock64() : 0;
       const bool horizontal = c == 1;
       const int nz = horizontal ? p.nz_h : p.nz_v;
       const double2* WA = reinterpret_cast<const double2*>(horizontal ? p.Wa_h : p.Wa_v);
@@ -1648,52 +1657,76 @@ __global__ __launch_bounds__(256 * KS) void k_extrude16_split(ExtrudeArgs p, int
             __builtin_amdgcn_sched_barrier(0);
           }
         };
-        // Fast form when every K slice is a whole number of 64-deep chunks (N a multiple of 64 KS, 3 N stencil samples): no index
+        // Fast form when every K slice is a whole number of 32-deep blocks (N a multiple of 64 KS, 3 N stencil samples): no index
         // clamps, no masks — a column of the product belongs to ONE env, so whatever a lane of an env outside this class feeds
         // (stale LDS) only reaches columns that are never stored.  The masked form spent ~12 vector instructions per matrix
-        // instruction on clamps and 64-bit masks: as much issue time as the fp64 matrix pipe itself (PMC: 96 us of vector work
-        // against 55 us of matrix work per SIMD and launch).
-        auto run_fast = [&](const double2* __restrict__ W, const double* __restrict__ vec, int kbeg, int kend, f64x4& acc) {
-          double a0[8], b0[8], a1[8], b1[8];
-          f64x4 acc2 = {0.0, 0.0, 0.0, 0.0};   // two accumulation chains: consecutive matrix ops do not wait for each other's result
-          auto load_fast = [&](int k0, double (&av)[8], double (&bv)[8]) {
+        // instruction on clamps and 64-bit masks: as much issue time as the fp64 matrix pipe itself.  The stencil and the noise
+        // passes run as ONE stream of blocks with three blocks of weights and one block of LDS operands in flight; two accumulation chains per pass.
+        auto run_fast = [&](const double2* __restrict__ Wa, const double* __restrict__ va, int na, const double2* __restrict__ Wb,
+                            const double* __restrict__ vb, int nb_blk, f64x4& accA_, f64x4& accB_) {
+          f64x4 accA2 = {0.0, 0.0, 0.0, 0.0}, accB2 = {0.0, 0.0, 0.0, 0.0};
+          const int nblk = na + nb_blk;   // blocks of 32 k-values: 4 16-byte weight loads per lane, 8 LDS reads, 8 matrix ops
+          double2 w0[4], w1[4], w2[4], w3[4];
+          double b0[8], b1[8];
+          auto loadw = [&](int jb, double2 (&w)[4]) {
+            jb = min(jb, nblk - 1);   // past the end: re-reads the last block (in range, never used).  NOT a branch around the loads: the
+                                      // compiler then loses count of the loads in flight and waits for all of them before every matrix op
+            const double2* __restrict__ src = jb < na ? Wa + (size_t)jb * 4 * 64 : Wb + (size_t)(jb - na) * 4 * 64;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const double2 w = W[(size_t)((k0 >> 3) + u) * 64 + lane];
-              av[2 * u] = w.x;
-              av[2 * u + 1] = w.y;
-              bv[2 * u] = vec[k0 + 8 * u + lk];
-              bv[2 * u + 1] = vec[k0 + 8 * u + lk + 4];
+            for (int u = 0; u < 4; ++u) w[u] = src[(size_t)u * 64 + lane];
+          };
+          // the B operands of a block (LDS) are requested one block ahead as well: read -> wait -> two matrix ops -> read ... was what
+          // the compiler made of reads placed next to their use: an LDS round trip in front of every pair of matrix ops, 260 cycles per
+          // matrix op and wave against the 64 it occupies the pipe (measured: weights served from L1 changed nothing)
+          auto loadb = [&](int jb, double (&bv)[8]) {
+            jb = min(jb, nblk - 1);
+            const double* v = (jb < na ? va + 32 * jb : vb + 32 * (jb - na)) + lk;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) bv[u] = v[4 * u];
+          };
+          auto mma = [&](int jb, const double2 (&w)[4], const double (&bv)[8]) {
+            if (jb >= nblk) return;
+            if (jb < na) {
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                accA_ = __builtin_amdgcn_mfma_f64_16x16x4f64(w[u].x, bv[2 * u], accA_, 0, 0, 0);
+                accA2 = __builtin_amdgcn_mfma_f64_16x16x4f64(w[u].y, bv[2 * u + 1], accA2, 0, 0, 0);
+              }
+            } else {
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                accB_ = __builtin_amdgcn_mfma_f64_16x16x4f64(w[u].x, bv[2 * u], accB_, 0, 0, 0);
+                accB2 = __builtin_amdgcn_mfma_f64_16x16x4f64(w[u].y, bv[2 * u + 1], accB2, 0, 0, 0);
+              }
             }
           };
-          load_fast(kbeg, a0, b0);
-          for (int k0 = kbeg; k0 < kend; k0 += 64) {
-            load_fast(k0 + 32, a1, b1);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < 8; u += 2) {
-              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[u], acc, 0, 0, 0);
-              acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u + 1], b0[u + 1], acc2, 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            load_fast(min(k0 + 64, kend - 32), a0, b0);   // (the last pass re-reads its own second half: in range, never used)
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < 8; u += 2) {
-              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b1[u], acc, 0, 0, 0);
-              acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u + 1], b1[u + 1], acc2, 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
+          // the scheduling fences keep the loads AHEAD of the matrix ops (left alone the compiler sinks every load to just before its use)
+#define AOG_EXT_STEP(J, WLOAD, BLOAD, WCUR, BCUR)   \
+  loadw((J) + 3, WLOAD);                            \
+  loadb((J) + 1, BLOAD);                            \
+  __builtin_amdgcn_sched_barrier(0);                \
+  mma((J), WCUR, BCUR);                             \
+  __builtin_amdgcn_sched_barrier(0);
+          loadw(0, w0);
+          loadw(1, w1);
+          loadw(2, w2);
+          loadb(0, b0);
+          for (int jb = 0; jb < nblk; jb += 4) {
+            AOG_EXT_STEP(jb, w3, b1, w0, b0)
+            AOG_EXT_STEP(jb + 1, w0, b0, w1, b1)
+            AOG_EXT_STEP(jb + 2, w1, b1, w2, b0)
+            AOG_EXT_STEP(jb + 3, w2, b0, w3, b1)
           }
+#undef AOG_EXT_STEP
 #pragma unroll
-          for (int q = 0; q < 4; ++q) acc[q] += acc2[q];
+          for (int q = 0; q < 4; ++q) { accA_[q] += accA2[q]; accB_[q] += accB2[q]; }
         };
         {
           const int ka = ((nz + 32 * KS - 1) / (32 * KS)) * 32, kb = ((N + 32 * KS - 1) / (32 * KS)) * 32;
           const int a0 = min(ks * ka, nz), a1 = min(a0 + ka, nz), b0 = min(ks * kb, N), b1 = min(b0 + kb, N);
           if (nz % (64 * KS) == 0 && N % (64 * KS) == 0) {
-            run_fast(WA + (size_t)rbc * nz8 * 64, zrow, a0, a1, accA);
-            run_fast(WB + (size_t)rbc * n8 * 64, nrow, b0, b1, accB);
+            run_fast(WA + ((size_t)rbc * nz8 + (a0 >> 3)) * 64, zrow + a0, (a1 - a0) >> 5, WB + ((size_t)rbc * n8 + (b0 >> 3)) * 64, nrow + b0,
+                     (b1 - b0) >> 5, accA, accB);
           } else {
             if (a1 > a0) run(WA + (size_t)rbc * nz8 * 64, nz8, zrow, nz, a0, a1, accA);
             if (b1 > b0) run(WB + (size_t)rbc * n8 * 64, n8, nrow, N, b0, b1, accB);
@@ -1703,7 +1736,7 @@ __global__ __launch_bounds__(256 * KS) void k_extrude16_split(ExtrudeArgs p, int
 #pragma unroll
         for (int q = 0; q < 4; ++q) part_v[q] = accA[q] + accB[q] * p.sqrt_cn2;
         long long t1 = 0;
-        if (dbg) { t1 = wall_clock64(); tm[4] += t1 - t0; }
+        if (dbg) { t1 = wall_clock64(); tm[4] += t1 - t0; cyc += clock64() - c0; }
         if (ks > 0) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) pb[((size_t)(ks - 1) * 4 + rbl) * 256 + q * 64 + lane] = part_v[q];
@@ -1774,6 +1807,8 @@ __global__ __launch_bounds__(256 * KS) void k_extrude16_split(ExtrudeArgs p, int
     status[9] += (int)tm[4];
     status[10] += (int)tm[5];
     status[8] += rounds;
+    status[11] += n_pass;
+    status[12] += (int)(cyc >> 4);
   }
   if (part == 0 && threadIdx.x < G && perm[env0 + threadIdx.x] >= 0) {
     const int g = threadIdx.x, env = s_env[g];

@@ -278,6 +278,8 @@ def main():
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", str(rank))             # (AOG_FORCE_DIST=1 without a launcher: a one-rank group)
+        os.environ.setdefault("WORLD_SIZE", str(world))
         if share:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
