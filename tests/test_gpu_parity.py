@@ -815,15 +815,16 @@ def test_pruned_screen_synthesis_matches_full_transform(monkeypatch, N, q):
     assert np.abs(p2 - f2).max() < 3e-5 * rms
 
 
-def test_shack_hartmann_chain_matches_oracle():
-    """SH_step (AO_env.py:254-290) on the device vs the oracle, stage by stage: the noise-free sensor image; then the
+@pytest.mark.parametrize("N", [96, 240])
+def test_shack_hartmann_chain_matches_oracle(N):
+    """SH_step (AO_env.py:254-290) on the device vs the oracle (N = 240 is the reference's pupil size), stage by stage: the noise-free sensor image; then the
     estimator + reconstructor + leaky integrator fed with the ORACLE's photon-noisy image (a Poisson stream cannot be replayed
     on images that differ in the last bits); then the env step that consumes the actuators."""
     torch = _torch()
     from adaptive_optics_gym_amd import BatchedAOEnv
     from oracle.ao_env_oracle import AOEnvOracle
 
-    N, A = 96, 8
+    A = 8
     scr = smooth_screens(1, N, 3)[0] * 0.5
     kw = dict(act_type="zernike", act_dim=A, obs_dim=2, timesteps_per_episode=50, num_pupil_pixels=N, SH_operation=True, verbose=False)
     env = BatchedAOEnv(1, "cuda:0", screens=scr[None], sh_fft_precision="double", **kw)      # complex128 transforms: image parity to 1e-5
