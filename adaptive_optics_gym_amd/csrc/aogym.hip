@@ -1003,7 +1003,33 @@ int aog_upload_sh(aog_env* e, const aog_sh_tables* t) {
   if ((rc = dev_alloc(e, &e->sh_act16, (size_t)e->n_etiles * e->A_pad * 32 * 2)) != AOG_OK) return rc;
   if ((rc = dev_alloc(e, &e->sh_phase, (size_t)e->n_etiles * e->n_ptiles * 1024)) != AOG_OK) return rc;
   e->sh_double = t->fft_double != 0;
-  {
+  e->sh_pruned = (!e->sh_double && (N == 128 || N == 256 || N == 512)) ? 2 * N / 64 : 0;
+  if (e->sh_pruned) {
+    // pruned three-pass propagation (k_sh_rows_fwd / k_sh_cols / k_sh_rows_inv): F1T [B][2N][N] in sh_pad; compact field [B][N][N] and
+    // GT [B][2N][N] in sh_in (zeroed once: pixels outside the aperture are never written)
+    const int L = 2 * N, RL = e->sh_pruned, BC = 64 / RL;
+    char* p1 = nullptr;
+    char* p2 = nullptr;
+    if ((rc = dev_alloc(e, &p1, (size_t)e->B * N2 * 2 * sizeof(float) * 2, false)) != AOG_OK) return rc;
+    if ((rc = dev_alloc(e, &p2, (size_t)e->B * N2 * 3 * sizeof(float) * 2, true)) != AOG_OK) return rc;
+    e->sh_pad = p1;
+    e->sh_in = p2;
+    std::vector<float> tw((size_t)L * 2), tfq((size_t)L * L * 2);
+    for (int j = 0; j < L; ++j) {
+      tw[2 * j] = (float)cos(2.0 * M_PI * j / L);
+      tw[2 * j + 1] = (float)sin(2.0 * M_PI * j / L);
+    }
+    for (int cg = 0; cg < L / BC; ++cg)
+      for (int k2 = 0; k2 < 64; ++k2)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int pp = lane / BC, bb = lane % BC;
+          const size_t src = ((size_t)(pp + RL * k2) * L + (size_t)cg * BC + bb) * 2, dst = (((size_t)cg * 64 + k2) * 64 + lane) * 2;
+          tfq[dst] = (float)t->transfer[src];
+          tfq[dst + 1] = (float)t->transfer[src + 1];
+        }
+    if ((rc = up(&e->sh_tw, tw.data(), tw.size())) != AOG_OK) return rc;
+    if ((rc = up(&e->sh_tfq, tfq.data(), tfq.size())) != AOG_OK) return rc;
+  } else {
     const size_t cbytes = e->sh_double ? sizeof(double) * 2 : sizeof(float) * 2;
     char* p1 = nullptr;
     char* p2 = nullptr;
@@ -1014,18 +1040,20 @@ int aog_upload_sh(aog_env* e, const aog_sh_tables* t) {
     e->sh_pad = p1;
     e->sh_in = p2;
   }
-  if (!e->sh_double) {
+  if (!e->sh_double && !e->sh_pruned) {
     std::vector<float> tf32(N2 * 4 * 2);
     for (size_t i = 0; i < tf32.size(); ++i) tf32[i] = (float)t->transfer[i];
     if ((rc = up(&e->sh_tf32, tf32.data(), tf32.size())) != AOG_OK) return rc;
   }
   if ((rc = dev_alloc(e, &e->sh_image, (size_t)e->B * N2, false)) != AOG_OK) return rc;
   if ((rc = dev_alloc(e, &e->sh_noisy, (size_t)e->B * N2, false)) != AOG_OK) return rc;
-  hipfftHandle plan;
-  int dims[2] = {2 * N, 2 * N};
-  if (hipfftPlanMany(&plan, 2, dims, nullptr, 1, 4 * N * N, nullptr, 1, 4 * N * N, e->sh_double ? HIPFFT_Z2Z : HIPFFT_C2C, e->B) != HIPFFT_SUCCESS)
-    return fail(AOG_ERR_HIP, "hipfftPlanMany(%s %d x %d, batch %d) failed", e->sh_double ? "Z2Z" : "C2C", 2 * N, 2 * N, e->B);
-  e->sh_plan = (void*)(uintptr_t)plan;
+  if (!e->sh_pruned) {
+    hipfftHandle plan;
+    int dims[2] = {2 * N, 2 * N};
+    if (hipfftPlanMany(&plan, 2, dims, nullptr, 1, 4 * N * N, nullptr, 1, 4 * N * N, e->sh_double ? HIPFFT_Z2Z : HIPFFT_C2C, e->B) != HIPFFT_SUCCESS)
+      return fail(AOG_ERR_HIP, "hipfftPlanMany(%s %d x %d, batch %d) failed", e->sh_double ? "Z2Z" : "C2C", 2 * N, 2 * N, e->B);
+    e->sh_plan = (void*)(uintptr_t)plan;
+  }
   e->sh_amp = t->field_amplitude;
   e->sh_scale = t->image_scale;
   e->sh_gain = t->gain;
@@ -1042,7 +1070,7 @@ int aog_sh_image(aog_env* e, double* image_dev, void* stream) {
   const int N = e->cfg.n_pupil;
   const size_t per = (size_t)4 * N * N;
   hipfftHandle plan = (hipfftHandle)(uintptr_t)e->sh_plan;
-  if (hipfftSetStream(plan, s) != HIPFFT_SUCCESS) return fail(AOG_ERR_HIP, "hipfftSetStream failed");
+  if (!e->sh_pruned && hipfftSetStream(plan, s) != HIPFFT_SUCCESS) return fail(AOG_ERR_HIP, "hipfftSetStream failed");
   if (int rct = ensure_tiles(e, s)) return rct;
   {
     const int n = e->B * e->A_pad;
@@ -1052,11 +1080,35 @@ int aog_sh_image(aog_env* e, double* image_dev, void* stream) {
   }
   const double norm = 1.0 / (double)per;  // hipFFT's inverse is un-normalised
   const dim3 g_ap((e->n_ap + 255) / 256, e->B), g_per((unsigned)((per + 255) / 256), e->B), g_img((N * N + 255) / 256, e->B);
-  if (e->sh_double) {
+  if (e->sh_pruned) {
+    float2* field = static_cast<float2*>(e->sh_in);
+    float2* GT = field + (size_t)e->B * N * N;
+    float2* F1T = static_cast<float2*>(e->sh_pad);
+    const float2* tw = reinterpret_cast<const float2*>(e->sh_tw);
+    hipLaunchKernelGGL(aog::k_sh_field<float2>, g_ap, dim3(256), 0, s, e->sh_phase, e->ap_index, reinterpret_cast<const double2*>(e->sh_mla), field, e->n_ap,
+                       e->n_ptiles, N, e->sh_amp, (size_t)N * N, N);
+    HIP_TRY(hipGetLastError());
+    const size_t lds = sizeof(float) * 64 * 65 * aog::kShFftWaves;
+    const double scale = e->sh_scale * norm * norm;
+    auto run = [&](auto rlc) -> int {
+      constexpr int RL = decltype(rlc)::v, BC = 64 / RL;
+      const int L = 64 * RL;
+      if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_sh_rows_fwd<RL>), lds, e->device)) return rc;
+      if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_sh_cols<RL>), lds, e->device)) return rc;
+      if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_sh_rows_inv<RL>), lds, e->device)) return rc;
+      const dim3 g_rows((N / BC + aog::kShFftWaves - 1) / aog::kShFftWaves, e->B), g_cols((L / BC + aog::kShFftWaves - 1) / aog::kShFftWaves, e->B);
+      hipLaunchKernelGGL(aog::k_sh_rows_fwd<RL>, g_rows, dim3(64 * aog::kShFftWaves), lds, s, field, F1T, tw);
+      hipLaunchKernelGGL(aog::k_sh_cols<RL>, g_cols, dim3(64 * aog::kShFftWaves), lds, s, F1T, GT, reinterpret_cast<const float2*>(e->sh_tfq), tw);
+      hipLaunchKernelGGL(aog::k_sh_rows_inv<RL>, g_rows, dim3(64 * aog::kShFftWaves), lds, s, GT, e->sh_image, tw, scale);
+      return AOG_OK;
+    };
+    int rcp = e->sh_pruned == 4 ? run(aog::IC<4>{}) : e->sh_pruned == 8 ? run(aog::IC<8>{}) : run(aog::IC<16>{});
+    if (rcp) return rcp;
+  } else if (e->sh_double) {
     double2* in = static_cast<double2*>(e->sh_in);
     double2* pad = static_cast<double2*>(e->sh_pad);
     hipLaunchKernelGGL(aog::k_sh_field<double2>, g_ap, dim3(256), 0, s, e->sh_phase, e->ap_index, reinterpret_cast<const double2*>(e->sh_mla), in, e->n_ap,
-                       e->n_ptiles, N, e->sh_amp);
+                       e->n_ptiles, N, e->sh_amp, per, 2 * N);
     HIP_TRY(hipGetLastError());
     hipfftDoubleComplex* buf = reinterpret_cast<hipfftDoubleComplex*>(pad);
     if (hipfftExecZ2Z(plan, reinterpret_cast<hipfftDoubleComplex*>(in), buf, HIPFFT_FORWARD) != HIPFFT_SUCCESS)
@@ -1068,7 +1120,7 @@ int aog_sh_image(aog_env* e, double* image_dev, void* stream) {
     float2* in = static_cast<float2*>(e->sh_in);
     float2* pad = static_cast<float2*>(e->sh_pad);
     hipLaunchKernelGGL(aog::k_sh_field<float2>, g_ap, dim3(256), 0, s, e->sh_phase, e->ap_index, reinterpret_cast<const double2*>(e->sh_mla), in, e->n_ap,
-                       e->n_ptiles, N, e->sh_amp);
+                       e->n_ptiles, N, e->sh_amp, per, 2 * N);
     HIP_TRY(hipGetLastError());
     hipfftComplex* buf = reinterpret_cast<hipfftComplex*>(pad);
     if (hipfftExecC2C(plan, reinterpret_cast<hipfftComplex*>(in), buf, HIPFFT_FORWARD) != HIPFFT_SUCCESS)

@@ -58,6 +58,9 @@ struct aog_env {
   double* sh_image = nullptr;     // [B][N*N]
   double* sh_noisy = nullptr;     // [B][N*N]
   void* sh_plan = nullptr;        // hipfftHandle (Z2Z, batch B)
+  int sh_pruned = 0;              // L / 64 (4, 8, 16) when the pruned three-pass propagation is used (complex64, N = 128 / 256 / 512); 0 = hipFFT 2-D
+  float* sh_tw = nullptr;         // [L] complex64 e^{+2 pi i j / L}
+  float* sh_tfq = nullptr;        // [L / BC][64][64] complex64 transfer function in the column pass's lane / register order
   double sh_amp = 0, sh_scale = 0, sh_gain = 0, sh_leak = 0;
   uint32_t sh_calls = 0;
   // device screen synthesis (K8)

@@ -2642,7 +2642,7 @@ __global__ __launch_bounds__(64 * kColsWaves) void k_screen_cols(ScreenSynthArgs
 // CT = double2 (complex128 transforms) or float2 (complex64: the default — the detector image is photon-noise limited at 1e-3, see aog_sh_tables)
 template <typename CT>
 __global__ void k_sh_field(const float* __restrict__ phase_tile, const int32_t* __restrict__ ap_index, const double2* __restrict__ mla_phase,
-                           CT* __restrict__ pad, int n_ap, int n_ptiles, int N, double amplitude) {
+                           CT* __restrict__ pad, int n_ap, int n_ptiles, int N, double amplitude, size_t env_stride, int row_stride) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   const int env = blockIdx.y;
   if (p >= n_ap) return;
@@ -2656,7 +2656,7 @@ __global__ void k_sh_field(const float* __restrict__ phase_tile, const int32_t* 
   CT v;
   v.x = (decltype(v.x))(amplitude * (cs * m.x - sn * m.y));
   v.y = (decltype(v.y))(amplitude * (cs * m.y + sn * m.x));
-  pad[(size_t)env * 4 * N * N + (size_t)iy * 2 * N + ix] = v;
+  pad[(size_t)env * env_stride + (size_t)iy * row_stride + ix] = v;   // zero-padded 2N x 2N (2-D transforms) or compact N x N (pruned passes)
 }
 
 // deformable_mirror_shack.actuators (metres, float64) -> the f16 hi/lo B-operand layout
@@ -2687,6 +2687,184 @@ __global__ void k_sh_intensity(const CT* __restrict__ f, double* __restrict__ im
   const int iy = idx / N, ix = idx - iy * N;
   const CT v = f[(size_t)env * 4 * N * N + (size_t)iy * 2 * N + ix];
   image[(size_t)env * N * N + idx] = ((double)v.x * (double)v.x + (double)v.y * (double)v.y) * scale;
+}
+
+// ---- pruned Fresnel propagation for pupils of N = 128, 256, 512 pixels (complex64) ------------------------------------------------------
+// The 2-D route (zero-padded 2N x 2N field -> forward FFT -> x transfer function -> inverse FFT -> crop N x N) moves four full passes over
+// the padded array per transform (rocFFT: 46 of the 76 ms of a config-5 iteration).  Three quarters of the forward input are zeros and
+// three quarters of the inverse output are dropped, so the same arithmetic runs as three passes over HALF-size intermediates:
+//   rows    field[iy][ix < N]  -> forward transform over x (length L = 2N, upper half of the input zero)  -> F1T[kx][iy]      (iy < N)
+//   columns F1T[kx][iy < N]    -> forward over y, x transfer[ky][kx], inverse over y, keep y < N          -> GT[kx][y]
+//   rows    GT[kx][y]          -> inverse over kx, keep x < N, |.|^2 x scale                              -> image[y][x]     (float64)
+// One wave transforms BC = 64 / RL lines of length L = 64 RL at a time (RL = 4, 8, 16), entirely in registers + one private LDS plane:
+//   layout A: lane l holds elements l + 64 r (r < RL) of each of its BC lines             (contiguous in memory: coalesced rows)
+//   layout B: lane (p, bb) = p BC + bb holds elements p + RL k2 (k2 < 64) of line bb
+//   A -> B:  radix-RL over r in registers, twiddle W_L^{l p}, LDS transpose, 64-point transform in registers
+//   B -> A:  64-point transform, LDS transpose, twiddle, radix-RL
+// so a forward / inverse pair with the transfer function in between (the column pass) never leaves the registers, and the transposition
+// between the passes happens in the store / load patterns (64-byte pieces).  Twiddles come from a table computed in float64 on the host.
+template <int RL, bool FWD>
+__device__ __forceinline__ void sh_fft_a2b(cf32 (&v)[64], float* __restrict__ lbuf, const float2* __restrict__ tw) {
+  constexpr int BC = 64 / RL, LG = log2_c(RL);
+  const int lane = threadIdx.x & 63;
+  auto fence = [] {
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the plane is private to the wave
+    __builtin_amdgcn_wave_barrier();
+  };
+  // forward transform = swap(re, im) o inverse transform o swap(re, im): dft_reg is the e^{+} kernel
+  if constexpr (FWD) static_for<64>([&](auto ic) { constexpr int i = decltype(ic)::v; const float t = v[i].x; v[i].x = v[i].y; v[i].y = t; });
+  cf32 wl[RL];
+  static_for<RL>([&](auto pc) {
+    constexpr int pp = decltype(pc)::v;
+    if constexpr (pp > 0) { const float2 t = tw[lane * pp]; wl[pp] = cf32{t.x, t.y}; }
+  });
+  static_for<BC>([&](auto bc) {
+    constexpr int bb = decltype(bc)::v;
+    cf32 x[RL];
+    static_for<RL>([&](auto rc) { x[decltype(rc)::v] = v[bb * RL + decltype(rc)::v]; });
+    dft_reg<RL>(x);
+    static_for<RL>([&](auto pc) {
+      constexpr int pp = decltype(pc)::v;
+      const cf32 y = x[bitrev_c(pp, LG)];
+      v[bb * RL + pp] = pp == 0 ? y : cmul(y, wl[pp]);
+    });
+  });
+  float zx[64];
+  static_for<64>([&](auto ic) { constexpr int i = decltype(ic)::v; constexpr int bb = i / RL, pp = i % RL; lbuf[(pp * BC + bb) * 65 + lane] = v[i].x; });
+  fence();
+  static_for<64>([&](auto tc) { zx[decltype(tc)::v] = lbuf[lane * 65 + decltype(tc)::v]; });
+  fence();
+  static_for<64>([&](auto ic) { constexpr int i = decltype(ic)::v; constexpr int bb = i / RL, pp = i % RL; lbuf[(pp * BC + bb) * 65 + lane] = v[i].y; });
+  fence();
+  static_for<64>([&](auto tc) { constexpr int t = decltype(tc)::v; v[t] = cf32{zx[t], lbuf[lane * 65 + t]}; });
+  fence();
+  dft_reg<64>(v);
+  cf32 o[64];
+  static_for<64>([&](auto ic) { constexpr int i = decltype(ic)::v; o[i] = v[bitrev_c(i, 6)]; });
+  static_for<64>([&](auto ic) {
+    constexpr int i = decltype(ic)::v;
+    if constexpr (FWD) v[i] = cf32{o[i].y, o[i].x};
+    else v[i] = o[i];
+  });
+}
+template <int RL, bool FWD>
+__device__ __forceinline__ void sh_fft_b2a(cf32 (&v)[64], float* __restrict__ lbuf, const float2* __restrict__ tw) {
+  constexpr int BC = 64 / RL, LG = log2_c(RL);
+  const int lane = threadIdx.x & 63;
+  auto fence = [] {
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+  };
+  if constexpr (FWD) static_for<64>([&](auto ic) { constexpr int i = decltype(ic)::v; const float t = v[i].x; v[i].x = v[i].y; v[i].y = t; });
+  dft_reg<64>(v);   // T[l] = v[bitrev(l)]
+  float ux[64];
+  static_for<64>([&](auto lc) { constexpr int l = decltype(lc)::v; lbuf[l * 65 + lane] = v[bitrev_c(l, 6)].x; });
+  fence();
+  static_for<64>([&](auto sc) { ux[decltype(sc)::v] = lbuf[lane * 65 + decltype(sc)::v]; });
+  fence();
+  static_for<64>([&](auto lc) { constexpr int l = decltype(lc)::v; lbuf[l * 65 + lane] = v[bitrev_c(l, 6)].y; });
+  fence();
+  static_for<64>([&](auto sc) { constexpr int ss = decltype(sc)::v; v[ss] = cf32{ux[ss], lbuf[lane * 65 + ss]}; });   // v[p BC + bb]
+  fence();
+  cf32 wl[RL];
+  static_for<RL>([&](auto pc) {
+    constexpr int pp = decltype(pc)::v;
+    if constexpr (pp > 0) { const float2 t = tw[lane * pp]; wl[pp] = cf32{t.x, t.y}; }
+  });
+  cf32 o[64];
+  static_for<BC>([&](auto bc) {
+    constexpr int bb = decltype(bc)::v;
+    cf32 x[RL];
+    static_for<RL>([&](auto pc) {
+      constexpr int pp = decltype(pc)::v;
+      x[pp] = pp == 0 ? v[bb] : cmul(v[pp * BC + bb], wl[pp]);
+    });
+    dft_reg<RL>(x);
+    static_for<RL>([&](auto rc) { constexpr int r = decltype(rc)::v; o[bb * RL + r] = x[bitrev_c(r, LG)]; });
+  });
+  static_for<64>([&](auto ic) {
+    constexpr int i = decltype(ic)::v;
+    if constexpr (FWD) v[i] = cf32{o[i].y, o[i].x};
+    else v[i] = o[i];
+  });
+}
+
+constexpr int kShFftWaves = 4;
+// rows, forward over x:  field [B][N][N] -> F1T [B][L][N]
+template <int RL>
+__global__ __launch_bounds__(64 * kShFftWaves, 2) void k_sh_rows_fwd(const float2* __restrict__ field, float2* __restrict__ F1T, const float2* __restrict__ tw) {
+  extern __shared__ float lds_shfft[];
+  constexpr int L = 64 * RL, N = L / 2, BC = 64 / RL;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int iy0 = (blockIdx.x * kShFftWaves + wave) * BC;
+  if (iy0 >= N) return;
+  const float2* src = field + ((size_t)blockIdx.y * N + iy0) * N + lane;
+  cf32 v[64];
+  static_for<64>([&](auto ic) {
+    constexpr int i = decltype(ic)::v;
+    constexpr int bb = i / RL, r = i % RL;
+    if constexpr (r < RL / 2) { const float2 t = src[(size_t)bb * N + 64 * r]; v[i] = cf32{t.x, t.y}; }
+    else v[i] = cf32{0.f, 0.f};   // the zero padding
+  });
+  sh_fft_a2b<RL, true>(v, lds_shfft + (size_t)wave * 64 * 65, tw);
+  const int pp = lane / BC, bb = lane - pp * BC;
+  float2* dst = F1T + ((size_t)blockIdx.y * L + pp) * N + iy0 + bb;
+  static_for<64>([&](auto kc) { constexpr int k2 = decltype(kc)::v; dst[(size_t)(RL * k2) * N] = make_float2(v[k2].x, v[k2].y); });
+}
+// columns: forward over y, transfer function, inverse over y:  F1T [B][L][N] -> GT [B][L][N]
+// tfq: [L / BC][64][64] = transfer[ky = p + RL k2][kx = group BC + bb] for lane (p, bb), register k2 (arranged on the host)
+template <int RL>
+__global__ __launch_bounds__(64 * kShFftWaves, 2) void k_sh_cols(const float2* __restrict__ F1T, float2* __restrict__ GT, const float2* __restrict__ tfq,
+                                                                 const float2* __restrict__ tw) {
+  extern __shared__ float lds_shfft[];
+  constexpr int L = 64 * RL, N = L / 2, BC = 64 / RL;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int cg = blockIdx.x * kShFftWaves + wave;
+  if (cg * BC >= L) return;
+  const float2* src = F1T + ((size_t)blockIdx.y * L + (size_t)cg * BC) * N + lane;
+  cf32 v[64];
+  static_for<64>([&](auto ic) {
+    constexpr int i = decltype(ic)::v;
+    constexpr int bb = i / RL, r = i % RL;
+    if constexpr (r < RL / 2) { const float2 t = src[(size_t)bb * N + 64 * r]; v[i] = cf32{t.x, t.y}; }
+    else v[i] = cf32{0.f, 0.f};
+  });
+  float* lbuf = lds_shfft + (size_t)wave * 64 * 65;
+  sh_fft_a2b<RL, true>(v, lbuf, tw);
+  const float2* tf = tfq + (size_t)cg * 64 * 64 + lane;
+  static_for<64>([&](auto kc) {
+    constexpr int k2 = decltype(kc)::v;
+    const float2 t = tf[k2 * 64];
+    v[k2] = cmul(v[k2], cf32{t.x, t.y});
+  });
+  sh_fft_b2a<RL, false>(v, lbuf, tw);
+  float2* dst = GT + ((size_t)blockIdx.y * L + (size_t)cg * BC) * N + lane;
+  static_for<64>([&](auto ic) {
+    constexpr int i = decltype(ic)::v;
+    constexpr int bb = i / RL, r = i % RL;
+    if constexpr (r < RL / 2) dst[(size_t)bb * N + 64 * r] = make_float2(v[i].x, v[i].y);
+  });
+}
+// rows, inverse over kx, intensity:  GT [B][L][N] -> image [B][N][N] float64
+template <int RL>
+__global__ __launch_bounds__(64 * kShFftWaves, 2) void k_sh_rows_inv(const float2* __restrict__ GT, double* __restrict__ image, const float2* __restrict__ tw,
+                                                                     double scale) {
+  extern __shared__ float lds_shfft[];
+  constexpr int L = 64 * RL, N = L / 2, BC = 64 / RL;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int y0 = (blockIdx.x * kShFftWaves + wave) * BC;
+  if (y0 >= N) return;
+  const int pp = lane / BC, bb = lane - pp * BC;
+  const float2* src = GT + ((size_t)blockIdx.y * L + pp) * N + y0 + bb;
+  cf32 v[64];
+  static_for<64>([&](auto kc) { constexpr int k2 = decltype(kc)::v; const float2 t = src[(size_t)(RL * k2) * N]; v[k2] = cf32{t.x, t.y}; });
+  sh_fft_b2a<RL, false>(v, lds_shfft + (size_t)wave * 64 * 65, tw);
+  double* dst = image + ((size_t)blockIdx.y * N + y0) * N + lane;
+  static_for<64>([&](auto ic) {
+    constexpr int i = decltype(ic)::v;
+    constexpr int b2 = i / RL, r = i % RL;
+    if constexpr (r < RL / 2) dst[(size_t)b2 * N + 64 * r] = ((double)v[i].x * (double)v[i].x + (double)v[i].y * (double)v[i].y) * scale;
+  });
 }
 
 // hcipy.util.large_poisson with the handle's Philox stream: normal approximation above 1e6 (like hcipy), and below it exact

@@ -863,6 +863,37 @@ def test_shack_hartmann_chain_matches_oracle(N):
     env32.close()
 
 
+@pytest.mark.parametrize("N,B", [(128, 5), (256, 3), (512, 2)])
+def test_shack_hartmann_pruned_propagation_matches_2d_transforms(N, B):
+    """Pupils of 128 / 256 / 512 pixels run the Fresnel propagation as three pruned passes of in-register length-2N transforms (complex64:
+    k_sh_rows_fwd, k_sh_cols, k_sh_rows_inv) instead of zero-padded 2-D FFTs; the detector image must equal the complex128 2-D route
+    (hipFFT Z2Z, the form the oracle test pins at N = 96 / 240) to complex64 rounding, for every env of the batch, also after the mirror
+    has moved."""
+    torch = _torch()
+    from adaptive_optics_gym_amd import BatchedAOEnv
+
+    scr = smooth_screens(B, N, 5) * 0.5
+    kw = dict(act_type="zernike", act_dim=8, obs_dim=2, timesteps_per_episode=50, num_pupil_pixels=N, SH_operation=True, verbose=False)
+    env64 = BatchedAOEnv(B, "cuda:0", screens=scr, sh_fft_precision="double", **kw)
+    env32 = BatchedAOEnv(B, "cuda:0", screens=scr, **kw)
+    env64.reset(); env32.reset()
+    for it in range(2):
+        ref = env64.sh_image().cpu().numpy()
+        got = env32.sh_image().cpu().numpy()
+        assert ref.shape == (B, N * N) and ref.max() > 0
+        for b in range(B):
+            np.testing.assert_allclose(got[b], ref[b], rtol=0, atol=5e-6 * ref[b].max())
+        assert not np.allclose(ref[0], ref[1], rtol=1e-3, atol=1e-6 * ref.max())
+        # the same (deterministically rounded) camera frame into both estimators: both Shack-Hartmann mirrors move identically
+        noisy = np.round(ref)
+        a = env64.sh_update(noisy)
+        torch.testing.assert_close(env32.sh_update(noisy), a, rtol=1e-9, atol=0)
+        env64.step(a)
+        env32.step(a)
+    env64.close()
+    env32.close()
+
+
 def test_shack_hartmann_device_noise_closed_loop():
     torch = _torch()
     from adaptive_optics_gym_amd import BatchedAOEnv
