@@ -315,11 +315,16 @@ class BatchedAOEnv:
         return img
 
     def sh_update(self, noisy_image):
-        """Estimator + leaky integrator on a caller-supplied (already noisy) image [B, N*N] float64 -> actions [B, A] float64."""
+        """Estimator + leaky integrator on a caller-supplied (already noisy) image [B, N*N] float64 -> actions [B, A] float64.
+        ``None``: photon noise from the handle's Philox stream on the image of the last ``sh_image()`` call (what ``SH_step`` does)."""
         torch = self._torch
-        nd = torch.as_tensor(noisy_image, device=self.device).to(torch.float64).reshape(self.num_envs, -1).contiguous()
         action = torch.empty((self.num_envs, self.num_modes), dtype=torch.float64, device=self.device)
-        _lib.check(self.lib.aog_sh_update(self._handle, C.c_void_p(nd.data_ptr()), C.c_void_p(action.data_ptr()), self._stream()))
+        if noisy_image is None:
+            nd_ptr = None
+        else:
+            nd = torch.as_tensor(noisy_image, device=self.device).to(torch.float64).reshape(self.num_envs, -1).contiguous()
+            nd_ptr = C.c_void_p(nd.data_ptr())
+        _lib.check(self.lib.aog_sh_update(self._handle, nd_ptr, C.c_void_p(action.data_ptr()), self._stream()))
         torch.cuda.current_stream(self.device).synchronize()
         return action
 

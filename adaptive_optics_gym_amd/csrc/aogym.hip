@@ -1029,6 +1029,7 @@ int aog_upload_sh(aog_env* e, const aog_sh_tables* t) {
         }
     if ((rc = up(&e->sh_tw, tw.data(), tw.size())) != AOG_OK) return rc;
     if ((rc = up(&e->sh_tfq, tfq.data(), tfq.size())) != AOG_OK) return rc;
+    if ((rc = dev_alloc(e, &e->sh_sums, (size_t)e->B * t->n_sub * 3)) != AOG_OK) return rc;
   } else {
     const size_t cbytes = e->sh_double ? sizeof(double) * 2 : sizeof(float) * 2;
     char* p1 = nullptr;
@@ -1088,23 +1089,41 @@ int aog_sh_image(aog_env* e, double* image_dev, void* stream) {
     hipLaunchKernelGGL(aog::k_sh_field<float2>, g_ap, dim3(256), 0, s, e->sh_phase, e->ap_index, reinterpret_cast<const double2*>(e->sh_mla), field, e->n_ap,
                        e->n_ptiles, N, e->sh_amp, (size_t)N * N, N);
     HIP_TRY(hipGetLastError());
-    const size_t lds = sizeof(float) * 64 * 65 * aog::kShFftWaves;
+    const size_t lds = sizeof(float) * 64 * 65 * aog::kShFftWaves, lds_fused = lds + sizeof(double) * 3 * e->sh_n_sub * aog::kShFftWaves;
     const double scale = e->sh_scale * norm * norm;
+    // nobody asked for the image (SH_step): photon noise and the estimator's per-lenslet sums are taken inside the last pass
+    const bool fused = image_dev == nullptr;
+    aog::ShFuseArgs fa{};
+    if (fused) {
+      e->sh_calls += 1;   // (the noise call the following aog_sh_update(null) would have made)
+      fa.sub_slot = e->sh_slot;
+      fa.x_det = e->sh_xdet;
+      fa.sums = e->sh_sums;
+      fa.n_sub = e->sh_n_sub;
+      fa.idx_base = (size_t)e->cfg.env_id_base * N * N;
+      fa.seed = e->rng_seed;
+      fa.call = e->sh_calls;
+      HIP_TRY(hipMemsetAsync(e->sh_sums, 0, sizeof(double) * (size_t)e->B * e->sh_n_sub * 3, s));
+    }
+    e->sh_sums_ready = fused;
     auto run = [&](auto rlc) -> int {
       constexpr int RL = decltype(rlc)::v, BC = 64 / RL;
       const int L = 64 * RL;
       if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_sh_rows_fwd<RL>), lds, e->device)) return rc;
       if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_sh_cols<RL>), lds, e->device)) return rc;
-      if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_sh_rows_inv<RL>), lds, e->device)) return rc;
+      if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_sh_rows_inv<RL, false>), lds, e->device)) return rc;
+      if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_sh_rows_inv<RL, true>), lds_fused, e->device)) return rc;
       const dim3 g_rows((N / BC + aog::kShFftWaves - 1) / aog::kShFftWaves, e->B), g_cols((L / BC + aog::kShFftWaves - 1) / aog::kShFftWaves, e->B);
       hipLaunchKernelGGL(aog::k_sh_rows_fwd<RL>, g_rows, dim3(64 * aog::kShFftWaves), lds, s, field, F1T, tw);
       hipLaunchKernelGGL(aog::k_sh_cols<RL>, g_cols, dim3(64 * aog::kShFftWaves), lds, s, F1T, GT, reinterpret_cast<const float2*>(e->sh_tfq), tw);
-      hipLaunchKernelGGL(aog::k_sh_rows_inv<RL>, g_rows, dim3(64 * aog::kShFftWaves), lds, s, GT, e->sh_image, tw, scale);
+      if (fused) hipLaunchKernelGGL((aog::k_sh_rows_inv<RL, true>), g_rows, dim3(64 * aog::kShFftWaves), lds_fused, s, GT, e->sh_image, tw, scale, fa);
+      else hipLaunchKernelGGL((aog::k_sh_rows_inv<RL, false>), g_rows, dim3(64 * aog::kShFftWaves), lds, s, GT, e->sh_image, tw, scale, fa);
       return AOG_OK;
     };
     int rcp = e->sh_pruned == 4 ? run(aog::IC<4>{}) : e->sh_pruned == 8 ? run(aog::IC<8>{}) : run(aog::IC<16>{});
     if (rcp) return rcp;
   } else if (e->sh_double) {
+    e->sh_sums_ready = false;
     double2* in = static_cast<double2*>(e->sh_in);
     double2* pad = static_cast<double2*>(e->sh_pad);
     hipLaunchKernelGGL(aog::k_sh_field<double2>, g_ap, dim3(256), 0, s, e->sh_phase, e->ap_index, reinterpret_cast<const double2*>(e->sh_mla), in, e->n_ap,
@@ -1117,6 +1136,7 @@ int aog_sh_image(aog_env* e, double* image_dev, void* stream) {
     if (hipfftExecZ2Z(plan, buf, buf, HIPFFT_BACKWARD) != HIPFFT_SUCCESS) return fail(AOG_ERR_HIP, "hipfftExecZ2Z backward failed");
     hipLaunchKernelGGL(aog::k_sh_intensity<double2>, g_img, dim3(256), 0, s, pad, e->sh_image, N, e->sh_scale * norm * norm);
   } else {
+    e->sh_sums_ready = false;
     float2* in = static_cast<float2*>(e->sh_in);
     float2* pad = static_cast<float2*>(e->sh_pad);
     hipLaunchKernelGGL(aog::k_sh_field<float2>, g_ap, dim3(256), 0, s, e->sh_phase, e->ap_index, reinterpret_cast<const double2*>(e->sh_mla), in, e->n_ap,
@@ -1142,7 +1162,10 @@ int aog_sh_update(aog_env* e, const double* noisy_image_dev, double* action_dev,
   const int N = e->cfg.n_pupil;
   const size_t n = (size_t)e->B * N * N;
   const double* img = noisy_image_dev;
-  if (!img) {
+  const double* sums_in = nullptr;
+  if (!img && e->sh_sums_ready) {
+    sums_in = e->sh_sums;   // the preceding aog_sh_image(null) already drew the noise and summed the lenslets
+  } else if (!img) {
     e->sh_calls += 1;
     hipLaunchKernelGGL(aog::k_sh_noise, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, e->sh_image, e->sh_noisy, n,
                        (size_t)e->cfg.env_id_base * N * N, e->rng_seed, e->sh_calls);
@@ -1150,6 +1173,8 @@ int aog_sh_update(aog_env* e, const double* noisy_image_dev, double* action_dev,
   }
   aog::ShEstimateArgs p{};
   p.image = img;
+  p.sums_in = sums_in;
+  e->sh_sums_ready = false;
   p.sub_slot = e->sh_slot;
   p.x_det = e->sh_xdet;
   p.centres = e->sh_centres;

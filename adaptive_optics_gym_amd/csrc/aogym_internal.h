@@ -60,6 +60,8 @@ struct aog_env {
   void* sh_plan = nullptr;        // hipfftHandle (Z2Z, batch B)
   int sh_pruned = 0;              // L / 64 (4, 8, 16) when the pruned three-pass propagation is used (complex64, N = 128 / 256 / 512); 0 = hipFFT 2-D
   float* sh_tw = nullptr;         // [L] complex64 e^{+2 pi i j / L}
+  double* sh_sums = nullptr;      // [B][n_sub][3] noisy per-lenslet sums of the fused row pass (aog_sh_image without an image pointer)
+  bool sh_sums_ready = false;     // set by that call, consumed by the next aog_sh_update(null)
   float* sh_tfq = nullptr;        // [L / BC][64][64] complex64 transfer function in the column pass's lane / register order
   double sh_amp = 0, sh_scale = 0, sh_gain = 0, sh_leak = 0;
   uint32_t sh_calls = 0;

@@ -2689,6 +2689,24 @@ __global__ void k_sh_intensity(const CT* __restrict__ f, double* __restrict__ im
   image[(size_t)env * N * N + idx] = ((double)v.x * (double)v.x + (double)v.y * (double)v.y) * scale;
 }
 
+// hcipy.util.large_poisson with the handle's Philox stream: normal approximation above 1e6 (like hcipy), and below it exact
+// inversion for lambda < 30, rounded normal approximation otherwise (indistinguishable at those counts).  idx = pixel index in the
+// GLOBAL batch: the stream does not depend on the batch split.
+__device__ __forceinline__ double sh_noisy_value(double lam, size_t idx, unsigned long long seed, uint32_t call) {
+  if (lam < 30.0) {
+    uint32_t c[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), call, 0x50155u};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    for (int r = 0; r < 10; ++r) { philox_round(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+    const double u = ((double)c[0] * 4294967296.0 + (double)c[1] + 0.5) * (1.0 / 18446744073709551616.0);
+    double pk = exp(-lam), cdf = pk;
+    int k = 0;
+    while (u > cdf && k < 200) { ++k; pk *= lam / k; cdf += pk; }
+    return (double)k;
+  }
+  const double g = philox_normal(seed ^ 0xA5A5A5A5ull, (uint32_t)(idx >> 32) ^ call, (uint32_t)idx, 0u);
+  return fmax(0.0, rint(lam + g * sqrt(lam)));
+}
+
 // ---- pruned Fresnel propagation for pupils of N = 128, 256, 512 pixels (complex64) ------------------------------------------------------
 // The 2-D route (zero-padded 2N x 2N field -> forward FFT -> x transfer function -> inverse FFT -> crop N x N) moves four full passes over
 // the padded array per transform (rocFFT: 46 of the 76 ms of a config-5 iteration).  Three quarters of the forward input are zeros and
@@ -2846,54 +2864,97 @@ __global__ __launch_bounds__(64 * kShFftWaves, 2) void k_sh_cols(const float2* _
   });
 }
 // rows, inverse over kx, intensity:  GT [B][L][N] -> image [B][N][N] float64
-template <int RL>
+// FUSED (the image itself is not asked for: SH_step): photon noise and the estimator's per-lenslet sums (flux, flux-weighted x and y:
+// k_sh_estimate's pixel loop) are taken here, while the intensities are in registers — the image is neither written nor re-read twice
+// (k_sh_noise 0.71 ms + k_sh_estimate 0.73 ms per 1024 envs at N = 256 against 0.33 ms for this pass).  A lane keeps running sums per
+// column while consecutive rows stay in the same lenslet, adds them to the wave's table in LDS when the lenslet changes, and the wave
+// adds its table to the env's sums in global memory.
+struct ShFuseArgs {
+  const int32_t* sub_slot;   // [N*N]
+  const double* x_det;       // [N]
+  double* sums;              // [B][n_sub][3], zeroed before the launch
+  int n_sub;
+  size_t idx_base;           // env_id_base * N * N
+  unsigned long long seed;
+  uint32_t call;
+};
+template <int RL, bool FUSED>
 __global__ __launch_bounds__(64 * kShFftWaves, 2) void k_sh_rows_inv(const float2* __restrict__ GT, double* __restrict__ image, const float2* __restrict__ tw,
-                                                                     double scale) {
+                                                                     double scale, ShFuseArgs f) {
   extern __shared__ float lds_shfft[];
   constexpr int L = 64 * RL, N = L / 2, BC = 64 / RL;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int y0 = (blockIdx.x * kShFftWaves + wave) * BC;
   if (y0 >= N) return;
+  double* tab = reinterpret_cast<double*>(lds_shfft + (size_t)kShFftWaves * 64 * 65) + (size_t)wave * 3 * f.n_sub;   // [n_sub][3], this wave's
+  if constexpr (FUSED) {
+    for (int i = lane; i < 3 * f.n_sub; i += 64) tab[i] = 0.0;
+  }
   const int pp = lane / BC, bb = lane - pp * BC;
   const float2* src = GT + ((size_t)blockIdx.y * L + pp) * N + y0 + bb;
   cf32 v[64];
   static_for<64>([&](auto kc) { constexpr int k2 = decltype(kc)::v; const float2 t = src[(size_t)(RL * k2) * N]; v[k2] = cf32{t.x, t.y}; });
   sh_fft_b2a<RL, false>(v, lds_shfft + (size_t)wave * 64 * 65, tw);
-  double* dst = image + ((size_t)blockIdx.y * N + y0) * N + lane;
-  static_for<64>([&](auto ic) {
-    constexpr int i = decltype(ic)::v;
-    constexpr int b2 = i / RL, r = i % RL;
-    if constexpr (r < RL / 2) dst[(size_t)b2 * N + 64 * r] = ((double)v[i].x * (double)v[i].x + (double)v[i].y * (double)v[i].y) * scale;
-  });
+  if constexpr (!FUSED) {
+    double* dst = image + ((size_t)blockIdx.y * N + y0) * N + lane;
+    static_for<64>([&](auto ic) {
+      constexpr int i = decltype(ic)::v;
+      constexpr int b2 = i / RL, r = i % RL;
+      if constexpr (r < RL / 2) dst[(size_t)b2 * N + 64 * r] = ((double)v[i].x * (double)v[i].x + (double)v[i].y * (double)v[i].y) * scale;
+    });
+  } else {
+    constexpr int NX = RL / 2;
+    int cur[NX];
+    double s0[NX], sy[NX], xd[NX];
+    static_for<NX>([&](auto rc) { constexpr int r = decltype(rc)::v; cur[r] = -1; s0[r] = 0.0; sy[r] = 0.0; xd[r] = f.x_det[lane + 64 * r]; });
+    auto flush = [&](int slot, double a0, double ay, double xdet) {
+      if (slot >= 0) {
+        atomicAdd(&tab[3 * slot], a0);
+        atomicAdd(&tab[3 * slot + 1], a0 * xdet);
+        atomicAdd(&tab[3 * slot + 2], ay);
+      }
+    };
+    static_for<BC>([&](auto bc) {
+      constexpr int b2 = decltype(bc)::v;
+      const int y = y0 + b2;
+      const double yd = f.x_det[y];
+      static_for<NX>([&](auto rc) {
+        constexpr int r = decltype(rc)::v, i = b2 * RL + r;
+        const int x = lane + 64 * r;
+        const double lam = ((double)v[i].x * (double)v[i].x + (double)v[i].y * (double)v[i].y) * scale;
+        const int slot = f.sub_slot[y * N + x];
+        if (slot != cur[r]) {
+          flush(cur[r], s0[r], sy[r], xd[r]);
+          cur[r] = slot; s0[r] = 0.0; sy[r] = 0.0;
+        }
+        if (slot >= 0) {
+          const double w = sh_noisy_value(lam, f.idx_base + ((size_t)blockIdx.y * N + y) * N + x, f.seed, f.call) + 1e-10;   // estimate([image + 1e-10]) (AO_env.py:277)
+          s0[r] += w;
+          sy[r] = fma(w, yd, sy[r]);
+        }
+      });
+    });
+    static_for<NX>([&](auto rc) { constexpr int r = decltype(rc)::v; flush(cur[r], s0[r], sy[r], xd[r]); });
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    double* out = f.sums + (size_t)blockIdx.y * 3 * f.n_sub;
+    for (int i = lane; i < 3 * f.n_sub; i += 64) {
+      const double t = tab[i];
+      if (t != 0.0) atomicAdd(&out[i], t);
+    }
+  }
 }
 
-// hcipy.util.large_poisson with the handle's Philox stream: normal approximation above 1e6 (like hcipy), and below it exact
-// inversion for lambda < 30, rounded normal approximation otherwise (indistinguishable at those counts)
 __global__ void k_sh_noise(const double* __restrict__ image, double* __restrict__ noisy, size_t n, size_t idx_base, unsigned long long seed,
                            uint32_t call) {
   const size_t il = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (il >= n) return;
-  const double lam = image[il];
-  const size_t idx = idx_base + il;   // pixel index in the GLOBAL batch (idx_base = env_id_base * N * N): the stream does not depend on the batch split
-  double out;
-  if (lam < 30.0) {
-    uint32_t c[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), call, 0x50155u};
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-    for (int r = 0; r < 10; ++r) { philox_round(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
-    const double u = ((double)c[0] * 4294967296.0 + (double)c[1] + 0.5) * (1.0 / 18446744073709551616.0);
-    double pk = exp(-lam), cdf = pk;
-    int k = 0;
-    while (u > cdf && k < 200) { ++k; pk *= lam / k; cdf += pk; }
-    out = (double)k;
-  } else {
-    const double g = philox_normal(seed ^ 0xA5A5A5A5ull, (uint32_t)(idx >> 32) ^ call, (uint32_t)idx, 0u);
-    out = fmax(0.0, rint(lam + g * sqrt(lam)));
-  }
-  noisy[il] = out;
+  noisy[il] = sh_noisy_value(image[il], idx_base + il, seed, call);   // idx_base = env_id_base * N * N
 }
 
 struct ShEstimateArgs {
   const double* image;          // [B][N*N] (already noisy)
+  const double* sums_in;        // [B][n_sub][3] from the fused row pass (then `image` is not read), or null
   const int32_t* sub_slot;      // [N*N]
   const double* x_det;          // [N]
   const double* centres;        // [n_sub][2]
@@ -2913,8 +2974,11 @@ __global__ __launch_bounds__(256) void k_sh_estimate(ShEstimateArgs p) {
   const int env = blockIdx.x;
   for (int i = threadIdx.x; i < 3 * p.n_sub; i += blockDim.x) sums[i] = 0.0;
   __syncthreads();
+  if (p.sums_in) {
+    for (int i = threadIdx.x; i < 3 * p.n_sub; i += blockDim.x) sums[i] = p.sums_in[(size_t)env * 3 * p.n_sub + i];
+  }
   const double* img = p.image + (size_t)env * p.N * p.N;
-  for (int idx = threadIdx.x; idx < p.N * p.N; idx += blockDim.x) {
+  for (int idx = threadIdx.x; idx < (p.sums_in ? 0 : p.N * p.N); idx += blockDim.x) {
     const int slot = p.sub_slot[idx];
     if (slot < 0) continue;
     const int iy = idx / p.N, ix = idx - iy * p.N;

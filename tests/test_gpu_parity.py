@@ -892,6 +892,21 @@ def test_shack_hartmann_pruned_propagation_matches_2d_transforms(N, B):
         env32.step(a)
     env64.close()
     env32.close()
+    # SH_step never asks for the image: photon noise and the lenslet sums are then taken inside the last propagation pass.  Same Philox
+    # stream, same pixels -> the actuators of the image -> k_sh_noise -> k_sh_estimate route (float64 sums in another order)
+    fused = BatchedAOEnv(B, "cuda:0", screens=scr, seed=21, **kw)
+    plain = BatchedAOEnv(B, "cuda:0", screens=scr, seed=21, **kw)
+    fused.reset(); plain.reset()
+    for it in range(3):
+        a_f, _ = fused.SH_step()
+        plain.sh_image()
+        a_p = plain.sh_update(None)
+        torch.testing.assert_close(a_f, a_p, rtol=1e-9, atol=1e-12 * float(a_p.abs().max()))
+        assert float(a_f.abs().max()) > 0
+        fused.step(a_f)
+        plain.step(a_p)
+    fused.close()
+    plain.close()
 
 
 def test_shack_hartmann_device_noise_closed_loop():
