@@ -1100,7 +1100,7 @@ int aog_sh_image(aog_env* e, double* image_dev, void* stream) {
       fa.x_det = e->sh_xdet;
       fa.sums = e->sh_sums;
       fa.n_sub = e->sh_n_sub;
-      fa.idx_base = (size_t)e->cfg.env_id_base * N * N;
+      fa.env_base = (size_t)e->cfg.env_id_base;
       fa.seed = e->rng_seed;
       fa.call = e->sh_calls;
       HIP_TRY(hipMemsetAsync(e->sh_sums, 0, sizeof(double) * (size_t)e->B * e->sh_n_sub * 3, s));
@@ -1160,15 +1160,14 @@ int aog_sh_update(aog_env* e, const double* noisy_image_dev, double* action_dev,
   HIP_TRY(hipSetDevice(e->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int N = e->cfg.n_pupil;
-  const size_t n = (size_t)e->B * N * N;
   const double* img = noisy_image_dev;
   const double* sums_in = nullptr;
   if (!img && e->sh_sums_ready) {
     sums_in = e->sh_sums;   // the preceding aog_sh_image(null) already drew the noise and summed the lenslets
   } else if (!img) {
     e->sh_calls += 1;
-    hipLaunchKernelGGL(aog::k_sh_noise, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, e->sh_image, e->sh_noisy, n,
-                       (size_t)e->cfg.env_id_base * N * N, e->rng_seed, e->sh_calls);
+    hipLaunchKernelGGL(aog::k_sh_noise, dim3((unsigned)((N * N + 255) / 256), e->B), dim3(256), 0, s, e->sh_image, e->sh_noisy, N,
+                       (size_t)e->cfg.env_id_base, e->rng_seed, e->sh_calls);
     img = e->sh_noisy;
   }
   aog::ShEstimateArgs p{};

@@ -2689,22 +2689,46 @@ __global__ void k_sh_intensity(const CT* __restrict__ f, double* __restrict__ im
   image[(size_t)env * N * N + idx] = ((double)v.x * (double)v.x + (double)v.y * (double)v.y) * scale;
 }
 
-// hcipy.util.large_poisson with the handle's Philox stream: normal approximation above 1e6 (like hcipy), and below it exact
-// inversion for lambda < 30, rounded normal approximation otherwise (indistinguishable at those counts).  idx = pixel index in the
-// GLOBAL batch: the stream does not depend on the batch split.
-__device__ __forceinline__ double sh_noisy_value(double lam, size_t idx, unsigned long long seed, uint32_t call) {
-  if (lam < 30.0) {
-    uint32_t c[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), call, 0x50155u};
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-    for (int r = 0; r < 10; ++r) { philox_round(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
-    const double u = ((double)c[0] * 4294967296.0 + (double)c[1] + 0.5) * (1.0 / 18446744073709551616.0);
-    double pk = exp(-lam), cdf = pk;
-    int k = 0;
-    while (u > cdf && k < 200) { ++k; pk *= lam / k; cdf += pk; }
-    return (double)k;
-  }
-  const double g = philox_normal(seed ^ 0xA5A5A5A5ull, (uint32_t)(idx >> 32) ^ call, (uint32_t)idx, 0u);
-  return fmax(0.0, rint(lam + g * sqrt(lam)));
+// hcipy.util.large_poisson with the handle's Philox stream: exact inversion for lambda < 30, rounded normal approximation above
+// (hcipy switches at 1e6; at these counts the two are indistinguishable).
+// Stream layout: pixel (global env ge, row y, column x) takes word (x >> 6) & 3 of the Philox call with counter
+// ((ge N + y) 64 + (x & 63), group (x >> 6) >> 2, call) — and, when it is bright, the same word of a second call for the Box-Muller angle.  The
+// lane of the fused row pass that holds columns x, x + 64, x + 128, ... therefore draws ONE call per four of its pixels (a call per pixel
+// with a float64 exp and a float64 inversion was ~350 instructions per pixel: two thirds of that pass); results do not depend on the
+// batch split, nor on which kernel draws them.
+__device__ __forceinline__ void sh_noise_words(size_t line, uint32_t group, bool second, unsigned long long seed, uint32_t call, uint32_t (&w)[4]) {
+  uint32_t c[4] = {(uint32_t)line, (uint32_t)(line >> 32) ^ (group << 20) ^ (second ? 0x80000000u : 0u), call, 0x50155u};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) { philox_round(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+  w[0] = c[0]; w[1] = c[1]; w[2] = c[2]; w[3] = c[3];
+}
+constexpr double kShPoissonSwitch = 30.0;
+// Poisson(lam), lam < 30, by inversion on a 32-bit uniform.  exp(-lam) in fp32 (relative error ~1e-7: the uniform is shrunk by 4e-7 so that
+// the accumulated distribution always reaches it), terms and sum in float64.
+__device__ __forceinline__ double sh_poisson_small(double lam, uint32_t word) {
+  const double u = ((double)word + 0.5) * (1.0 / 4294967296.0) * (1.0 - 4e-7);
+  double pk = (double)__expf(-(float)lam), cdf = pk;
+  int k = 0;
+  while (u > cdf && k < 200) { ++k; pk *= lam * __builtin_amdgcn_rcp((double)k); cdf += pk; }
+  return (double)k;
+}
+__device__ __forceinline__ double sh_poisson_large(double lam, uint32_t word_r, uint32_t word_a) {
+  const float u1 = ((float)(word_r >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float u2 = (float)(word_a >> 8) * (1.0f / 16777216.0f);   // revolutions
+  const float g = sqrtf(-2.0f * __logf(u1)) * __builtin_amdgcn_cosf(u2);
+  return fmax(0.0, rint(lam + (double)(g * sqrtf((float)lam))));
+}
+// one pixel on its own (k_sh_noise: pupils the pruned passes do not cover, caller-visible images)
+__device__ __forceinline__ double sh_noisy_value(double lam, size_t ge, int y, int x, int N, unsigned long long seed, uint32_t call) {
+  const size_t line = (ge * N + y) * 64 + (x & 63);
+  const uint32_t r = (uint32_t)x >> 6;
+  uint32_t w[4];
+  sh_noise_words(line, r >> 2, false, seed, call, w);
+  if (lam < kShPoissonSwitch) return sh_poisson_small(lam, w[r & 3]);
+  uint32_t w2[4];
+  sh_noise_words(line, r >> 2, true, seed, call, w2);
+  return sh_poisson_large(lam, w[r & 3], w2[r & 3]);
 }
 
 // ---- pruned Fresnel propagation for pupils of N = 128, 256, 512 pixels (complex64) ------------------------------------------------------
@@ -2874,7 +2898,7 @@ struct ShFuseArgs {
   const double* x_det;       // [N]
   double* sums;              // [B][n_sub][3], zeroed before the launch
   int n_sub;
-  size_t idx_base;           // env_id_base * N * N
+  size_t env_base;           // aog_config.env_id_base: the noise stream is keyed by the GLOBAL env id
   unsigned long long seed;
   uint32_t call;
 };
@@ -2918,9 +2942,16 @@ __global__ __launch_bounds__(64 * kShFftWaves, 2) void k_sh_rows_inv(const float
       constexpr int b2 = decltype(bc)::v;
       const int y = y0 + b2;
       const double yd = f.x_det[y];
+      const size_t line = ((f.env_base + blockIdx.y) * N + y) * 64 + lane;
+      uint32_t wa[4] = {0, 0, 0, 0}, wb[4] = {0, 0, 0, 0};
+      bool have_b = false;
       static_for<NX>([&](auto rc) {
         constexpr int r = decltype(rc)::v, i = b2 * RL + r;
         const int x = lane + 64 * r;
+        if constexpr ((r & 3) == 0) {
+          sh_noise_words(line, r >> 2, false, f.seed, f.call, wa);
+          have_b = false;
+        }
         const double lam = ((double)v[i].x * (double)v[i].x + (double)v[i].y * (double)v[i].y) * scale;
         const int slot = f.sub_slot[y * N + x];
         if (slot != cur[r]) {
@@ -2928,7 +2959,14 @@ __global__ __launch_bounds__(64 * kShFftWaves, 2) void k_sh_rows_inv(const float
           cur[r] = slot; s0[r] = 0.0; sy[r] = 0.0;
         }
         if (slot >= 0) {
-          const double w = sh_noisy_value(lam, f.idx_base + ((size_t)blockIdx.y * N + y) * N + x, f.seed, f.call) + 1e-10;   // estimate([image + 1e-10]) (AO_env.py:277)
+          double out;
+          if (lam < kShPoissonSwitch) {
+            out = sh_poisson_small(lam, wa[r & 3]);
+          } else {
+            if (!have_b) { sh_noise_words(line, r >> 2, true, f.seed, f.call, wb); have_b = true; }
+            out = sh_poisson_large(lam, wa[r & 3], wb[r & 3]);
+          }
+          const double w = out + 1e-10;   // estimate([image + 1e-10]) (AO_env.py:277)
           s0[r] += w;
           sy[r] = fma(w, yd, sy[r]);
         }
@@ -2945,11 +2983,12 @@ __global__ __launch_bounds__(64 * kShFftWaves, 2) void k_sh_rows_inv(const float
   }
 }
 
-__global__ void k_sh_noise(const double* __restrict__ image, double* __restrict__ noisy, size_t n, size_t idx_base, unsigned long long seed,
-                           uint32_t call) {
-  const size_t il = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (il >= n) return;
-  noisy[il] = sh_noisy_value(image[il], idx_base + il, seed, call);   // idx_base = env_id_base * N * N
+__global__ void k_sh_noise(const double* __restrict__ image, double* __restrict__ noisy, int N, size_t env_base, unsigned long long seed, uint32_t call) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N * N) return;
+  const size_t il = (size_t)blockIdx.y * N * N + idx;
+  const int y = idx / N;
+  noisy[il] = sh_noisy_value(image[il], env_base + blockIdx.y, y, idx - y * N, N, seed, call);
 }
 
 struct ShEstimateArgs {
