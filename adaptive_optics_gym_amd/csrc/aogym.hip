@@ -112,6 +112,30 @@ static void launch_phase_t(aog_env* e, hipStream_t s, const _Float16* act16, flo
                      reinterpret_cast<const aog::f16x8*>(e->modes16), reinterpret_cast<const aog::f32x4*>(e->psi_tile),
                      reinterpret_cast<const aog::f16x8*>(act16), reinterpret_cast<aog::f32x4*>(out_tile), e->n_ptiles, e->n_etiles);
 }
+template <int A_PAD>
+static void launch_phase_field_t(aog_env* e, hipStream_t s, const _Float16* act16, const aog::PhaseFieldArgs& fa) {
+  hipLaunchKernelGGL((aog::k_phase_mfma<A_PAD, true>), dim3((e->n_ptiles + 3) / 4, e->n_etiles), dim3(256), 0, s,
+                     reinterpret_cast<const aog::f16x8*>(e->modes16), reinterpret_cast<const aog::f32x4*>(e->psi_tile),
+                     reinterpret_cast<const aog::f16x8*>(act16), static_cast<aog::f32x4*>(nullptr), e->n_ptiles, e->n_etiles, fa);
+}
+void launch_phase_field(aog_env* e, hipStream_t s, const _Float16* act16, float* field, size_t env_stride, int row_stride) {
+  aog::PhaseFieldArgs fa{};
+  fa.ap_yx = e->sh_ap_yx;
+  fa.mla32 = reinterpret_cast<const float2*>(e->sh_mla32);
+  fa.field = reinterpret_cast<float2*>(field);
+  fa.env_stride = env_stride;
+  fa.row_stride = row_stride;
+  fa.n_ap = e->n_ap;
+  fa.B = e->B;
+  fa.N = e->cfg.n_pupil;
+  fa.amplitude = (float)e->sh_amp;
+  switch (e->A_pad) {
+    case 16: launch_phase_field_t<16>(e, s, act16, fa); break;
+    case 32: launch_phase_field_t<32>(e, s, act16, fa); break;
+    case 64: launch_phase_field_t<64>(e, s, act16, fa); break;
+    default: launch_phase_field_t<128>(e, s, act16, fa); break;
+  }
+}
 void launch_phase(aog_env* e, hipStream_t s, const _Float16* act16, float* out_tile) {
   switch (e->A_pad) {
     case 16: launch_phase_t<16>(e, s, act16, out_tile); break;
@@ -1030,6 +1054,13 @@ int aog_upload_sh(aog_env* e, const aog_sh_tables* t) {
     if ((rc = up(&e->sh_tw, tw.data(), tw.size())) != AOG_OK) return rc;
     if ((rc = up(&e->sh_tfq, tfq.data(), tfq.size())) != AOG_OK) return rc;
     if ((rc = dev_alloc(e, &e->sh_sums, (size_t)e->B * t->n_sub * 3)) != AOG_OK) return rc;
+    std::vector<int32_t> apidx((size_t)e->n_ap), yx((size_t)e->n_ap);
+    HIP_TRY(hipMemcpy(apidx.data(), e->ap_index, sizeof(int32_t) * e->n_ap, hipMemcpyDeviceToHost));
+    for (int i = 0; i < e->n_ap; ++i) yx[i] = ((apidx[i] / N) << 16) | (apidx[i] % N);
+    std::vector<float> mla32(N2 * 2);
+    for (size_t i = 0; i < N2 * 2; ++i) mla32[i] = (float)t->mla_phase[i];
+    if ((rc = up(&e->sh_ap_yx, yx.data(), yx.size())) != AOG_OK) return rc;
+    if ((rc = up(&e->sh_mla32, mla32.data(), mla32.size())) != AOG_OK) return rc;
   } else {
     const size_t cbytes = e->sh_double ? sizeof(double) * 2 : sizeof(float) * 2;
     char* p1 = nullptr;
@@ -1077,7 +1108,8 @@ int aog_sh_image(aog_env* e, double* image_dev, void* stream) {
     const int n = e->B * e->A_pad;
     hipLaunchKernelGGL(aog::k_sh_act16, dim3((n + 255) / 256), dim3(256), 0, s, e->sh_act, e->sh_act16, e->B, e->A, e->A_pad,
                        2.0 / e->cfg.wavelength_wfs);
-    aog_host::launch_phase(e, s, e->sh_act16, e->sh_phase);
+    if (e->sh_pruned) aog_host::launch_phase_field(e, s, e->sh_act16, static_cast<float*>(e->sh_in), (size_t)N * N, N);   // phases -> field in one kernel
+    else aog_host::launch_phase(e, s, e->sh_act16, e->sh_phase);
   }
   const double norm = 1.0 / (double)per;  // hipFFT's inverse is un-normalised
   const dim3 g_ap((e->n_ap + 255) / 256, e->B), g_per((unsigned)((per + 255) / 256), e->B), g_img((N * N + 255) / 256, e->B);
@@ -1086,9 +1118,6 @@ int aog_sh_image(aog_env* e, double* image_dev, void* stream) {
     float2* GT = field + (size_t)e->B * N * N;
     float2* F1T = static_cast<float2*>(e->sh_pad);
     const float2* tw = reinterpret_cast<const float2*>(e->sh_tw);
-    hipLaunchKernelGGL(aog::k_sh_field<float2>, g_ap, dim3(256), 0, s, e->sh_phase, e->ap_index, reinterpret_cast<const double2*>(e->sh_mla), field, e->n_ap,
-                       e->n_ptiles, N, e->sh_amp, (size_t)N * N, N);
-    HIP_TRY(hipGetLastError());
     const size_t lds = sizeof(float) * 64 * 65 * aog::kShFftWaves, lds_fused = lds + sizeof(double) * 3 * e->sh_n_sub * aog::kShFftWaves;
     const double scale = e->sh_scale * norm * norm;
     // nobody asked for the image (SH_step): photon noise and the estimator's per-lenslet sums are taken inside the last pass

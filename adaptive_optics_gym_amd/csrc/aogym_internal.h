@@ -60,6 +60,8 @@ struct aog_env {
   void* sh_plan = nullptr;        // hipfftHandle (Z2Z, batch B)
   int sh_pruned = 0;              // L / 64 (4, 8, 16) when the pruned three-pass propagation is used (complex64, N = 128 / 256 / 512); 0 = hipFFT 2-D
   float* sh_tw = nullptr;         // [L] complex64 e^{+2 pi i j / L}
+  int32_t* sh_ap_yx = nullptr;    // [n_ap] iy << 16 | ix of aperture pixel p
+  float* sh_mla32 = nullptr;      // [N*N] complex64 micro-lens phase factor
   double* sh_sums = nullptr;      // [B][n_sub][3] noisy per-lenslet sums of the fused row pass (aog_sh_image without an image pointer)
   bool sh_sums_ready = false;     // set by that call, consumed by the next aog_sh_update(null)
   float* sh_tfq = nullptr;        // [L / BC][64][64] complex64 transfer function in the column pass's lane / register order
@@ -162,4 +164,5 @@ void launch_fused_apad64(aog_env* e, hipStream_t s);
 void launch_fused_apad128(aog_env* e, hipStream_t s);
 // phase-only contraction u = psi + Mt a for every (pixel, env) with the actuator operands `act16`, written in the psi_tile layout
 void launch_phase(aog_env* e, hipStream_t s, const _Float16* act16, float* out_tile);
+void launch_phase_field(aog_env* e, hipStream_t s, const _Float16* act16, float* field, size_t env_stride, int row_stride);   // complex64 field
 }  // namespace aog_host

@@ -833,10 +833,22 @@ __global__ __launch_bounds__(512, 2) void k_fused_tab(const f16x8* __restrict__ 
 
 // Phase-only form of the contraction: u = psi + Mt a for every (pixel, env), written back in the psi_tile layout.  Used by the
 // Shack-Hartmann chain, whose mirror (deformable_mirror_shack) carries its own actuators.  One wave per (env tile, pixel tile).
-template <int A_PAD>
+// FIELD: instead of the phases, the Shack-Hartmann chain's input field E = amplitude e^{2 pi i u} x micro-lens phase goes out, complex64 at
+// (iy, ix) of the env's image (compact N x N for the pruned passes): a lane holds four consecutive aperture pixels per register group and the
+// two half-waves of an env adjacent groups, so a store instruction writes 64 contiguous bytes per env (k_sh_field re-read the phases
+// through the tile layout and wrote 8 bytes per thread: 0.23 ms per 1024 envs at N = 256 on top of this kernel's 0.11).
+struct PhaseFieldArgs {
+  const int32_t* ap_yx;      // [n_ap] iy << 16 | ix
+  const float2* mla32;       // [N*N] micro-lens phase factor, complex64
+  float2* field;
+  size_t env_stride;
+  int row_stride, n_ap, B, N;
+  float amplitude;
+};
+template <int A_PAD, bool FIELD = false>
 __global__ __launch_bounds__(256) void k_phase_mfma(const f16x8* __restrict__ modes16, const f32x4* __restrict__ psi_tile,
                                                     const f16x8* __restrict__ act16, f32x4* __restrict__ out_tile, int n_ptiles,
-                                                    int n_etiles) {
+                                                    int n_etiles, PhaseFieldArgs fa = PhaseFieldArgs{}) {
   constexpr int NSTEP = A_PAD / 16;
   const int lane = threadIdx.x & 63;
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -853,13 +865,45 @@ __global__ __launch_bounds__(256) void k_phase_mfma(const f16x8* __restrict__ mo
     d = __builtin_amdgcn_mfma_f32_32x32x16_f16(ml, bh, d, 0, 0, 0);
   }
   const size_t base = (((size_t)etile * n_ptiles + t) * 4) * 64 + lane;
+  const int env = etile * 32 + (lane & 31), h = lane >> 5;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const f32x4 p = psi_tile[base + g * 64];
     f32x4 o;
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[r] = fmaf(d[4 * g + r], kPhaseUnscale, p[r]);
-    out_tile[base + g * 64] = o;
+    if constexpr (!FIELD) {
+      out_tile[base + g * 64] = o;
+    } else {
+      const int pix0 = t * 32 + 8 * g + 4 * h;   // aperture pixels of accumulator registers 4 g .. 4 g + 3 (see k_fused_tab)
+      if (env < fa.B && pix0 < fa.n_ap) {
+        const int yx0 = fa.ap_yx[pix0], yx3 = fa.ap_yx[min(pix0 + 3, fa.n_ap - 1)];
+        float2 e4[4];
+        int yxs[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool row4 = yx3 == yx0 + 3;   // the four pixels lie side by side in one image row (nearly always)
+          yxs[r] = row4 ? yx0 + r : fa.ap_yx[min(pix0 + r, fa.n_ap - 1)];
+          const int iy = yxs[r] >> 16, ix = yxs[r] & 0xffff;
+          float sn, cs;
+          sincospif(2.0f * (o[r] - rintf(o[r])), &sn, &cs);
+          const float2 m = fa.mla32[iy * fa.N + ix];
+          e4[r] = make_float2(fa.amplitude * (cs * m.x - sn * m.y), fa.amplitude * (cs * m.y + sn * m.x));
+        }
+        float2* dst0 = fa.field + (size_t)env * fa.env_stride + (size_t)(yx0 >> 16) * fa.row_stride + (yx0 & 0xffff);
+        if (yx3 == yx0 + 3 && pix0 + 3 < fa.n_ap) {   // (8-byte aligned 16-byte stores: global memory takes them)
+          typedef float f32x4s __attribute__((ext_vector_type(4), aligned(8)));
+          const f32x4s lo = {e4[0].x, e4[0].y, e4[1].x, e4[1].y}, hi = {e4[2].x, e4[2].y, e4[3].x, e4[3].y};
+          reinterpret_cast<f32x4s*>(dst0)[0] = lo;
+          reinterpret_cast<f32x4s*>(dst0)[1] = hi;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (pix0 + r < fa.n_ap)
+              fa.field[(size_t)env * fa.env_stride + (size_t)(yxs[r] >> 16) * fa.row_stride + (yxs[r] & 0xffff)] = e4[r];
+        }
+      }
+    }
   }
 }
 
@@ -2689,8 +2733,9 @@ __global__ void k_sh_intensity(const CT* __restrict__ f, double* __restrict__ im
   image[(size_t)env * N * N + idx] = ((double)v.x * (double)v.x + (double)v.y * (double)v.y) * scale;
 }
 
-// hcipy.util.large_poisson with the handle's Philox stream: exact inversion for lambda < 30, rounded normal approximation above
-// (hcipy switches at 1e6; at these counts the two are indistinguishable).
+// hcipy.util.large_poisson with the handle's Philox stream: exact inversion for lambda < 12, above it the rounded normal approximation with the
+// Cornish-Fisher skewness term (hcipy switches to a plain rounded normal at 1e6; the sensor's controller reads flux-weighted centroids
+// of ~1e3 pixels per lenslet: mean, variance and third moment of every pixel's count are those of the Poisson law).
 // Stream layout: pixel (global env ge, row y, column x) takes word (x >> 6) & 3 of the Philox call with counter
 // ((ge N + y) 64 + (x & 63), group (x >> 6) >> 2, call) — and, when it is bright, the same word of a second call for the Box-Muller angle.  The
 // lane of the fused row pass that holds columns x, x + 64, x + 128, ... therefore draws ONE call per four of its pixels (a call per pixel
@@ -2703,21 +2748,36 @@ __device__ __forceinline__ void sh_noise_words(size_t line, uint32_t group, bool
   for (int r = 0; r < 10; ++r) { philox_round(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
   w[0] = c[0]; w[1] = c[1]; w[2] = c[2]; w[3] = c[3];
 }
-constexpr double kShPoissonSwitch = 30.0;
-// Poisson(lam), lam < 30, by inversion on a 32-bit uniform.  exp(-lam) in fp32 (relative error ~1e-7: the uniform is shrunk by 4e-7 so that
-// the accumulated distribution always reaches it), terms and sum in float64.
-__device__ __forceinline__ double sh_poisson_small(double lam, uint32_t word) {
-  const double u = ((double)word + 0.5) * (1.0 / 4294967296.0) * (1.0 - 4e-7);
-  double pk = (double)__expf(-(float)lam), cdf = pk;
-  int k = 0;
-  while (u > cdf && k < 200) { ++k; pk *= lam * __builtin_amdgcn_rcp((double)k); cdf += pk; }
-  return (double)k;
+constexpr double kShPoissonSwitch = 12.0;
+// Poisson(lam), lam < 12, by inversion on a 32-bit uniform.  exp(-lam) in fp32 (relative error ~1e-7: the uniform is shrunk by 4e-7 so that
+// the accumulated distribution always reaches it), terms and sum in float64.  The wave walks the terms in lockstep (k is wave-uniform,
+// 1 / k comes from a scalar table) until its last lane is done: at most ~30 terms below the switch.
+struct RcpTable { double v[64]; };
+__device__ constexpr RcpTable make_rcp_table() {
+  RcpTable t{};
+  t.v[0] = 0.0;
+  for (int k = 1; k < 64; ++k) t.v[k] = 1.0 / (double)k;
+  return t;
 }
+__constant__ const RcpTable kShRcp = make_rcp_table();
+__device__ __forceinline__ double sh_poisson_small(double lam, uint32_t word, bool active) {
+  const double u = active ? ((double)word + 0.5) * (1.0 / 4294967296.0) * (1.0 - 4e-7) : 0.0;
+  double pk = (double)__expf(-(float)lam), cdf = pk;
+  int kres = 0;
+  for (int k = 1; k < 64; ++k) {
+    const bool more = u > cdf;
+    if (!__any(more ? 1 : 0)) break;
+    const double rk = kShRcp.v[k];
+    if (more) { pk *= lam * rk; cdf += pk; kres = k; }
+  }
+  return (double)kres;
+}
+// rounded normal approximation with the Cornish-Fisher skewness term (matches mean, variance and third moment of Poisson(lam))
 __device__ __forceinline__ double sh_poisson_large(double lam, uint32_t word_r, uint32_t word_a) {
   const float u1 = ((float)(word_r >> 8) + 0.5f) * (1.0f / 16777216.0f);
   const float u2 = (float)(word_a >> 8) * (1.0f / 16777216.0f);   // revolutions
   const float g = sqrtf(-2.0f * __logf(u1)) * __builtin_amdgcn_cosf(u2);
-  return fmax(0.0, rint(lam + (double)(g * sqrtf((float)lam))));
+  return fmax(0.0, rint(lam + (double)(g * sqrtf((float)lam) + (g * g - 1.0f) * (1.0f / 6.0f))));
 }
 // one pixel on its own (k_sh_noise: pupils the pruned passes do not cover, caller-visible images)
 __device__ __forceinline__ double sh_noisy_value(double lam, size_t ge, int y, int x, int N, unsigned long long seed, uint32_t call) {
@@ -2725,7 +2785,9 @@ __device__ __forceinline__ double sh_noisy_value(double lam, size_t ge, int y, i
   const uint32_t r = (uint32_t)x >> 6;
   uint32_t w[4];
   sh_noise_words(line, r >> 2, false, seed, call, w);
-  if (lam < kShPoissonSwitch) return sh_poisson_small(lam, w[r & 3]);
+  const bool small = lam < kShPoissonSwitch;
+  const double ks = sh_poisson_small(small ? lam : 0.0, w[r & 3], small);   // (every lane walks the wave's loop: no divergent call)
+  if (small) return ks;
   uint32_t w2[4];
   sh_noise_words(line, r >> 2, true, seed, call, w2);
   return sh_poisson_large(lam, w[r & 3], w2[r & 3]);
@@ -2958,11 +3020,10 @@ __global__ __launch_bounds__(64 * kShFftWaves, 2) void k_sh_rows_inv(const float
           flush(cur[r], s0[r], sy[r], xd[r]);
           cur[r] = slot; s0[r] = 0.0; sy[r] = 0.0;
         }
+        const bool small = slot >= 0 && lam < kShPoissonSwitch;
+        double out = sh_poisson_small(small ? lam : 0.0, wa[r & 3], small);   // (the wave's loop: every lane takes part)
         if (slot >= 0) {
-          double out;
-          if (lam < kShPoissonSwitch) {
-            out = sh_poisson_small(lam, wa[r & 3]);
-          } else {
+          if (!small) {
             if (!have_b) { sh_noise_words(line, r >> 2, true, f.seed, f.call, wb); have_b = true; }
             out = sh_poisson_large(lam, wa[r & 3], wb[r & 3]);
           }
