@@ -284,6 +284,8 @@ int evolve_layer(aog_env* e, hipStream_t s) {
   p.N = e->cfg.n_pupil;
   p.nz_v = e->nz_v;
   p.nz_h = e->nz_h;
+  p.near_v = e->near_v;
+  p.near_h = e->near_h;
   p.t_prev = (double)(e->timestep - 1) * e->delta_t;
   p.t_new = (double)e->timestep * e->delta_t;
   p.pitch = e->pitch;
@@ -791,22 +793,47 @@ int aog_upload_layer(aog_env* e, const aog_layer_tables* t) {
     return AOG_OK;
   };
   if (e->layer_ready) return fail(AOG_ERR_STATE, "aog_upload_layer: already uploaded");
-  if ((rc = upload_blocked(t->A_vertical, N, e->nz_v, &e->Wa_v)) != AOG_OK) return rc;
+  // The device keeps the stencil samples (and the matching columns of A) with the NEAR ones first — the samples in the two newest slices
+  // (rows 0, 1 of the 'bottom' stencil, columns 0, 1 of the 'left' one), which change with every extrusion — and the FAR ones after
+  // them: k_extrude16_split fetches an env's far samples for the next round ahead of the inter-workgroup barrier.  A permutation of
+  // the terms of A z: every kernel form reads the same arrays.
+  auto near_first = [&](const int32_t* stencil, const double* A, int nz, bool vertical, std::vector<int32_t>& st, std::vector<double>& Ap) -> int {
+    std::vector<int> order;
+    for (int pass = 0; pass < 2; ++pass)
+      for (int k = 0; k < nz; ++k) {
+        const int slice = vertical ? stencil[k] / N : stencil[k] % N;
+        if ((slice < 2) == (pass == 0)) order.push_back(k);
+      }
+    int n_near = 0;
+    for (int k = 0; k < nz; ++k) n_near += (vertical ? stencil[k] / N : stencil[k] % N) < 2;
+    st.resize(nz);
+    Ap.resize((size_t)N * nz);
+    for (int k = 0; k < nz; ++k) {
+      st[k] = stencil[order[k]];
+      for (int r = 0; r < N; ++r) Ap[(size_t)r * nz + k] = A[(size_t)r * nz + order[k]];
+    }
+    return n_near;
+  };
+  std::vector<int32_t> st_v, st_h;
+  std::vector<double> Ap_v, Ap_h;
+  e->near_v = near_first(t->stencil_vertical, t->A_vertical, e->nz_v, true, st_v, Ap_v);
+  e->near_h = near_first(t->stencil_horizontal, t->A_horizontal, e->nz_h, false, st_h, Ap_h);
+  if ((rc = upload_blocked(Ap_v.data(), N, e->nz_v, &e->Wa_v)) != AOG_OK) return rc;
   if ((rc = upload_blocked(t->B_vertical, N, N, &e->Wb_v)) != AOG_OK) return rc;
-  if ((rc = upload_blocked(t->A_horizontal, N, e->nz_h, &e->Wa_h)) != AOG_OK) return rc;
+  if ((rc = upload_blocked(Ap_h.data(), N, e->nz_h, &e->Wa_h)) != AOG_OK) return rc;
   if ((rc = upload_blocked(t->B_horizontal, N, N, &e->Wb_h)) != AOG_OK) return rc;
-  if ((rc = upload_t(t->A_vertical, N, e->nz_v, &e->At_v)) != AOG_OK) return rc;
+  if ((rc = upload_t(Ap_v.data(), N, e->nz_v, &e->At_v)) != AOG_OK) return rc;
   if ((rc = upload_t(t->B_vertical, N, N, &e->Bt_v)) != AOG_OK) return rc;
-  if ((rc = upload_t(t->A_horizontal, N, e->nz_h, &e->At_h)) != AOG_OK) return rc;
+  if ((rc = upload_t(Ap_h.data(), N, e->nz_h, &e->At_h)) != AOG_OK) return rc;
   if ((rc = upload_t(t->B_horizontal, N, N, &e->Bt_h)) != AOG_OK) return rc;
   if ((rc = dev_alloc(e, &e->stencil_v, e->nz_v, false)) != AOG_OK) return rc;
   if ((rc = dev_alloc(e, &e->stencil_h, e->nz_h, false)) != AOG_OK) return rc;
-  HIP_TRY(hipMemcpy(e->stencil_v, t->stencil_vertical, sizeof(int32_t) * e->nz_v, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(e->stencil_h, t->stencil_horizontal, sizeof(int32_t) * e->nz_h, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->stencil_v, st_v.data(), sizeof(int32_t) * e->nz_v, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->stencil_h, st_h.data(), sizeof(int32_t) * e->nz_h, hipMemcpyHostToDevice));
   {
     std::vector<int32_t> pv(e->nz_v), ph(e->nz_h);
-    for (int k = 0; k < e->nz_v; ++k) pv[k] = (int32_t)(((uint32_t)(t->stencil_vertical[k] / N) << 16) | (uint32_t)(t->stencil_vertical[k] % N));
-    for (int k = 0; k < e->nz_h; ++k) ph[k] = (int32_t)(((uint32_t)(t->stencil_horizontal[k] / N) << 16) | (uint32_t)(t->stencil_horizontal[k] % N));
+    for (int k = 0; k < e->nz_v; ++k) pv[k] = (int32_t)(((uint32_t)(st_v[k] / N) << 16) | (uint32_t)(st_v[k] % N));
+    for (int k = 0; k < e->nz_h; ++k) ph[k] = (int32_t)(((uint32_t)(st_h[k] / N) << 16) | (uint32_t)(st_h[k] % N));
     if ((rc = dev_alloc(e, &e->stencil_v_yx, e->nz_v, false)) != AOG_OK) return rc;
     if ((rc = dev_alloc(e, &e->stencil_h_yx, e->nz_h, false)) != AOG_OK) return rc;
     HIP_TRY(hipMemcpy(e->stencil_v_yx, pv.data(), sizeof(int32_t) * e->nz_v, hipMemcpyHostToDevice));

@@ -131,6 +131,7 @@ struct aog_env {
   double* Wa_h = nullptr;
   double* Wb_h = nullptr;
   int nz_v = 0, nz_h = 0;
+  int near_v = 0, near_h = 0;    // stencil samples in the two newest slices come first in the uploaded order (aog_upload_layer)
   double sqrt_cn2 = 0, pitch = 0, delta_t = 0;
   const double* next_noise = nullptr;
   int next_noise_max_ext = 0;

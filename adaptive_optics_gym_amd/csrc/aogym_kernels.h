@@ -1154,6 +1154,7 @@ struct ExtrudeArgs {
   const double* Wb_h;
   const double* noise;       // nullable: [B][max_ext][N]
   int N, nz_v, nz_h, max_ext;
+  int near_v, near_h;        // the stencils' first near_* samples lie in the two newest slices (rows / columns 0, 1), the rest further in
   double t_prev, t_new, pitch, sqrt_cn2;
   unsigned long long seed;
   int env_base;              // global id of env 0 of this handle: the Philox streams are keyed by env_base + env
@@ -1574,6 +1575,55 @@ __global__ __launch_bounds__(256 * KS) void k_extrude16_split(ExtrudeArgs p, int
   long long tm[6] = {0, 0, 0, 0, 0, 0};
   int n_pass = 0;
   long long cyc = 0;
+  constexpr int GD = 12;
+  const int n_waves = (int)(blockDim.x >> 6);
+  // samples [k_lo, k_hi) of env slot g's stencil (class c: 1 = 'left' stencil, x extrusion; 2 = 'bottom', y) at origin (ox, oy) -> zb
+  auto gather_env = [&](int g, int c, int k_lo, int k_hi, int ox, int oy) {
+    const bool horizontal = c == 1;
+    const int32_t* st = horizontal ? st_h : st_v;
+    const bool flipped = __builtin_amdgcn_readfirstlane(horizontal ? s_dx[g] : s_dy[g]) > 0;
+    const double* __restrict__ src = p.master + (size_t)__builtin_amdgcn_readfirstlane(s_env[g]) * N * N;
+    double* zrow_g = zb + (size_t)g * zs;
+    for (int k0 = k_lo; k0 < k_hi; k0 += 64 * GD) {
+      double v[GD];
+#pragma unroll
+      for (int u = 0; u < GD; ++u) {
+        const int k = min(k0 + 64 * u + lane, k_hi - 1);   // branch-free: every lane loads from a valid address
+        const uint32_t pk = (uint32_t)st[k];
+        int sy = (int)(pk >> 16), sx = (int)(pk & 0xFFFFu);
+        sy = flipped ? N - 1 - sy : sy;
+        sx = flipped ? N - 1 - sx : sx;
+        int py = sy + oy, px = sx + ox;
+        py -= py >= N ? N : 0;
+        px -= px >= N ? N : 0;
+        v[u] = src[py * N + px];
+      }
+#pragma unroll
+      for (int u = 0; u < GD; ++u) {
+        const int k = k0 + 64 * u + lane;
+        if (k < k_hi) zrow_g[k] = v[u];
+      }
+    }
+  };
+  // the normals of env slot g's extrusion number rr of this step -> nb
+  auto noise_env = [&](int g, int rr) {
+    const int env = __builtin_amdgcn_readfirstlane(s_env[g]);
+    double* nrow_g = nb + (size_t)g * ns;
+    if (p.noise && rr < p.max_ext) {
+      const double* __restrict__ src = p.noise + ((size_t)env * p.max_ext + rr) * N;
+      for (int jx = lane; jx < N; jx += 64) nrow_g[jx] = src[jx];
+    } else {
+      const uint32_t ctr = p.ext_counter[env] + (uint32_t)rr;
+      for (int j4 = lane; 4 * j4 < N; j4 += 64) {   // four normals per Philox call
+        double v[4];
+        philox_normal4(p.seed, (uint32_t)(p.env_base + env), ctr, (uint32_t)j4, v);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (4 * j4 + u < N) nrow_g[4 * j4 + u] = v[u];
+      }
+    }
+  };
+  int pf = 0;   // bit j: the far samples of this wave's j-th env are already in zb (fetched in the previous round's tail)
   for (int r = 0; r < rounds; ++r) {
     long long t0 = dbg ? wall_clock64() : 0;
     auto cls = [&](int g) { return r < abs(s_dx[g]) ? 1 : (r < abs(s_dx[g]) + abs(s_dy[g]) ? 2 : 0); };
@@ -1583,58 +1633,20 @@ __global__ __launch_bounds__(256 * KS) void k_extrude16_split(ExtrudeArgs p, int
     // batch is issued before any is consumed: the samples come from HBM / L2 (the master screens do not fit the caches), one memory
     // round trip per batch of 12.  (What is left is sector traffic: 8 bytes used of every 64 fetched.  A transposed copy of the master
     // screens for the column stencils was tried: its scattered writes cost more than the contiguous reads saved.)
-    constexpr int GD = 12;
-    const int n_waves = (int)(blockDim.x >> 6);
-    for (int g = wave; g < G; g += n_waves) {
+    // The stencils arrive with their NEAR samples (the two newest slices: rows / columns 0 and 1) first and the FAR ones after them
+    // (aog_upload_layer orders them so).  An env that extrudes in the same direction as in the round before had its far samples and its
+    // normals fetched in that round's tail, AHEAD of the group barrier (they do not depend on the slice the partners were writing): here
+    // it only gathers the near samples, which come out of the L2 the partners just wrote.
+    for (int jg = 0, g = wave; g < G; g += n_waves, ++jg) {
       const int c = __builtin_amdgcn_readfirstlane(cls(g));
       if (!c) continue;   // (rows of envs outside both classes keep stale samples: their product columns are never stored)
-      const bool horizontal = c == 1;
-      const int nz = horizontal ? p.nz_h : p.nz_v;
-      const int32_t* st = horizontal ? st_h : st_v;
-      const bool flipped = __builtin_amdgcn_readfirstlane(horizontal ? s_dx[g] : s_dy[g]) > 0;
-      const int oy = __builtin_amdgcn_readfirstlane(s_oy[g]), ox = __builtin_amdgcn_readfirstlane(s_ox[g]);
-      const double* __restrict__ src = p.master + (size_t)__builtin_amdgcn_readfirstlane(s_env[g]) * N * N;
-      double* zrow_g = zb + (size_t)g * zs;
-      for (int k0 = 0; k0 < nz; k0 += 64 * GD) {
-        double v[GD];
-#pragma unroll
-        for (int u = 0; u < GD; ++u) {
-          const int k = min(k0 + 64 * u + lane, nz - 1);   // branch-free: every lane loads from a valid address
-          const uint32_t pk = (uint32_t)st[k];
-          int sy = (int)(pk >> 16), sx = (int)(pk & 0xFFFFu);
-          sy = flipped ? N - 1 - sy : sy;
-          sx = flipped ? N - 1 - sx : sx;
-          int py = sy + oy, px = sx + ox;
-          py -= py >= N ? N : 0;
-          px -= px >= N ? N : 0;
-          v[u] = src[py * N + px];
-        }
-#pragma unroll
-        for (int u = 0; u < GD; ++u) {
-          const int k = k0 + 64 * u + lane;
-          if (k < nz) zrow_g[k] = v[u];
-        }
-      }
+      const int nz = c == 1 ? p.nz_h : p.nz_v, near = c == 1 ? p.near_h : p.near_v;
+      gather_env(g, c, 0, ((pf >> jg) & 1) ? near : nz, __builtin_amdgcn_readfirstlane(s_ox[g]), __builtin_amdgcn_readfirstlane(s_oy[g]));
     }
     if (dbg) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); long long t = wall_clock64(); tm[0] += t - t0; t0 = t; }
-    // normals of the same envs (no barrier in between: a wave fills the rows of its own envs)
-    for (int g = wave; g < G; g += n_waves) {
-      if (!__builtin_amdgcn_readfirstlane(cls(g))) continue;
-      const int env = __builtin_amdgcn_readfirstlane(s_env[g]);
-      double* nrow_g = nb + (size_t)g * ns;
-      if (p.noise && r < p.max_ext) {
-        const double* __restrict__ src = p.noise + ((size_t)env * p.max_ext + r) * N;
-        for (int j = lane; j < N; j += 64) nrow_g[j] = src[j];
-      } else {
-        const uint32_t ctr = p.ext_counter[env] + (uint32_t)r;
-        for (int j4 = lane; 4 * j4 < N; j4 += 64) {   // four normals per Philox call
-          double v[4];
-          philox_normal4(p.seed, (uint32_t)(p.env_base + env), ctr, (uint32_t)j4, v);
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-            if (4 * j4 + u < N) nrow_g[4 * j4 + u] = v[u];
-        }
-      }
+    if (r == 0) {   // (later rounds: drawn in the previous round's tail)
+      for (int g = wave; g < G; g += n_waves)
+        if (__builtin_amdgcn_readfirstlane(cls(g))) noise_env(g, r);
     }
     __syncthreads();
     if (dbg) { long long t = wall_clock64(); tm[1] += t - t0; t0 = t; }
@@ -1803,6 +1815,26 @@ __global__ __launch_bounds__(256 * KS) void k_extrude16_split(ExtrudeArgs p, int
             store_master(p, s_env[g], py, px, v);
           }
         }
+      }
+    }
+    // ---- tail: what the next round needs and this round's slice does not touch, while the partners finish ----
+    // (every wave is past its last read of zb / nb: the partial-sum exchange above ends in a workgroup barrier)
+    pf = 0;
+    if (r + 1 < rounds) {
+      auto cls_next = [&](int g) { return r + 1 < abs(s_dx[g]) ? 1 : (r + 1 < abs(s_dx[g]) + abs(s_dy[g]) ? 2 : 0); };
+      for (int jg = 0, g = wave; g < G; g += n_waves, ++jg) {
+        const int c1 = __builtin_amdgcn_readfirstlane(cls_next(g));
+        if (!c1) continue;
+        if (c1 == __builtin_amdgcn_readfirstlane(cls(g))) {
+          // same direction again: next round's frame is this one moved by one slice, its far samples (>= 2 slices in) are >= 1 slice
+          // in now — written in earlier rounds, behind earlier barriers
+          int nox = __builtin_amdgcn_readfirstlane(s_ox[g]), noy = __builtin_amdgcn_readfirstlane(s_oy[g]);
+          if (c1 == 1) nox = __builtin_amdgcn_readfirstlane(s_dx[g]) > 0 ? (nox + 1 == N ? 0 : nox + 1) : (nox == 0 ? N - 1 : nox - 1);
+          else noy = __builtin_amdgcn_readfirstlane(s_dy[g]) > 0 ? (noy + 1 == N ? 0 : noy + 1) : (noy == 0 ? N - 1 : noy - 1);
+          gather_env(g, c1, c1 == 1 ? p.near_h : p.near_v, c1 == 1 ? p.nz_h : p.nz_v, nox, noy);
+          pf |= 1 << jg;
+        }
+        noise_env(g, r + 1);
       }
     }
     // ---- group barrier: this round's rows of all four workgroups are visible before anyone gathers again ----
