@@ -1005,9 +1005,10 @@ int aog_generate_screens(aog_env* e, int first, int count, int oversampling, dou
   const float crop_scale = (float)(std::sqrt(cn_squared) / ((double)m * m * pixel_pitch * pixel_pitch));
   for (int done = 0; done < count; done += e->fft_batch) {
     const int nb = std::min(e->fft_batch, count - done);
-    const size_t pairs = (size_t)m * m / 2;
-    hipLaunchKernelGGL(aog::k_spectrum_fill, dim3((unsigned)((pairs + 255) / 256), nb), dim3(256), 0, s, reinterpret_cast<float2*>(e->fft_work), m,
-                       first + done, e->cfg.env_id_base, e->rng_seed, e->screen_gen, du, u0 * u0, amp_scale);
+    const int q = m / N, lw = aog::spectrum_lane_width(N), n_r = (N + lw - 1) / lw;
+    const size_t calls = (size_t)q * lw * ((n_r + 3) / 4) * m;
+    hipLaunchKernelGGL(aog::k_spectrum_fill, dim3((unsigned)((calls + 255) / 256), nb), dim3(256), 0, s, reinterpret_cast<float2*>(e->fft_work), m, q,
+                       first + done, e->cfg.env_id_base, e->rng_seed, e->screen_gen, (float)du, (float)(u0 * u0), (float)amp_scale);
     HIP_TRY(hipGetLastError());
     // the plan is batched for fft_batch transforms; surplus slots of a short last chunk hold stale (finite) data and are ignored
     if (hipfftExecC2C(plan, reinterpret_cast<hipfftComplex*>(e->fft_work), reinterpret_cast<hipfftComplex*>(e->fft_work), HIPFFT_BACKWARD) !=

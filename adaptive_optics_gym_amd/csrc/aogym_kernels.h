@@ -2150,48 +2150,68 @@ __global__ void k_cgemm_small(const double2* __restrict__ a, const double2* __re
 //   spectrum[b][v][u] = a(u, v) (g1 + i g2),  a = sqrt(PSD_vK (2 pi)^2 / du^2)  on the UNSHIFTED (q N)^2 FFT grid,
 //   then an un-normalised inverse FFT (hipFFT) and k_screen_crop takes Re of the centred N x N crop / (M delta^2) * sqrt(Cn^2).
 // ------------------------------------------------------------------------------------------------
-#ifdef AOG_MAIN_TU
-__global__ void k_spectrum_fill(float2* __restrict__ spec, int m, int first_local, int env_base, unsigned long long seed,
-                                const uint32_t* __restrict__ gen, double du, double u0sq, double amp_scale) {
-  // one thread = two adjacent complex samples (one Philox call = 4 words = 2 Box-Muller pairs)
-  const size_t pair = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t per_env = (size_t)m * m / 2;
-  const int b = blockIdx.y;
-  if (pair >= per_env) return;
-  // Half-plane form (see k_screen_rows): lines v > m/2 stay zero, lines 0 < v < m/2 carry sqrt(2) x the amplitude
-  const int v_line = (int)((2 * pair) / m);   // m is even: both samples of a pair sit on one line
-  if (2 * v_line > m) {
-    reinterpret_cast<float4*>(spec + (size_t)b * m * m)[pair] = make_float4(0.f, 0.f, 0.f, 0.f);
-    return;
-  }
-  const float line_scale = (v_line == 0 || 2 * v_line == m) ? 1.f : 1.41421356237f;
-  // stream = (seed, GLOBAL env id, how many screens this env has drawn so far): independent of batch split and reset masks
-  const uint32_t generation = gen[first_local + b] + 1u;
-  uint32_t c[4] = {(uint32_t)pair, (uint32_t)(pair >> 32) ^ (generation * 0x9E3779B9u), (uint32_t)(env_base + first_local + b), 0x5C4EE7u};
+// Spectrum stream: sample (line v, column u = q a + bg, a = lane + LW r) is word r & 3 of the Philox call whose counter is the flat index of
+// the call's first sample, v m + q (lane + LW (r & ~3)) + bg — the four samples of a call are the ones ONE lane of the pruned row pass
+// feeds into one radix-R butterfly (k_screen_rows), so that pass draws a call per four samples and keeps nothing across its steps.  One
+// 32-bit word makes one complex normal: 16 bits of radius uniform, 16 bits of angle (the screen is a sum of 8 M such terms per pixel:
+// only their variance and independence reach it; E r^2 of the 16-bit form is 2 to 1e-4).  LW = 64 or 60 (pupils of 64 R / 60 R pixels).
+__device__ __forceinline__ void spectrum_words(size_t cidx, uint32_t generation, uint32_t env_global, unsigned long long seed, uint32_t (&w)[4]) {
+  uint32_t c[4] = {(uint32_t)cidx, (uint32_t)(cidx >> 32) ^ (generation * 0x9E3779B9u), env_global, 0x5C4EE7u};
   uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int rr = 0; rr < 10; ++rr) {
     philox_round(c, k0, k1);
     k0 += 0x9E3779B9u;
     k1 += 0xBB67AE85u;
   }
-  float2 out[2];
+  w[0] = c[0]; w[1] = c[1]; w[2] = c[2]; w[3] = c[3];
+}
+// a(u, v) (g1 + i g2) from one word; raw hardware transcendentals (v_log = log2, v_exp = 2^x, v_sqrt, v_sin / v_cos in revolutions):
+// arguments are normal floats in range by construction (u1 in (0, 1), f2 + u0^2 > 0)
+__device__ __forceinline__ float2 spectrum_sample(uint32_t word, int uu, int m, float fv, float du, float u0sq, float amp_scale) {
+  const float fu = du * (float)(uu < m / 2 ? uu : uu - m);
+  const float f2 = fu * fu + fv * fv;
+  const float amp = f2 == 0.f ? 0.f : amp_scale * __builtin_amdgcn_exp2f((-11.0f / 12.0f) * __builtin_amdgcn_logf(f2 + u0sq));
+  const float u1 = ((float)(word & 0xffffu) + 0.5f) * (1.0f / 65536.0f);
+  const float u2 = (float)(word >> 16) * (1.0f / 65536.0f);
+  const float rad = amp * __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));   // sqrt(-2 ln u1)
+  return make_float2(rad * __builtin_amdgcn_cosf(u2), rad * __builtin_amdgcn_sinf(u2));
+}
+__host__ __device__ inline int spectrum_lane_width(int N) { return (N % 64 != 0 && N % 60 == 0) ? 60 : 64; }
+
+#ifdef AOG_MAIN_TU
+// full (q N)^2 spectrum for the hipFFT route (pupils the pruned passes do not cover, and the equivalence test): one thread per Philox call
+__global__ void k_spectrum_fill(float2* __restrict__ spec, int m, int q, int first_local, int env_base, unsigned long long seed,
+                                const uint32_t* __restrict__ gen, float du, float u0sq, float amp_scale) {
+  const int N = m / q, LW = spectrum_lane_width(N), R = (N + LW - 1) / LW, RG = (R + 3) / 4;
+  const size_t calls_per_line = (size_t)q * LW * RG;
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  if (tid >= calls_per_line * m) return;
+  const int v = (int)(tid / calls_per_line);
+  const size_t rem = tid - (size_t)v * calls_per_line;
+  const int rg = (int)(rem / ((size_t)q * LW)), rem2 = (int)(rem - (size_t)rg * q * LW), lane_a = rem2 / q, bg = rem2 - lane_a * q;
+  float2* line = spec + ((size_t)b * m + v) * m;
+  // Half-plane form (see k_screen_rows): lines v > m/2 stay zero, lines 0 < v < m/2 carry sqrt(2) x the amplitude
+  const bool zero_line = 2 * v > m;
+  uint32_t w[4] = {0, 0, 0, 0};
+  if (!zero_line)
+    spectrum_words((size_t)v * m + (size_t)q * (lane_a + LW * 4 * rg) + bg, gen[first_local + b] + 1u, (uint32_t)(env_base + first_local + b), seed, w);
+  const float line_scale = (v == 0 || 2 * v == m) ? 1.f : 1.41421356237f;
+  const float fv = du * (float)v;
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const size_t idx = 2 * pair + h;
-    const int v = (int)(idx / m), u = (int)(idx - (size_t)v * m);
-    const double fu = du * (double)(u < m / 2 ? u : u - m), fv = du * (double)(v < m / 2 ? v : v - m);
-    const double f2 = fu * fu + fv * fv;
-    // 0.0229 r0^(-5/3) ((f^2 + u0^2)/(2 pi)^2)^(-11/6) (2 pi)^2 / du^2, zero at the origin; amp_scale holds the constants
-    const float a = f2 < 1e-18 ? 0.f : line_scale * (float)(amp_scale * pow(f2 + u0sq, -11.0 / 12.0));
-    const float u1 = ((float)c[2 * h] + 0.5f) * (1.0f / 4294967296.0f);
-    const float u2 = ((float)c[2 * h + 1] + 0.5f) * (1.0f / 4294967296.0f);
-    const float r = a * sqrtf(-2.0f * __logf(u1));
-    float sn, cs;
-    __sincosf(6.2831853071795865f * u2, &sn, &cs);
-    out[h] = make_float2(r * cs, r * sn);
+  for (int j = 0; j < 4; ++j) {
+    const int a = lane_a + LW * (4 * rg + j);
+    if (a >= N) continue;
+    const int uu = q * a + bg;
+    float2 o = make_float2(0.f, 0.f);
+    if (!zero_line) {
+      o = spectrum_sample(w[j], uu, m, fv, du, u0sq, amp_scale);
+      o.x *= line_scale;
+      o.y *= line_scale;
+    }
+    line[uu] = o;
   }
-  reinterpret_cast<float4*>(spec + (size_t)b * m * m)[pair] = make_float4(out[0].x, out[0].y, out[1].x, out[1].y);
 }
 
 // after a synthesis launch: the envs it served have drawn one more screen
@@ -2494,7 +2514,7 @@ struct ScreenSynthArgs {
   float du, u0sq, amp_scale, crop_scale;
 };
 
-// the shared transform: `load(bb_global, r)` supplies sample (a = lane + 64 r, b = bb_global) already multiplied by (-1)^a;
+// the shared transform: `load(bb_global, x)` supplies the samples x[r] = (a = lane + LW r, b = bb_global), r < R, already multiplied by (-1)^a;
 // on return acc[p] (p < R) holds out[(p + R * lane) - N/2 ... i.e. output index i = p + R * lane of the centred crop.
 template <int R, int LW, class Load>
 __device__ __forceinline__ void pruned_line(Load&& load, int q, int N, float* __restrict__ lbuf, cf32 (&acc)[R]) {
@@ -2528,8 +2548,7 @@ __device__ __forceinline__ void pruned_line(Load&& load, int q, int N, float* __
       constexpr int bb = decltype(bc)::v;
       if (bb < BC) {
         cf32 x[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) x[r] = load(b0 + bb, r, IC<(bb & 1)>{});   // b0 is a multiple of BC: parity of b = parity of bb when q > 1
+        load(b0 + bb, x);   // the R samples a = lane + LW r of column group b0 + bb
         dft_reg<R>(x);
 #pragma unroll
         for (int p = 0; p < R; ++p) {
@@ -2627,39 +2646,22 @@ __global__ __launch_bounds__(256, 2) void k_screen_rows(ScreenSynthArgs p) {
   // (-1)^a, a = lane + LW r (LW is even), times the half-plane weight of this line
   const float sign = ((lane & 1) ? -1.f : 1.f) * ((v == 0 || 2 * v == m) ? 1.f : 1.41421356237f);
   const uint32_t generation = p.gen[p.first_local + b] + 1u;
-  cf32 pending[R];   // second sample of the Philox pair drawn for (a, b even): consumed as (a, b + 1)
-  auto load = [&](int bg, int r, auto oddc) -> cf32 {
-    // samples come in Philox pairs (u even, u + 1): b even draws, b odd uses the second half
-    const int a = min(lane, LW - 1) + LW * r;   // (idle lanes compute a duplicate that is never stored)
-    const int u = q * a + bg;
-    if constexpr (decltype(oddc)::v == 1) return pending[r];   // (only reached with q > 1: q = 1 has the single b = 0)
-    const size_t idx = (size_t)v * m + (u & ~1);
-    const size_t pair = idx >> 1;
-    uint32_t c[4] = {(uint32_t)pair, (uint32_t)(pair >> 32) ^ (generation * 0x9E3779B9u), (uint32_t)(p.env_base + p.first_local + b), 0x5C4EE7u};
-    uint32_t k0 = (uint32_t)p.seed, k1 = (uint32_t)(p.seed >> 32);
-#pragma unroll
-    for (int rr = 0; rr < 10; ++rr) {
-      philox_round(c, k0, k1);
-      k0 += 0x9E3779B9u;
-      k1 += 0xBB67AE85u;
-    }
-    cf32 o[2];
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      const int uu = (u & ~1) + hh;
-      const float fu = p.du * (float)(uu < m / 2 ? uu : uu - m);
-      const float f2 = fu * fu + fv * fv;
-      // raw hardware transcendentals (v_log = log2, v_exp = 2^x, v_sqrt, v_sin / v_cos in revolutions): arguments are normal
-      // floats in range by construction (u1 in (0, 1), f2 + u0^2 > 0), the library forms' special-case handling is dead weight
-      const float amp = f2 == 0.f ? 0.f : p.amp_scale * __builtin_amdgcn_exp2f((-11.0f / 12.0f) * __builtin_amdgcn_logf(f2 + p.u0sq));
-      const float u1 = ((float)c[2 * hh] + 0.5f) * (1.0f / 4294967296.0f);
-      const float u2 = ((float)c[2 * hh + 1] + 0.5f) * (1.0f / 4294967296.0f);
-      const float rad = sign * amp * __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));   // sqrt(-2 ln u1)
-      o[hh] = cf32{rad * __builtin_amdgcn_cosf(u2), rad * __builtin_amdgcn_sinf(u2)};
-    }
-    if (q == 1) return o[u & 1];   // no oversampling: one sample per call (the pair partner belongs to the next a)
-    pending[r] = o[1];
-    return o[0];
+  const uint32_t env_global = (uint32_t)(p.env_base + p.first_local + b);
+  const int a0 = min(lane, LW - 1);   // (idle lanes compute a duplicate that is never stored)
+  auto load = [&](int bg, cf32 (&x)[R]) {
+    // one Philox call per four samples of this lane (see spectrum_words)
+    static_for<(R + 3) / 4>([&](auto gc) {
+      constexpr int rg = decltype(gc)::v;
+      uint32_t w[4];
+      spectrum_words((size_t)v * m + (size_t)q * (a0 + LW * 4 * rg) + bg, generation, env_global, p.seed, w);
+      static_for<4>([&](auto jc) {
+        constexpr int r = 4 * rg + decltype(jc)::v;
+        if constexpr (r < R) {
+          const float2 o = spectrum_sample(w[decltype(jc)::v], q * (a0 + LW * r) + bg, m, fv, p.du, p.u0sq, p.amp_scale);
+          x[r] = cf32{sign * o.x, sign * o.y};
+        }
+      });
+    });
   };
   cf32 acc[R];
   pruned_line<R, LW>(load, q, N, lds_syn + (size_t)wave * 64 * 65, acc);
@@ -2684,11 +2686,14 @@ __global__ __launch_bounds__(64 * kColsWaves) void k_screen_cols(ScreenSynthArgs
   const float sign = (lane & 1) ? -1.f : 1.f;
   const int lines = m / 2 + 1;
   const float2* src = p.T + (size_t)b * lines * N + ix;
-  auto load = [&](int bg, int r, auto) -> cf32 {
-    const int vv = q * (min(lane, LW - 1) + LW * r) + bg;
-    if (vv >= lines) return cf32{0.f, 0.f};   // the conjugate half plane is folded into the lines below m/2 (see k_screen_rows)
-    const float2 t = src[(size_t)vv * N];
-    return cf32{sign * t.x, sign * t.y};
+  auto load = [&](int bg, cf32 (&x)[R]) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int vv = q * (min(lane, LW - 1) + LW * r) + bg;
+      float2 t = make_float2(0.f, 0.f);   // the conjugate half plane is folded into the lines below m/2 (see k_screen_rows)
+      if (vv < lines) t = src[(size_t)vv * N];
+      x[r] = cf32{sign * t.x, sign * t.y};
+    }
   };
   cf32 acc[R];
   pruned_line<R, LW>(load, q, N, lds_syn + (size_t)wave * 64 * 65, acc);
