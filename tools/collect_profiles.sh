@@ -23,6 +23,9 @@ for c in 3 4 5; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_c$c -- python3 $R/bench.py --config $c --no-cpu-baseline --no-parity > $OUT/${TAG}_prof_c$c.log 2>&1
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_k4 -- python3 $R/tools/k4_loop.py > $OUT/${TAG}_prof_k4.log 2>&1
+python3 $R/tools/sh_loop2.py 1024 256 64 single > $OUT/${TAG}_sh_loop.log 2>&1
+python3 $R/tools/k4_loop.py > $OUT/${TAG}_k4_loop.log 2>&1
+python3 $R/tools/dyn_loop.py 1024 200 > $OUT/${TAG}_dyn_loop.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_sh -- python3 $R/tools/sh_loop2.py 1024 256 64 single > $OUT/${TAG}_prof_sh.log 2>&1
 python3 $R/tools/single_env_latency.py > $OUT/${TAG}_single.log 2>&1
 fi
@@ -42,7 +45,8 @@ python3 tools/summarize_prof.py --stats gpurun_out/${TAG}_prof_c2 --pmc gpurun_o
   python3 tools/summarize_stats.py gpurun_out/${TAG}_prof_k4 "K4 batched focal fields (aog_focal_images, B=1024, N=256)" "rocprofv3 --kernel-trace --stats -- python3 tools/k4_loop.py"
   echo '```'; grep aog_focal_images gpurun_out/${TAG}_prof_k4.log; echo '```'; echo
   python3 tools/summarize_stats.py gpurun_out/${TAG}_prof_sh "Shack-Hartmann loop (SH_step + step, B=1024, N=256, complex64 transforms)" "rocprofv3 --kernel-trace --stats -- python3 tools/sh_loop2.py 1024 256 64 single"
-  echo '```'; grep "per SH_step" gpurun_out/${TAG}_prof_sh.log; echo '```'; echo
+  echo "Un-profiled runs of the same loops (the profiler's per-launch overhead inflates the loop times above):"; echo
+  echo '```'; grep -h "per SH_step" gpurun_out/${TAG}_sh_loop.log; grep -h aog_focal_images gpurun_out/${TAG}_k4_loop.log; grep -h "us per step" gpurun_out/${TAG}_dyn_loop.log; echo '```'; echo
   echo "## single-env drop-in latency (tools/single_env_latency.py)"; echo; echo '```'; cat gpurun_out/${TAG}_single.log | grep AOEnv; echo '```'
 } > profiles/${TAG}_next_rows.md
 echo done
