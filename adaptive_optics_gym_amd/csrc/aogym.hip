@@ -105,6 +105,14 @@ void launch_fast(aog_env* e, hipStream_t s) {
 
 }  // namespace
 
+namespace {
+// zero `n_words` 32-bit words at p on stream s with a kernel of the library (see k_zero_words for why not hipMemsetAsync)
+void zero_words(void* p, size_t n_words, hipStream_t s) {
+  const unsigned blocks = (unsigned)std::min<size_t>((n_words + 255) / 256, 4096);
+  if (n_words) hipLaunchKernelGGL(aog::k_zero_words, dim3(blocks), dim3(256), 0, s, static_cast<uint32_t*>(p), n_words);
+}
+}  // namespace
+
 namespace aog_host {
 template <int A_PAD>
 static void launch_phase_t(aog_env* e, hipStream_t s, const _Float16* act16, float* out_tile) {
@@ -300,7 +308,7 @@ int evolve_layer(aog_env* e, hipStream_t s) {
     const size_t lds = ext_split_lds(e);
     auto kern = aog::k_extrude16_split<aog::kExtKs>;
     if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, e->device)) return rc;
-    HIP_TRY(hipMemsetAsync(e->ext_bar, 0, sizeof(unsigned) * round_up(e->n_ext_groups, 4), s));
+    zero_words(e->ext_bar, (size_t)round_up(e->n_ext_groups, 4), s);
     p.origin = e->origin;
     const int groups8 = round_up(e->n_ext_groups, 8);
     hipLaunchKernelGGL(kern, dim3(groups8 * aog::kExtParts), dim3(256 * aog::kExtKs), lds, s, p, e->B, e->ext_perm, e->ext_bar, e->dev_status,
@@ -1072,10 +1080,10 @@ int aog_upload_sh(aog_env* e, const aog_sh_tables* t) {
       tw[2 * j + 1] = (float)sin(2.0 * M_PI * j / L);
     }
     for (int cg = 0; cg < L / BC; ++cg)
-      for (int k2 = 0; k2 < 64; ++k2)
+      for (int i = 0; i < 64; ++i)             // register i = bb RL + r of layout A: ky = lane + 64 r, kx = cg BC + bb (k_sh_cols)
         for (int lane = 0; lane < 64; ++lane) {
-          const int pp = lane / BC, bb = lane % BC;
-          const size_t src = ((size_t)(pp + RL * k2) * L + (size_t)cg * BC + bb) * 2, dst = (((size_t)cg * 64 + k2) * 64 + lane) * 2;
+          const int bb = i / RL, r = i % RL;
+          const size_t src = ((size_t)(lane + 64 * r) * L + (size_t)cg * BC + bb) * 2, dst = (((size_t)cg * 64 + i) * 64 + lane) * 2;
           tfq[dst] = (float)t->transfer[src];
           tfq[dst + 1] = (float)t->transfer[src + 1];
         }
@@ -1160,7 +1168,7 @@ int aog_sh_image(aog_env* e, double* image_dev, void* stream) {
       fa.env_base = (size_t)e->cfg.env_id_base;
       fa.seed = e->rng_seed;
       fa.call = e->sh_calls;
-      HIP_TRY(hipMemsetAsync(e->sh_sums, 0, sizeof(double) * (size_t)e->B * e->sh_n_sub * 3, s));
+      zero_words(e->sh_sums, (size_t)e->B * e->sh_n_sub * 3 * 2, s);
     }
     e->sh_sums_ready = fused;
     auto run = [&](auto rlc) -> int {
@@ -1501,7 +1509,7 @@ int aog_focal_images(aog_env* e, int first, int count, float* field_dev, void* s
   aog_host::launch_phase(e, s, e->act16, e->focal_phase);
   for (int done = 0; done < count; done += e->focal_chunk) {
     const int nb = std::min(e->focal_chunk, count - done);
-    HIP_TRY(hipMemsetAsync(e->focal_Eb, 0, sizeof(float) * 2 * N2 * nb, s));
+    zero_words(e->focal_Eb, (size_t)2 * N2 * nb, s);
     hipLaunchKernelGGL(aog::k_focal_E_batched, dim3((e->n_ap + 255) / 256, nb), dim3(256), 0, s, e->focal_phase, e->ap_index,
                        reinterpret_cast<float2*>(e->focal_Eb), first + done, e->n_ap, e->n_ptiles, (int)N2);
     // T[b] = m1 (nf x N) . E[b] (N x N);   F[b] = T[b] (nf x N) . m2 (N x nf)

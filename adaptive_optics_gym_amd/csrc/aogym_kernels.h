@@ -2214,6 +2214,13 @@ __global__ void k_spectrum_fill(float2* __restrict__ spec, int m, int q, int fir
   }
 }
 
+// Zero-fill on the caller's stream as a kernel of our own.  hipMemsetAsync on the per-step path went through the runtime's blit path,
+// and in some processes (it varied from one process to the next on the same box) every dependent kernel behind it then started
+// ~5 ms late: the Shack-Hartmann loop ran at 5.00 instead of 2.0 ms per iteration.
+__global__ void k_zero_words(uint32_t* __restrict__ p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+
 // after a synthesis launch: the envs it served have drawn one more screen
 __global__ void k_bump_generation(uint32_t* __restrict__ gen, int count) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2824,16 +2831,16 @@ __device__ __forceinline__ double sh_noisy_value(double lam, size_t ge, int y, i
 // The 2-D route (zero-padded 2N x 2N field -> forward FFT -> x transfer function -> inverse FFT -> crop N x N) moves four full passes over
 // the padded array per transform (rocFFT: 46 of the 76 ms of a config-5 iteration).  Three quarters of the forward input are zeros and
 // three quarters of the inverse output are dropped, so the same arithmetic runs as three passes over HALF-size intermediates:
-//   rows    field[iy][ix < N]  -> forward transform over x (length L = 2N, upper half of the input zero)  -> F1T[kx][iy]      (iy < N)
-//   columns F1T[kx][iy < N]    -> forward over y, x transfer[ky][kx], inverse over y, keep y < N          -> GT[kx][y]
-//   rows    GT[kx][y]          -> inverse over kx, keep x < N, |.|^2 x scale                              -> image[y][x]     (float64)
+//   rows    field[iy][ix < N]  -> forward transform over x (length L = 2N, upper half of the input zero)  -> F1T (kx, iy < N), tiled
+//   columns F1T                -> forward over y, x transfer[ky][kx], inverse over y, keep y < N          -> GT (kx, y < N), tiled
+//   rows    GT                 -> inverse over kx, keep x < N, |.|^2 x scale                              -> image[y][x]     (float64)
 // One wave transforms BC = 64 / RL lines of length L = 64 RL at a time (RL = 4, 8, 16), entirely in registers + one private LDS plane:
 //   layout A: lane l holds elements l + 64 r (r < RL) of each of its BC lines             (contiguous in memory: coalesced rows)
 //   layout B: lane (p, bb) = p BC + bb holds elements p + RL k2 (k2 < 64) of line bb
 //   A -> B:  radix-RL over r in registers, twiddle W_L^{l p}, LDS transpose, 64-point transform in registers
 //   B -> A:  64-point transform, LDS transpose, twiddle, radix-RL
 // so a forward / inverse pair with the transfer function in between (the column pass) never leaves the registers, and the transposition
-// between the passes happens in the store / load patterns (64-byte pieces).  Twiddles come from a table computed in float64 on the host.
+// between the passes happens in the layout of the intermediates: 512-byte tiles of RL columns x 64 / RL rows (see k_sh_rows_fwd).  Twiddles come from a table computed in float64 on the host.
 template <int RL, bool FWD>
 __device__ __forceinline__ void sh_fft_a2b(cf32 (&v)[64], float* __restrict__ lbuf, const float2* __restrict__ tw) {
   constexpr int BC = 64 / RL, LG = log2_c(RL);
@@ -2938,12 +2945,18 @@ __global__ __launch_bounds__(64 * kShFftWaves, 2) void k_sh_rows_fwd(const float
     else v[i] = cf32{0.f, 0.f};   // the zero padding
   });
   sh_fft_a2b<RL, true>(v, lds_shfft + (size_t)wave * 64 * 65, tw);
-  const int pp = lane / BC, bb = lane - pp * BC;
-  float2* dst = F1T + ((size_t)blockIdx.y * L + pp) * N + iy0 + bb;
-  static_for<64>([&](auto kc) { constexpr int k2 = decltype(kc)::v; dst[(size_t)(RL * k2) * N] = make_float2(v[k2].x, v[k2].y); });
+  // tiled intermediate: element (row y, column kx) lives in tile (kx / RL, y / BC) at [kx % RL][y % BC] — 64 elements = 512 bytes = exactly
+  // what the 64 lanes (p, bb) of layout B hold for one k2: one fully coalesced store per k2 (a plain [kx][y] array took eight 64-byte
+  // pieces in eight different rows per instruction: 512 scattered pieces per wave, and the pass fell to 40 % of its speed whenever the
+  // allocation came back from the driver in small physical fragments)
+  float2* dst = F1T + (size_t)blockIdx.y * L * N + (size_t)(iy0 / BC) * 64 + lane;
+  static_for<64>([&](auto kc) { constexpr int k2 = decltype(kc)::v; dst[(size_t)k2 * (N / BC) * 64] = make_float2(v[k2].x, v[k2].y); });
 }
-// columns: forward over y, transfer function, inverse over y:  F1T [B][L][N] -> GT [B][L][N]
-// tfq: [L / BC][64][64] = transfer[ky = p + RL k2][kx = group BC + bb] for lane (p, bb), register k2 (arranged on the host)
+// columns: forward over y, transfer function, inverse over y:  F1T -> GT (both tiled, see k_sh_rows_fwd)
+// The wave takes its BC columns in layout B of the y transform (lane (p, bb) holds rows y = p + RL k2 of column bb: for one k2 that is a
+// whole 512-byte tile of the intermediates, or 64 / RL aligned pieces of neighbouring tiles), runs B -> A forward, multiplies by the
+// transfer function in layout A, runs A -> B inverse and stores rows y < N the same way.
+// tfq: [L / BC][64][64] = transfer[ky = lane + 64 r][kx = group BC + bb] for register bb RL + r (arranged on the host)
 template <int RL>
 __global__ __launch_bounds__(64 * kShFftWaves, 2) void k_sh_cols(const float2* __restrict__ F1T, float2* __restrict__ GT, const float2* __restrict__ tfq,
                                                                  const float2* __restrict__ tw) {
@@ -2952,28 +2965,33 @@ __global__ __launch_bounds__(64 * kShFftWaves, 2) void k_sh_cols(const float2* _
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int cg = blockIdx.x * kShFftWaves + wave;
   if (cg * BC >= L) return;
-  const float2* src = F1T + ((size_t)blockIdx.y * L + (size_t)cg * BC) * N + lane;
+  const int pp = lane / BC, bb = lane - pp * BC;
+  const int kx = cg * BC + bb;
+  // element (y = pp + RL k2, kx): tile (kx / RL, y / BC) at [kx % RL][y % BC]
+  auto tiled = [&](int k2) {
+    const int y = pp + RL * k2;
+    return ((size_t)(kx / RL) * (N / BC) + y / BC) * 64 + (kx % RL) * BC + (y % BC);
+  };
+  const float2* src = F1T + (size_t)blockIdx.y * L * N;
   cf32 v[64];
-  static_for<64>([&](auto ic) {
-    constexpr int i = decltype(ic)::v;
-    constexpr int bb = i / RL, r = i % RL;
-    if constexpr (r < RL / 2) { const float2 t = src[(size_t)bb * N + 64 * r]; v[i] = cf32{t.x, t.y}; }
-    else v[i] = cf32{0.f, 0.f};
-  });
-  float* lbuf = lds_shfft + (size_t)wave * 64 * 65;
-  sh_fft_a2b<RL, true>(v, lbuf, tw);
-  const float2* tf = tfq + (size_t)cg * 64 * 64 + lane;
   static_for<64>([&](auto kc) {
     constexpr int k2 = decltype(kc)::v;
-    const float2 t = tf[k2 * 64];
-    v[k2] = cmul(v[k2], cf32{t.x, t.y});
+    if constexpr (k2 < N / RL) { const float2 t = src[tiled(k2)]; v[k2] = cf32{t.x, t.y}; }
+    else v[k2] = cf32{0.f, 0.f};   // the zero padding (y >= N)
   });
-  sh_fft_b2a<RL, false>(v, lbuf, tw);
-  float2* dst = GT + ((size_t)blockIdx.y * L + (size_t)cg * BC) * N + lane;
+  float* lbuf = lds_shfft + (size_t)wave * 64 * 65;
+  sh_fft_b2a<RL, true>(v, lbuf, tw);
+  const float2* tf = tfq + (size_t)cg * 64 * 64 + lane;
   static_for<64>([&](auto ic) {
     constexpr int i = decltype(ic)::v;
-    constexpr int bb = i / RL, r = i % RL;
-    if constexpr (r < RL / 2) dst[(size_t)bb * N + 64 * r] = make_float2(v[i].x, v[i].y);
+    const float2 t = tf[i * 64];
+    v[i] = cmul(v[i], cf32{t.x, t.y});
+  });
+  sh_fft_a2b<RL, false>(v, lbuf, tw);
+  float2* dst = GT + (size_t)blockIdx.y * L * N;
+  static_for<64>([&](auto kc) {
+    constexpr int k2 = decltype(kc)::v;
+    if constexpr (k2 < N / RL) dst[tiled(k2)] = make_float2(v[k2].x, v[k2].y);
   });
 }
 // rows, inverse over kx, intensity:  GT [B][L][N] -> image [B][N][N] float64
@@ -3003,10 +3021,9 @@ __global__ __launch_bounds__(64 * kShFftWaves, 2) void k_sh_rows_inv(const float
   if constexpr (FUSED) {
     for (int i = lane; i < 3 * f.n_sub; i += 64) tab[i] = 0.0;
   }
-  const int pp = lane / BC, bb = lane - pp * BC;
-  const float2* src = GT + ((size_t)blockIdx.y * L + pp) * N + y0 + bb;
+  const float2* src = GT + (size_t)blockIdx.y * L * N + (size_t)(y0 / BC) * 64 + lane;   // tiled layout: one coalesced 512-byte load per k2
   cf32 v[64];
-  static_for<64>([&](auto kc) { constexpr int k2 = decltype(kc)::v; const float2 t = src[(size_t)(RL * k2) * N]; v[k2] = cf32{t.x, t.y}; });
+  static_for<64>([&](auto kc) { constexpr int k2 = decltype(kc)::v; const float2 t = src[(size_t)k2 * (N / BC) * 64]; v[k2] = cf32{t.x, t.y}; });
   sh_fft_b2a<RL, false>(v, lds_shfft + (size_t)wave * 64 * 65, tw);
   if constexpr (!FUSED) {
     double* dst = image + ((size_t)blockIdx.y * N + y0) * N + lane;

