@@ -1063,7 +1063,9 @@ int aog_upload_sh(aog_env* e, const aog_sh_tables* t) {
   if ((rc = dev_alloc(e, &e->sh_act16, (size_t)e->n_etiles * e->A_pad * 32 * 2)) != AOG_OK) return rc;
   if ((rc = dev_alloc(e, &e->sh_phase, (size_t)e->n_etiles * e->n_ptiles * 1024)) != AOG_OK) return rc;
   e->sh_double = t->fft_double != 0;
-  e->sh_pruned = (!e->sh_double && (N == 128 || N == 256 || N == 512)) ? 2 * N / 64 : 0;
+  // pruned passes: lines of 2N = LW RL with LW = 64 (N = 128, 256, 512) or 60 (N = 240: the reference's pupil, and 480)
+  const int sh_lw = aog::spectrum_lane_width(N);
+  e->sh_pruned = (!e->sh_double && (N == 128 || N == 256 || N == 512 || N == 240 || N == 480)) ? 2 * N / sh_lw : 0;
   if (e->sh_pruned) {
     // pruned three-pass propagation (k_sh_rows_fwd / k_sh_cols / k_sh_rows_inv): F1T [B][2N][N] in sh_pad; compact field [B][N][N] and
     // GT [B][2N][N] in sh_in (zeroed once: pixels outside the aperture are never written)
@@ -1074,7 +1076,7 @@ int aog_upload_sh(aog_env* e, const aog_sh_tables* t) {
     if ((rc = dev_alloc(e, &p2, (size_t)e->B * N2 * 3 * sizeof(float) * 2, true)) != AOG_OK) return rc;
     e->sh_pad = p1;
     e->sh_in = p2;
-    std::vector<float> tw((size_t)L * 2), tfq((size_t)L * L * 2);
+    std::vector<float> tw((size_t)L * 2), tfq((size_t)(L / BC) * 64 * 64 * 2);
     for (int j = 0; j < L; ++j) {
       tw[2 * j] = (float)cos(2.0 * M_PI * j / L);
       tw[2 * j + 1] = (float)sin(2.0 * M_PI * j / L);
@@ -1083,7 +1085,9 @@ int aog_upload_sh(aog_env* e, const aog_sh_tables* t) {
       for (int i = 0; i < 64; ++i)             // register i = bb RL + r of layout A: ky = lane + 64 r, kx = cg BC + bb (k_sh_cols)
         for (int lane = 0; lane < 64; ++lane) {
           const int bb = i / RL, r = i % RL;
-          const size_t src = ((size_t)(lane + 64 * r) * L + (size_t)cg * BC + bb) * 2, dst = (((size_t)cg * 64 + i) * 64 + lane) * 2;
+          const size_t dst = (((size_t)cg * 64 + i) * 64 + lane) * 2;
+          if (lane >= sh_lw) { tfq[dst] = 0.f; tfq[dst + 1] = 0.f; continue; }   // (lanes LW .. 63 hold nothing)
+          const size_t src = ((size_t)(lane + sh_lw * r) * L + (size_t)cg * BC + bb) * 2;
           tfq[dst] = (float)t->transfer[src];
           tfq[dst + 1] = (float)t->transfer[src + 1];
         }
@@ -1171,21 +1175,23 @@ int aog_sh_image(aog_env* e, double* image_dev, void* stream) {
       zero_words(e->sh_sums, (size_t)e->B * e->sh_n_sub * 3 * 2, s);
     }
     e->sh_sums_ready = fused;
-    auto run = [&](auto rlc) -> int {
-      constexpr int RL = decltype(rlc)::v, BC = 64 / RL;
-      const int L = 64 * RL;
-      if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_sh_rows_fwd<RL>), lds, e->device)) return rc;
-      if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_sh_cols<RL>), lds, e->device)) return rc;
-      if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_sh_rows_inv<RL, false>), lds, e->device)) return rc;
-      if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_sh_rows_inv<RL, true>), lds_fused, e->device)) return rc;
+    auto run = [&](auto rlc, auto lwc) -> int {
+      constexpr int RL = decltype(rlc)::v, LW = decltype(lwc)::v, BC = 64 / RL;
+      const int L = LW * RL;
+      if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_sh_rows_fwd<RL, LW>), lds, e->device)) return rc;
+      if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_sh_cols<RL, LW>), lds, e->device)) return rc;
+      if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_sh_rows_inv<RL, LW, false>), lds, e->device)) return rc;
+      if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_sh_rows_inv<RL, LW, true>), lds_fused, e->device)) return rc;
       const dim3 g_rows((N / BC + aog::kShFftWaves - 1) / aog::kShFftWaves, e->B), g_cols((L / BC + aog::kShFftWaves - 1) / aog::kShFftWaves, e->B);
-      hipLaunchKernelGGL(aog::k_sh_rows_fwd<RL>, g_rows, dim3(64 * aog::kShFftWaves), lds, s, field, F1T, tw);
-      hipLaunchKernelGGL(aog::k_sh_cols<RL>, g_cols, dim3(64 * aog::kShFftWaves), lds, s, F1T, GT, reinterpret_cast<const float2*>(e->sh_tfq), tw);
-      if (fused) hipLaunchKernelGGL((aog::k_sh_rows_inv<RL, true>), g_rows, dim3(64 * aog::kShFftWaves), lds_fused, s, GT, e->sh_image, tw, scale, fa);
-      else hipLaunchKernelGGL((aog::k_sh_rows_inv<RL, false>), g_rows, dim3(64 * aog::kShFftWaves), lds, s, GT, e->sh_image, tw, scale, fa);
+      hipLaunchKernelGGL((aog::k_sh_rows_fwd<RL, LW>), g_rows, dim3(64 * aog::kShFftWaves), lds, s, field, F1T, tw);
+      hipLaunchKernelGGL((aog::k_sh_cols<RL, LW>), g_cols, dim3(64 * aog::kShFftWaves), lds, s, F1T, GT, reinterpret_cast<const float2*>(e->sh_tfq), tw);
+      if (fused) hipLaunchKernelGGL((aog::k_sh_rows_inv<RL, LW, true>), g_rows, dim3(64 * aog::kShFftWaves), lds_fused, s, GT, e->sh_image, tw, scale, fa);
+      else hipLaunchKernelGGL((aog::k_sh_rows_inv<RL, LW, false>), g_rows, dim3(64 * aog::kShFftWaves), lds, s, GT, e->sh_image, tw, scale, fa);
       return AOG_OK;
     };
-    int rcp = e->sh_pruned == 4 ? run(aog::IC<4>{}) : e->sh_pruned == 8 ? run(aog::IC<8>{}) : run(aog::IC<16>{});
+    int rcp;
+    if (N % 64 == 0) rcp = e->sh_pruned == 4 ? run(aog::IC<4>{}, aog::IC<64>{}) : e->sh_pruned == 8 ? run(aog::IC<8>{}, aog::IC<64>{}) : run(aog::IC<16>{}, aog::IC<64>{});
+    else rcp = e->sh_pruned == 8 ? run(aog::IC<8>{}, aog::IC<60>{}) : run(aog::IC<16>{}, aog::IC<60>{});
     if (rcp) return rcp;
   } else if (e->sh_double) {
     e->sh_sums_ready = false;

@@ -2769,8 +2769,8 @@ __global__ void k_sh_intensity(const CT* __restrict__ f, double* __restrict__ im
 // hcipy.util.large_poisson with the handle's Philox stream: exact inversion for lambda < 12, above it the rounded normal approximation with the
 // Cornish-Fisher skewness term (hcipy switches to a plain rounded normal at 1e6; the sensor's controller reads flux-weighted centroids
 // of ~1e3 pixels per lenslet: mean, variance and third moment of every pixel's count are those of the Poisson law).
-// Stream layout: pixel (global env ge, row y, column x) takes word (x >> 6) & 3 of the Philox call with counter
-// ((ge N + y) 64 + (x & 63), group (x >> 6) >> 2, call) — and, when it is bright, the same word of a second call for the Box-Muller angle.  The
+// Stream layout: with x = l + LW r (LW = 64, or 60 for pupils of 60 R pixels: spectrum_lane_width), pixel (global env ge, row y, column x)
+// takes word r & 3 of the Philox call with counter ((ge N + y) 64 + l, group r >> 2, call) — and, when it is bright, the same word of a second call for the Box-Muller angle.  The
 // lane of the fused row pass that holds columns x, x + 64, x + 128, ... therefore draws ONE call per four of its pixels (a call per pixel
 // with a float64 exp and a float64 inversion was ~350 instructions per pixel: two thirds of that pass); results do not depend on the
 // batch split, nor on which kernel draws them.
@@ -2814,8 +2814,9 @@ __device__ __forceinline__ double sh_poisson_large(double lam, uint32_t word_r, 
 }
 // one pixel on its own (k_sh_noise: pupils the pruned passes do not cover, caller-visible images)
 __device__ __forceinline__ double sh_noisy_value(double lam, size_t ge, int y, int x, int N, unsigned long long seed, uint32_t call) {
-  const size_t line = (ge * N + y) * 64 + (x & 63);
-  const uint32_t r = (uint32_t)x >> 6;
+  const int lw = spectrum_lane_width(N);
+  const size_t line = (ge * N + y) * 64 + (x % lw);
+  const uint32_t r = (uint32_t)(x / lw);
   uint32_t w[4];
   sh_noise_words(line, r >> 2, false, seed, call, w);
   const bool small = lam < kShPoissonSwitch;
@@ -2840,7 +2841,9 @@ __device__ __forceinline__ double sh_noisy_value(double lam, size_t ge, int y, i
 //   B -> A:  64-point transform, LDS transpose, twiddle, radix-RL
 // so a forward / inverse pair with the transfer function in between (the column pass) never leaves the registers, and the transposition
 // between the passes happens in the layout of the intermediates: 512-byte tiles of RL columns x 64 / RL rows (see k_sh_rows_fwd).  Twiddles come from a table computed in float64 on the host.
-template <int RL, bool FWD>
+// LW = 64 (lines of 64 RL) or 60 (lines of 60 RL: the reference's 240-pixel pupil): lanes LW .. 63 idle in the per-element phases and the
+// in-register transform has LW points (mixed radix 2 x 2 x 3 x 5 for 60)
+template <int RL, bool FWD, int LW = 64>
 __device__ __forceinline__ void sh_fft_a2b(cf32 (&v)[64], float* __restrict__ lbuf, const float2* __restrict__ tw) {
   constexpr int BC = 64 / RL, LG = log2_c(RL);
   const int lane = threadIdx.x & 63;
@@ -2853,7 +2856,7 @@ __device__ __forceinline__ void sh_fft_a2b(cf32 (&v)[64], float* __restrict__ lb
   cf32 wl[RL];
   static_for<RL>([&](auto pc) {
     constexpr int pp = decltype(pc)::v;
-    if constexpr (pp > 0) { const float2 t = tw[lane * pp]; wl[pp] = cf32{t.x, t.y}; }
+    if constexpr (pp > 0) { const float2 t = tw[min(lane, LW - 1) * pp]; wl[pp] = cf32{t.x, t.y}; }
   });
   static_for<BC>([&](auto bc) {
     constexpr int bb = decltype(bc)::v;
@@ -2866,25 +2869,33 @@ __device__ __forceinline__ void sh_fft_a2b(cf32 (&v)[64], float* __restrict__ lb
       v[bb * RL + pp] = pp == 0 ? y : cmul(y, wl[pp]);
     });
   });
-  float zx[64];
-  static_for<64>([&](auto ic) { constexpr int i = decltype(ic)::v; constexpr int bb = i / RL, pp = i % RL; lbuf[(pp * BC + bb) * 65 + lane] = v[i].x; });
+  float zx[LW];
+  const bool owner = LW == 64 || lane < LW;
+  static_for<64>([&](auto ic) { constexpr int i = decltype(ic)::v; constexpr int bb = i / RL, pp = i % RL; if (owner) lbuf[(pp * BC + bb) * 65 + lane] = v[i].x; });
   fence();
-  static_for<64>([&](auto tc) { zx[decltype(tc)::v] = lbuf[lane * 65 + decltype(tc)::v]; });
+  static_for<LW>([&](auto tc) { zx[decltype(tc)::v] = lbuf[lane * 65 + decltype(tc)::v]; });
   fence();
-  static_for<64>([&](auto ic) { constexpr int i = decltype(ic)::v; constexpr int bb = i / RL, pp = i % RL; lbuf[(pp * BC + bb) * 65 + lane] = v[i].y; });
+  static_for<64>([&](auto ic) { constexpr int i = decltype(ic)::v; constexpr int bb = i / RL, pp = i % RL; if (owner) lbuf[(pp * BC + bb) * 65 + lane] = v[i].y; });
   fence();
-  static_for<64>([&](auto tc) { constexpr int t = decltype(tc)::v; v[t] = cf32{zx[t], lbuf[lane * 65 + t]}; });
+  static_for<LW>([&](auto tc) { constexpr int t = decltype(tc)::v; v[t] = cf32{zx[t], lbuf[lane * 65 + t]}; });
   fence();
-  dft_reg<64>(v);
   cf32 o[64];
-  static_for<64>([&](auto ic) { constexpr int i = decltype(ic)::v; o[i] = v[bitrev_c(i, 6)]; });
+  if constexpr (LW == 64) {
+    dft_reg<64>(v);
+    static_for<64>([&](auto ic) { constexpr int i = decltype(ic)::v; o[i] = v[bitrev_c(i, 6)]; });
+  } else {
+    cf32 zin[LW], zout[LW];
+    static_for<LW>([&](auto ic) { zin[decltype(ic)::v] = v[decltype(ic)::v]; });
+    dft_rec<LW, LW, 0, 1>(zin, zout, [](int e) { return cf32{kTw60.c[e][0], kTw60.c[e][1]}; });
+    static_for<64>([&](auto ic) { constexpr int i = decltype(ic)::v; if constexpr (i < LW) o[i] = zout[i]; else o[i] = cf32{0.f, 0.f}; });
+  }
   static_for<64>([&](auto ic) {
     constexpr int i = decltype(ic)::v;
     if constexpr (FWD) v[i] = cf32{o[i].y, o[i].x};
     else v[i] = o[i];
   });
 }
-template <int RL, bool FWD>
+template <int RL, bool FWD, int LW = 64>
 __device__ __forceinline__ void sh_fft_b2a(cf32 (&v)[64], float* __restrict__ lbuf, const float2* __restrict__ tw) {
   constexpr int BC = 64 / RL, LG = log2_c(RL);
   const int lane = threadIdx.x & 63;
@@ -2893,20 +2904,28 @@ __device__ __forceinline__ void sh_fft_b2a(cf32 (&v)[64], float* __restrict__ lb
     __builtin_amdgcn_wave_barrier();
   };
   if constexpr (FWD) static_for<64>([&](auto ic) { constexpr int i = decltype(ic)::v; const float t = v[i].x; v[i].x = v[i].y; v[i].y = t; });
-  dft_reg<64>(v);   // T[l] = v[bitrev(l)]
+  cf32 T[LW];   // the LW-point transform of this lane's sequence, natural order
+  if constexpr (LW == 64) {
+    dft_reg<64>(v);
+    static_for<64>([&](auto lc) { constexpr int l = decltype(lc)::v; T[l] = v[bitrev_c(l, 6)]; });
+  } else {
+    cf32 zin[LW];
+    static_for<LW>([&](auto ic) { zin[decltype(ic)::v] = v[decltype(ic)::v]; });
+    dft_rec<LW, LW, 0, 1>(zin, T, [](int e) { return cf32{kTw60.c[e][0], kTw60.c[e][1]}; });
+  }
   float ux[64];
-  static_for<64>([&](auto lc) { constexpr int l = decltype(lc)::v; lbuf[l * 65 + lane] = v[bitrev_c(l, 6)].x; });
+  static_for<LW>([&](auto lc) { constexpr int l = decltype(lc)::v; lbuf[l * 65 + lane] = T[l].x; });
   fence();
-  static_for<64>([&](auto sc) { ux[decltype(sc)::v] = lbuf[lane * 65 + decltype(sc)::v]; });
+  static_for<64>([&](auto sc) { ux[decltype(sc)::v] = lbuf[min(lane, LW - 1) * 65 + decltype(sc)::v]; });
   fence();
-  static_for<64>([&](auto lc) { constexpr int l = decltype(lc)::v; lbuf[l * 65 + lane] = v[bitrev_c(l, 6)].y; });
+  static_for<LW>([&](auto lc) { constexpr int l = decltype(lc)::v; lbuf[l * 65 + lane] = T[l].y; });
   fence();
-  static_for<64>([&](auto sc) { constexpr int ss = decltype(sc)::v; v[ss] = cf32{ux[ss], lbuf[lane * 65 + ss]}; });   // v[p BC + bb]
+  static_for<64>([&](auto sc) { constexpr int ss = decltype(sc)::v; v[ss] = cf32{ux[ss], lbuf[min(lane, LW - 1) * 65 + ss]}; });   // v[p BC + bb]
   fence();
   cf32 wl[RL];
   static_for<RL>([&](auto pc) {
     constexpr int pp = decltype(pc)::v;
-    if constexpr (pp > 0) { const float2 t = tw[lane * pp]; wl[pp] = cf32{t.x, t.y}; }
+    if constexpr (pp > 0) { const float2 t = tw[min(lane, LW - 1) * pp]; wl[pp] = cf32{t.x, t.y}; }
   });
   cf32 o[64];
   static_for<BC>([&](auto bc) {
@@ -2928,39 +2947,39 @@ __device__ __forceinline__ void sh_fft_b2a(cf32 (&v)[64], float* __restrict__ lb
 
 constexpr int kShFftWaves = 4;
 // rows, forward over x:  field [B][N][N] -> F1T [B][L][N]
-template <int RL>
+template <int RL, int LW>
 __global__ __launch_bounds__(64 * kShFftWaves, 2) void k_sh_rows_fwd(const float2* __restrict__ field, float2* __restrict__ F1T, const float2* __restrict__ tw) {
   extern __shared__ float lds_shfft[];
-  constexpr int L = 64 * RL, N = L / 2, BC = 64 / RL;
+  constexpr int L = LW * RL, N = L / 2, BC = 64 / RL;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int iy0 = (blockIdx.x * kShFftWaves + wave) * BC;
   if (iy0 >= N) return;
-  const float2* src = field + ((size_t)blockIdx.y * N + iy0) * N + lane;
+  const float2* src = field + ((size_t)blockIdx.y * N + iy0) * N + min(lane, LW - 1);
   cf32 v[64];
   static_for<64>([&](auto ic) {
     constexpr int i = decltype(ic)::v;
     constexpr int bb = i / RL, r = i % RL;
-    if constexpr (r < RL / 2) { const float2 t = src[(size_t)bb * N + 64 * r]; v[i] = cf32{t.x, t.y}; }
+    if constexpr (r < RL / 2) { const float2 t = src[(size_t)bb * N + LW * r]; v[i] = cf32{t.x, t.y}; }
     else v[i] = cf32{0.f, 0.f};   // the zero padding
   });
-  sh_fft_a2b<RL, true>(v, lds_shfft + (size_t)wave * 64 * 65, tw);
+  sh_fft_a2b<RL, true, LW>(v, lds_shfft + (size_t)wave * 64 * 65, tw);
   // tiled intermediate: element (row y, column kx) lives in tile (kx / RL, y / BC) at [kx % RL][y % BC] — 64 elements = 512 bytes = exactly
   // what the 64 lanes (p, bb) of layout B hold for one k2: one fully coalesced store per k2 (a plain [kx][y] array took eight 64-byte
   // pieces in eight different rows per instruction: 512 scattered pieces per wave, and the pass fell to 40 % of its speed whenever the
   // allocation came back from the driver in small physical fragments)
   float2* dst = F1T + (size_t)blockIdx.y * L * N + (size_t)(iy0 / BC) * 64 + lane;
-  static_for<64>([&](auto kc) { constexpr int k2 = decltype(kc)::v; dst[(size_t)k2 * (N / BC) * 64] = make_float2(v[k2].x, v[k2].y); });
+  static_for<LW>([&](auto kc) { constexpr int k2 = decltype(kc)::v; dst[(size_t)k2 * (N / BC) * 64] = make_float2(v[k2].x, v[k2].y); });
 }
 // columns: forward over y, transfer function, inverse over y:  F1T -> GT (both tiled, see k_sh_rows_fwd)
 // The wave takes its BC columns in layout B of the y transform (lane (p, bb) holds rows y = p + RL k2 of column bb: for one k2 that is a
 // whole 512-byte tile of the intermediates, or 64 / RL aligned pieces of neighbouring tiles), runs B -> A forward, multiplies by the
 // transfer function in layout A, runs A -> B inverse and stores rows y < N the same way.
 // tfq: [L / BC][64][64] = transfer[ky = lane + 64 r][kx = group BC + bb] for register bb RL + r (arranged on the host)
-template <int RL>
+template <int RL, int LW>
 __global__ __launch_bounds__(64 * kShFftWaves, 2) void k_sh_cols(const float2* __restrict__ F1T, float2* __restrict__ GT, const float2* __restrict__ tfq,
                                                                  const float2* __restrict__ tw) {
   extern __shared__ float lds_shfft[];
-  constexpr int L = 64 * RL, N = L / 2, BC = 64 / RL;
+  constexpr int L = LW * RL, N = L / 2, BC = 64 / RL;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int cg = blockIdx.x * kShFftWaves + wave;
   if (cg * BC >= L) return;
@@ -2979,14 +2998,14 @@ __global__ __launch_bounds__(64 * kShFftWaves, 2) void k_sh_cols(const float2* _
     else v[k2] = cf32{0.f, 0.f};   // the zero padding (y >= N)
   });
   float* lbuf = lds_shfft + (size_t)wave * 64 * 65;
-  sh_fft_b2a<RL, true>(v, lbuf, tw);
+  sh_fft_b2a<RL, true, LW>(v, lbuf, tw);
   const float2* tf = tfq + (size_t)cg * 64 * 64 + lane;
   static_for<64>([&](auto ic) {
     constexpr int i = decltype(ic)::v;
     const float2 t = tf[i * 64];
     v[i] = cmul(v[i], cf32{t.x, t.y});
   });
-  sh_fft_a2b<RL, false>(v, lbuf, tw);
+  sh_fft_a2b<RL, false, LW>(v, lbuf, tw);
   float2* dst = GT + (size_t)blockIdx.y * L * N;
   static_for<64>([&](auto kc) {
     constexpr int k2 = decltype(kc)::v;
@@ -3008,11 +3027,11 @@ struct ShFuseArgs {
   unsigned long long seed;
   uint32_t call;
 };
-template <int RL, bool FUSED>
+template <int RL, int LW, bool FUSED>
 __global__ __launch_bounds__(64 * kShFftWaves, 2) void k_sh_rows_inv(const float2* __restrict__ GT, double* __restrict__ image, const float2* __restrict__ tw,
                                                                      double scale, ShFuseArgs f) {
   extern __shared__ float lds_shfft[];
-  constexpr int L = 64 * RL, N = L / 2, BC = 64 / RL;
+  constexpr int L = LW * RL, N = L / 2, BC = 64 / RL;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int y0 = (blockIdx.x * kShFftWaves + wave) * BC;
   if (y0 >= N) return;
@@ -3022,20 +3041,27 @@ __global__ __launch_bounds__(64 * kShFftWaves, 2) void k_sh_rows_inv(const float
   }
   const float2* src = GT + (size_t)blockIdx.y * L * N + (size_t)(y0 / BC) * 64 + lane;   // tiled layout: one coalesced 512-byte load per k2
   cf32 v[64];
-  static_for<64>([&](auto kc) { constexpr int k2 = decltype(kc)::v; const float2 t = src[(size_t)k2 * (N / BC) * 64]; v[k2] = cf32{t.x, t.y}; });
-  sh_fft_b2a<RL, false>(v, lds_shfft + (size_t)wave * 64 * 65, tw);
+  static_for<64>([&](auto kc) {
+    constexpr int k2 = decltype(kc)::v;
+    if constexpr (k2 < LW) { const float2 t = src[(size_t)k2 * (N / BC) * 64]; v[k2] = cf32{t.x, t.y}; }
+    else v[k2] = cf32{0.f, 0.f};
+  });
+  sh_fft_b2a<RL, false, LW>(v, lds_shfft + (size_t)wave * 64 * 65, tw);
+  const bool owner = LW == 64 || lane < LW;   // lanes LW .. 63 hold no pixels
   if constexpr (!FUSED) {
     double* dst = image + ((size_t)blockIdx.y * N + y0) * N + lane;
     static_for<64>([&](auto ic) {
       constexpr int i = decltype(ic)::v;
       constexpr int b2 = i / RL, r = i % RL;
-      if constexpr (r < RL / 2) dst[(size_t)b2 * N + 64 * r] = ((double)v[i].x * (double)v[i].x + (double)v[i].y * (double)v[i].y) * scale;
+      if constexpr (r < RL / 2) {
+        if (owner) dst[(size_t)b2 * N + LW * r] = ((double)v[i].x * (double)v[i].x + (double)v[i].y * (double)v[i].y) * scale;
+      }
     });
   } else {
     constexpr int NX = RL / 2;
     int cur[NX];
     double s0[NX], sy[NX], xd[NX];
-    static_for<NX>([&](auto rc) { constexpr int r = decltype(rc)::v; cur[r] = -1; s0[r] = 0.0; sy[r] = 0.0; xd[r] = f.x_det[lane + 64 * r]; });
+    static_for<NX>([&](auto rc) { constexpr int r = decltype(rc)::v; cur[r] = -1; s0[r] = 0.0; sy[r] = 0.0; xd[r] = f.x_det[min(lane, LW - 1) + LW * r]; });
     auto flush = [&](int slot, double a0, double ay, double xdet) {
       if (slot >= 0) {
         atomicAdd(&tab[3 * slot], a0);
@@ -3047,18 +3073,18 @@ __global__ __launch_bounds__(64 * kShFftWaves, 2) void k_sh_rows_inv(const float
       constexpr int b2 = decltype(bc)::v;
       const int y = y0 + b2;
       const double yd = f.x_det[y];
-      const size_t line = ((f.env_base + blockIdx.y) * N + y) * 64 + lane;
+      const size_t line = ((f.env_base + blockIdx.y) * N + y) * 64 + lane;   // (= x % LW: sh_noisy_value's key)
       uint32_t wa[4] = {0, 0, 0, 0}, wb[4] = {0, 0, 0, 0};
       bool have_b = false;
       static_for<NX>([&](auto rc) {
         constexpr int r = decltype(rc)::v, i = b2 * RL + r;
-        const int x = lane + 64 * r;
+        const int x = min(lane, LW - 1) + LW * r;
         if constexpr ((r & 3) == 0) {
           sh_noise_words(line, r >> 2, false, f.seed, f.call, wa);
           have_b = false;
         }
         const double lam = ((double)v[i].x * (double)v[i].x + (double)v[i].y * (double)v[i].y) * scale;
-        const int slot = f.sub_slot[y * N + x];
+        const int slot = owner ? f.sub_slot[y * N + x] : -1;
         if (slot != cur[r]) {
           flush(cur[r], s0[r], sy[r], xd[r]);
           cur[r] = slot; s0[r] = 0.0; sy[r] = 0.0;

@@ -193,7 +193,7 @@ int aog_upload_sh(aog_env* env, const aog_sh_tables* sh);
 
 /* camera.integrate(shwfs(magnifier(deformable_mirror_shack(layer(wf_wfs)))), delta_t); camera.read_out() (AO_env.py:263-274):
  * the noise-free Shack-Hartmann image of every env, [B][N*N] float64.  image_dev may be NULL = "the next call is aog_sh_update(NULL)":
- * the image stays internal, and for pupils of 128 / 256 / 512 pixels (complex64) it is not even written — photon noise and the
+ * the image stays internal, and for pupils of 128 / 240 / 256 / 480 / 512 pixels (complex64) it is not even written — photon noise and the
  * estimator's per-lenslet sums are taken inside the last propagation pass and handed to that aog_sh_update. */
 int aog_sh_image(aog_env* env, double* image_dev, void* stream);
 
