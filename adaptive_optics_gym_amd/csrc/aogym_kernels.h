@@ -824,9 +824,9 @@ __global__ __launch_bounds__(512, 2) void k_fused_tab(const f16x8* __restrict__ 
 // Phase-only form of the contraction: u = psi + Mt a for every (pixel, env), written back in the psi_tile layout.  Used by the
 // Shack-Hartmann chain, whose mirror (deformable_mirror_shack) carries its own actuators.  One wave per (env tile, pixel tile).
 // FIELD: instead of the phases, the Shack-Hartmann chain's input field E = amplitude e^{2 pi i u} x micro-lens phase goes out, complex64 at
-// (iy, ix) of the env's image (compact N x N for the pruned passes): a lane holds four consecutive aperture pixels per register group and the
-// two half-waves of an env adjacent groups, so a store instruction writes 64 contiguous bytes per env (k_sh_field re-read the phases
-// through the tile layout and wrote 8 bytes per thread: 0.23 ms per 1024 envs at N = 256 on top of this kernel's 0.11).
+// (iy, ix) of the env's image (compact N x N for the pruned passes), through a [32 envs][32 pixels] tile in LDS so that a store instruction
+// writes 256 contiguous bytes per env (k_sh_field re-read the phases through the tile layout and wrote 8 bytes per thread: 0.23 ms per
+// 1024 envs at N = 256 on top of this kernel's 0.11).
 struct PhaseFieldArgs {
   const int32_t* ap_yx;      // [n_ap] iy << 16 | ix
   const float2* mla32;       // [N*N] micro-lens phase factor, complex64
@@ -843,6 +843,8 @@ __global__ __launch_bounds__(256) void k_phase_mfma(const f16x8* __restrict__ mo
   const int lane = threadIdx.x & 63;
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int etile = blockIdx.y;
+  __shared__ float2 field_lds[FIELD ? 4 * 32 * 33 : 1];
+  float2* field_tile = field_lds + (FIELD ? (threadIdx.x >> 6) * 32 * 33 : 0);
   if (t >= n_ptiles || etile >= n_etiles) return;
   const f16x8* asrc = act16 + ((size_t)etile * NSTEP * 2) * 64 + lane;
   const f16x8* ms = modes16 + ((size_t)t * NSTEP * 2) * 64 + lane;
@@ -855,7 +857,7 @@ __global__ __launch_bounds__(256) void k_phase_mfma(const f16x8* __restrict__ mo
     d = __builtin_amdgcn_mfma_f32_32x32x16_f16(ml, bh, d, 0, 0, 0);
   }
   const size_t base = (((size_t)etile * n_ptiles + t) * 4) * 64 + lane;
-  const int env = etile * 32 + (lane & 31), h = lane >> 5;
+  [[maybe_unused]] const int h = lane >> 5;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const f32x4 p = psi_tile[base + g * 64];
@@ -865,33 +867,32 @@ __global__ __launch_bounds__(256) void k_phase_mfma(const f16x8* __restrict__ mo
     if constexpr (!FIELD) {
       out_tile[base + g * 64] = o;
     } else {
-      const int pix0 = t * 32 + 8 * g + 4 * h;   // aperture pixels of accumulator registers 4 g .. 4 g + 3 (see k_fused_tab)
-      if (env < fa.B && pix0 < fa.n_ap) {
-        const int yx0 = fa.ap_yx[pix0], yx3 = fa.ap_yx[min(pix0 + 3, fa.n_ap - 1)];
-        float2 e4[4];
-        int yxs[4];
+      // this lane's four field values of register group g -> the wave's [32 envs][32 pixels] tile in LDS; written out below with the
+      // lanes along the PIXELS of an env (256 contiguous bytes per env and instruction: 32-byte pieces straight from the accumulator
+      // layout ran the kernel at 1.2 TB/s)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const bool row4 = yx3 == yx0 + 3;   // the four pixels lie side by side in one image row (nearly always)
-          yxs[r] = row4 ? yx0 + r : fa.ap_yx[min(pix0 + r, fa.n_ap - 1)];
-          const int iy = yxs[r] >> 16, ix = yxs[r] & 0xffff;
-          float sn, cs;
-          sincospif(2.0f * (o[r] - rintf(o[r])), &sn, &cs);
-          const float2 m = fa.mla32[iy * fa.N + ix];
-          e4[r] = make_float2(fa.amplitude * (cs * m.x - sn * m.y), fa.amplitude * (cs * m.y + sn * m.x));
-        }
-        float2* dst0 = fa.field + (size_t)env * fa.env_stride + (size_t)(yx0 >> 16) * fa.row_stride + (yx0 & 0xffff);
-        if (yx3 == yx0 + 3 && pix0 + 3 < fa.n_ap) {   // (8-byte aligned 16-byte stores: global memory takes them)
-          typedef float f32x4s __attribute__((ext_vector_type(4), aligned(8)));
-          const f32x4s lo = {e4[0].x, e4[0].y, e4[1].x, e4[1].y}, hi = {e4[2].x, e4[2].y, e4[3].x, e4[3].y};
-          reinterpret_cast<f32x4s*>(dst0)[0] = lo;
-          reinterpret_cast<f32x4s*>(dst0)[1] = hi;
-        } else {
+      for (int r = 0; r < 4; ++r) {
+        const int q = 8 * g + 4 * h + r;
+        const int pix = min(t * 32 + q, fa.n_ap - 1);
+        const int yx = fa.ap_yx[pix], iy = yx >> 16, ix = yx & 0xffff;
+        float sn, cs;
+        sincospif(2.0f * (o[r] - rintf(o[r])), &sn, &cs);
+        const float2 m = fa.mla32[iy * fa.N + ix];
+        field_tile[(lane & 31) * 33 + q] = make_float2(fa.amplitude * (cs * m.x - sn * m.y), fa.amplitude * (cs * m.y + sn * m.x));
+      }
+    }
+  }
+  if constexpr (FIELD) {
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the tile is private to the wave
+    __builtin_amdgcn_wave_barrier();
+    const int q = lane & 31, pix = t * 32 + q;
+    if (pix < fa.n_ap) {
+      const int yx = fa.ap_yx[pix];
+      float2* dst = fa.field + (size_t)(yx >> 16) * fa.row_stride + (yx & 0xffff);
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (pix0 + r < fa.n_ap)
-              fa.field[(size_t)env * fa.env_stride + (size_t)(yxs[r] >> 16) * fa.row_stride + (yxs[r] & 0xffff)] = e4[r];
-        }
+      for (int j = 0; j < 16; ++j) {
+        const int el = 2 * j + (lane >> 5), env_j = etile * 32 + el;
+        if (env_j < fa.B) dst[(size_t)env_j * fa.env_stride] = field_tile[el * 33 + q];
       }
     }
   }
