@@ -2857,7 +2857,7 @@ __device__ __forceinline__ void sh_fft_a2b(cf32 (&v)[64], float* __restrict__ lb
   cf32 wl[RL];
   static_for<RL>([&](auto pc) {
     constexpr int pp = decltype(pc)::v;
-    if constexpr (pp > 0) { const float2 t = tw[min(lane, LW - 1) * pp]; wl[pp] = cf32{t.x, t.y}; }
+    if constexpr (pp > 0 && RL < 16) { const float2 t = tw[min(lane, LW - 1) * pp]; wl[pp] = cf32{t.x, t.y}; }
   });
   static_for<BC>([&](auto bc) {
     constexpr int bb = decltype(bc)::v;
@@ -2867,7 +2867,11 @@ __device__ __forceinline__ void sh_fft_a2b(cf32 (&v)[64], float* __restrict__ lb
     static_for<RL>([&](auto pc) {
       constexpr int pp = decltype(pc)::v;
       const cf32 y = x[bitrev_c(pp, LG)];
-      v[bb * RL + pp] = pp == 0 ? y : cmul(y, wl[pp]);
+      if constexpr (pp == 0) v[bb * RL] = y;
+      else if constexpr (RL >= 16) {   // (radix 16: the twiddles are re-read from the L1 per line instead of 32 registers held throughout)
+        const float2 t = tw[min(lane, LW - 1) * pp];
+        v[bb * RL + pp] = cmul(y, cf32{t.x, t.y});
+      } else v[bb * RL + pp] = cmul(y, wl[pp]);
     });
   });
   float zx[LW];
@@ -2926,7 +2930,7 @@ __device__ __forceinline__ void sh_fft_b2a(cf32 (&v)[64], float* __restrict__ lb
   cf32 wl[RL];
   static_for<RL>([&](auto pc) {
     constexpr int pp = decltype(pc)::v;
-    if constexpr (pp > 0) { const float2 t = tw[min(lane, LW - 1) * pp]; wl[pp] = cf32{t.x, t.y}; }
+    if constexpr (pp > 0 && RL < 16) { const float2 t = tw[min(lane, LW - 1) * pp]; wl[pp] = cf32{t.x, t.y}; }
   });
   cf32 o[64];
   static_for<BC>([&](auto bc) {
@@ -2934,7 +2938,11 @@ __device__ __forceinline__ void sh_fft_b2a(cf32 (&v)[64], float* __restrict__ lb
     cf32 x[RL];
     static_for<RL>([&](auto pc) {
       constexpr int pp = decltype(pc)::v;
-      x[pp] = pp == 0 ? v[bb] : cmul(v[pp * BC + bb], wl[pp]);
+      if constexpr (pp == 0) x[0] = v[bb];
+      else if constexpr (RL >= 16) {
+        const float2 t = tw[min(lane, LW - 1) * pp];
+        x[pp] = cmul(v[pp * BC + bb], cf32{t.x, t.y});
+      } else x[pp] = cmul(v[pp * BC + bb], wl[pp]);
     });
     dft_reg<RL>(x);
     static_for<RL>([&](auto rc) { constexpr int r = decltype(rc)::v; o[bb * RL + r] = x[bitrev_c(r, LG)]; });
@@ -2987,7 +2995,9 @@ __global__ __launch_bounds__(64 * kShFftWaves, 2) void k_sh_cols(const float2* _
   const int pp = lane / BC, bb = lane - pp * BC;
   const int kx = cg * BC + bb;
   // element (y = pp + RL k2, kx): tile (kx / RL, y / BC) at [kx % RL][y % BC]
-  auto tiled = [&](int k2) {
+  const size_t tile0 = ((size_t)(kx / RL) * (N / BC) + pp / BC) * 64 + (kx % RL) * BC + (pp % BC);   // the element of k2 = 0
+  auto tiled = [&](int k2) -> size_t {
+    if constexpr (RL % BC == 0) return tile0 + (size_t)k2 * (RL / BC) * 64;   // RL k2 rows further: RL / BC whole tiles (one base, fixed strides)
     const int y = pp + RL * k2;
     return ((size_t)(kx / RL) * (N / BC) + y / BC) * 64 + (kx % RL) * BC + (y % BC);
   };
@@ -3001,10 +3011,13 @@ __global__ __launch_bounds__(64 * kShFftWaves, 2) void k_sh_cols(const float2* _
   float* lbuf = lds_shfft + (size_t)wave * 64 * 65;
   sh_fft_b2a<RL, true, LW>(v, lbuf, tw);
   const float2* tf = tfq + (size_t)cg * 64 * 64 + lane;
-  static_for<64>([&](auto ic) {
-    constexpr int i = decltype(ic)::v;
-    const float2 t = tf[i * 64];
-    v[i] = cmul(v[i], cf32{t.x, t.y});
+  // (eight table loads at a time: left alone the compiler requests all 64 first — 128 more live registers, spills at RL = 16)
+  static_for<8>([&](auto gc) {
+    constexpr int g8 = decltype(gc)::v;
+    float2 t8[8];
+    static_for<8>([&](auto jc) { t8[decltype(jc)::v] = tf[(8 * g8 + decltype(jc)::v) * 64]; });
+    static_for<8>([&](auto jc) { constexpr int i = 8 * g8 + decltype(jc)::v; v[i] = cmul(v[i], cf32{t8[decltype(jc)::v].x, t8[decltype(jc)::v].y}); });
+    __builtin_amdgcn_sched_barrier(0);
   });
   sh_fft_a2b<RL, false, LW>(v, lbuf, tw);
   float2* dst = GT + (size_t)blockIdx.y * L * N;
