@@ -352,6 +352,8 @@ def main():
     start_episode()
     if spinup:
         run(spinup)
+        fence()      # the first burst of launches after a LONG asynchronous run costs the host ~55 us per step instead of ~30 (measured:
+                     # tools/spin_probe.py) — the W warm-up steps take that, not the K timed ones
     run(args.warmup)
     fence()
     env.profile_read()                       # discard the warm-up's samples; timing stays on
