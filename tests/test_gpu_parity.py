@@ -863,7 +863,7 @@ def test_shack_hartmann_chain_matches_oracle(N):
     env32.close()
 
 
-@pytest.mark.parametrize("N,B", [(128, 5), (240, 3), (256, 3), (512, 2)])
+@pytest.mark.parametrize("N,B", [(128, 5), (240, 3), (256, 3), (480, 2), (512, 2)])
 def test_shack_hartmann_pruned_propagation_matches_2d_transforms(N, B):
     """Pupils of 128 / 256 / 512 pixels (lines of 64 R) and of 240 pixels (the reference's size: lines of 60 R) run the Fresnel propagation as three pruned passes of in-register length-2N transforms (complex64:
     k_sh_rows_fwd, k_sh_cols, k_sh_rows_inv) instead of zero-padded 2-D FFTs; the detector image must equal the complex128 2-D route
