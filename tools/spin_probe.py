@@ -1,5 +1,6 @@
+"""Host vs wall time per step of a 20-step burst right after a long asynchronous run (why bench.py fences after its spin-up).  Developer probe."""
 import os, sys, time
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from adaptive_optics_gym_amd import BatchedAOEnv
 B = 1024
