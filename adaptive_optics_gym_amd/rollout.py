@@ -12,7 +12,9 @@ What is mirrored, and what is not:
   all-gather of episode returns per episode (``sharding.EpisodeReturnGatherer``).
 
 The learners (SAC/DDPG/PPO updates, replay buffer) are outside the env hot path and are not rebuilt; the tensors returned
-here are what they consume.
+here are what they consume: ``replay_transitions`` flattens them into the five arrays the reference's replay buffer stores and
+samples (``replay_buffer.py:21-34``: state, action, reward, next_state, done), ``sharding.gather_transitions`` all-gathers them over
+the ranks for a central buffer.
 """
 from __future__ import annotations
 
@@ -192,3 +194,21 @@ def rollout(env, actor, episodes: int = 1, cov_var: float = 0.5, gatherer=None, 
     out["ep_returns"] = torch.stack(ep_returns)
     out["avg_ep_rew"] = float(out["ep_returns"].mean().item()) / T
     return out
+
+
+def replay_transitions(batch, episode_major: bool = False):
+    """The hand-off to a replay buffer (``ReplayBuffer.add(state, action, reward, next_state, done)``, ``replay_buffer.py:21-25``;
+    ``sample_batch`` stacks exactly these five, ``:30-34``): the ``[T*E, B, ...]`` tensors of ``rollout`` as five flat device tensors
+    ``(state [n, o*o], action [n, A], reward [n], next_state [n, o*o], done [n])``, n = T*E*B.
+
+    Order: step-major (all envs of step 0, then step 1, ...) — the order a vectorised collector appends in; ``episode_major=True``
+    gives env-major order instead (each env's steps contiguous: the order ``B`` single-env collectors appending one after the other
+    would produce, ``algorithm.py:238-276``).  Views where the layout allows, no host copy."""
+    keys = ("obs", "act", "rew", "next_obs", "done")
+    out = []
+    for k in keys:
+        t = batch[k]
+        if episode_major:
+            t = t.transpose(0, 1)
+        out.append(t.reshape((t.shape[0] * t.shape[1],) + tuple(t.shape[2:])))
+    return tuple(out)

@@ -97,3 +97,28 @@ class EpisodeReturnGatherer:
         else:
             self.last_global_returns = self.returns.clone()
         return self.last_global_returns
+
+
+def gather_transitions(transitions, distributed: bool, group=None):
+    """Optional exchange for a CENTRAL replay buffer: all-gather the five flat transition tensors of
+    ``rollout.replay_transitions`` over the ranks (one collective per tensor, rank-major order; ~0.3 KB per env-step).  Every rank
+    must contribute the same number of transitions (equal shards: the lock-step episodes guarantee equal step counts).  Identity
+    when not distributed.  bool tensors travel as uint8 (RCCL has no bool type)."""
+    if not distributed:
+        return tuple(transitions)
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    out = []
+    for t in transitions:
+        is_bool = t.dtype == torch.bool
+        send = (t.to(torch.uint8) if is_bool else t).contiguous()
+        stage = send.device.type == "cuda" and dist.get_backend(group) == "gloo"   # single-GPU rehearsals: gloo moves host tensors
+        src = send.cpu() if stage else send
+        recv = torch.empty((world * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+        dist.all_gather_into_tensor(recv, src, group=group)
+        if stage:
+            recv = recv.to(send.device)
+        out.append(recv.to(torch.bool) if is_bool else recv)
+    return tuple(out)

@@ -88,3 +88,48 @@ def test_single_process_gatherer_matches():
     g.add(torch.tensor([1.0, 2.0, 3.0, 4.0]))
     g.add(torch.tensor([1.0, 1.0, 1.0, 1.0]))
     assert g.finish_episode().tolist() == [2.0, 3.0, 4.0, 5.0]
+
+
+def _worker_transitions(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    from adaptive_optics_gym_amd.sharding import gather_transitions
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 6
+    base = rank * n
+    tr = (torch.arange(base, base + n, dtype=torch.float16).reshape(n, 1).repeat(1, 4), torch.full((n, 3), float(rank)),
+          torch.arange(base, base + n, dtype=torch.float32), torch.zeros((n, 4), dtype=torch.float16), torch.arange(n) % 2 == rank)
+    got = gather_transitions(tr, True)
+    if rank == 0:
+        q.put([g.tolist() for g in got] + [[str(g.dtype) for g in got]])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_transition_allgather_world2():
+    """Optional exchange for a central replay buffer: rank-major all-gather of the five transition tensors; dtypes kept."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_transitions, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    state, action, reward, nxt, done, dtypes = got
+    assert reward == [float(i) for i in range(12)]
+    assert [row[0] for row in state] == [float(i) for i in range(12)] and len(state[0]) == 4
+    assert [row[0] for row in action] == [0.0] * 6 + [1.0] * 6
+    assert done == [i % 2 == 0 for i in range(6)] + [i % 2 == 1 for i in range(6)]
+    assert dtypes == ["torch.float16", "torch.float32", "torch.float32", "torch.float16", "torch.bool"]
+    from adaptive_optics_gym_amd.sharding import gather_transitions
+
+    same = gather_transitions((torch.ones(2, 2),), False)
+    assert same[0].shape == (2, 2)

@@ -57,3 +57,29 @@ def test_rollout_layout_and_logged_scalar():
     ep = out["rew"].reshape(E, T, B).sum(1)
     torch.testing.assert_close(out["ep_returns"], ep)
     assert abs(out["avg_ep_rew"] - float(ep.mean()) / T) < 1e-6   # algorithm.py:509-510
+
+
+def test_replay_transitions_match_per_env_collection():
+    """The replay hand-off (replay_buffer.py:21-34): flattened (state, action, reward, next_state, done) of the batched rollout equal
+    what B single-env collectors appending one transition per step would have stored."""
+    from adaptive_optics_gym_amd.rollout import replay_transitions
+
+    torch.manual_seed(5)
+    B, T, E = 3, 4, 2
+    env = FakeEnv(B, 4, 6, T)
+    out = rollout(env, make_actor(4, 6, 16), episodes=E)
+    st, ac, rw, ns, dn = replay_transitions(out)
+    n = T * E * B
+    assert st.shape == (n, 4) and ac.shape == (n, 6) and rw.shape == (n,) and ns.shape == (n, 4) and dn.shape == (n,)
+    # step-major: transition (step i, env b) sits at i * B + b
+    for i in (0, 3, 5):
+        for b in range(B):
+            k = i * B + b
+            assert torch.equal(st[k], out["obs"][i, b]) and torch.equal(ac[k], out["act"][i, b]) and torch.equal(ns[k], out["next_obs"][i, b])
+            assert rw[k] == out["rew"][i, b] and dn[k] == out["done"][i, b]
+    # env-major: each env's trajectory contiguous, in time order (what a single-env loop appends, algorithm.py:238-276)
+    st2, ac2, rw2, ns2, dn2 = replay_transitions(out, episode_major=True)
+    for b in range(B):
+        torch.testing.assert_close(rw2[b * T * E:(b + 1) * T * E], out["rew"][:, b])
+        assert torch.equal(ns2[b * T * E:(b + 1) * T * E - 1][: T - 1], st2[b * T * E + 1:b * T * E + T])   # next_state of t = state of t + 1
+    assert int(dn.sum()) == E * B
