@@ -10,11 +10,12 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libaogym.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 AOG_REWARD = {"strehl_ratio": 0, "smf_ssim": 1}
 AOG_PRECISION = {"fast": 0, "fp64": 1}
 AOG_KERNEL = {"auto": 0, "valu": 1, "mfma": 2}
+AOG_SCREENS = {"twoband": 0, "hcipy16": 1}
 
 
 class AogConfig(C.Structure):
@@ -75,6 +76,7 @@ SYMBOLS = {
     "aog_set_rng_seed": (C.c_int, [C.c_void_p, C.c_uint64]),
     "aog_get_screens_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "aog_generate_screens": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p]),
+    "aog_set_screen_method": (C.c_int, [C.c_void_p, C.c_int]),
     "aog_upload_sh": (C.c_int, [C.c_void_p, C.POINTER(AogShTables)]),
     "aog_sh_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "aog_sh_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -32,6 +32,9 @@ class BatchedAOEnv:
     seed                seed of the screen generator (global env g uses seed + g for ``screen_source='numpy'``)
     screen_source       'device' (default: hipFFT synthesis inside libaogym, Philox normals) | 'torch' (same algorithm through
                         torch.fft) | 'numpy' (hcipy's draw order on a numpy legacy stream, float64, host)
+    screen_method       'twoband' (default: device synthesis splits the von Karman spectrum into a low band on hcipy's (16 N)^2 grid and a
+                        high band on the (2 N)^2 grid — the same stationary Gaussian field on the pupil to < 1e-4 of its variance at every
+                        lag, 60x fewer spectrum samples) | 'hcipy16' (the literal (16 N)^2 draw); only ``screen_source='device'`` reads it
     screens             optional [B, N, N] achromatic screens to use instead of generating them
     global_env_offset   global id of env 0 of this instance (multi-GPU: ``sharding.shard_range(total, rank, world)[0]``)
     total_envs          size of the global batch this instance is a contiguous slice of (default: offset + num_envs).
@@ -50,7 +53,7 @@ class BatchedAOEnv:
                  timesteps_per_episode=20, flat_mirror_start_per_episode=True, SH_operation=False, *,
                  num_pupil_pixels=240, seed=None, screen_source="device", screen_oversampling=16, screens=None,
                  precision="fast", kernel="auto", pixel_chunks=0, rng=None, verbose=True, params=None,
-                 global_env_offset=0, total_envs=None, sh_fft_precision="single"):
+                 global_env_offset=0, total_envs=None, sh_fft_precision="single", screen_method="twoband"):
         import torch
 
         self._torch = torch
@@ -96,6 +99,9 @@ class BatchedAOEnv:
         self.seed = seed
         self.screen_source = screen_source
         self.screen_oversampling = int(screen_oversampling)
+        if screen_method not in _lib.AOG_SCREENS:
+            raise ValueError("screen_method must be 'twoband' or 'hcipy16'")
+        self.screen_method = screen_method
         self._rng = rng
         self._episode_returns = None
         self._trunc = None
@@ -155,6 +161,7 @@ class BatchedAOEnv:
                               _dptr(keep["sc"], C.c_double), _dptr(keep["m1"], C.c_double), _dptr(keep["m2"], C.c_double),
                               int(t.focal_m1.shape[0]))
         _lib.check(self.lib.aog_upload_tables(self._handle, C.byref(tabs)))
+        _lib.check(self.lib.aog_set_screen_method(self._handle, _lib.AOG_SCREENS[screen_method]))
         self.info = _lib.AogInfo()
         _lib.check(self.lib.aog_get_info(self._handle, C.byref(self.info)))
 

@@ -74,7 +74,11 @@ struct aog_env {
   float* fft_crop = nullptr;     // [fft_batch][N][N]
   float* syn_T = nullptr;        // pruned synthesis: [syn_batch][m][N] complex64 (lines after pass A)
   float* syn_out = nullptr;      // [syn_batch][N][N]
-  int syn_batch = 0, syn_m = 0;
+  int syn_batch = 0, syn_m = 0;     // syn_m: q N of the literal layout, -(q N) of the two-band layout
+  int screen_method = AOG_SCREENS_TWOBAND;
+  float* low_c = nullptr;        // general route of the two-band form: low-band spectrum [fft_batch][KL][2 KL] complex64
+  float* low_T = nullptr;        // and its lines [fft_batch][KL][N] complex64
+  int low_key = 0;
   uint32_t* screen_gen = nullptr;   // [B] screens synthesised so far per env (Philox stream position of k_screen_rows / k_spectrum_fill)
   // focal-image export (optional)
   int n_focal = 0;

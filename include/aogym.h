@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define AOG_ABI_VERSION 13
+#define AOG_ABI_VERSION 14
 
 typedef struct aog_env aog_env;
 
@@ -169,6 +169,17 @@ int aog_get_screens_f64(aog_env* env, double* psi_dev, int first, int count, voi
  * oversampled array (pruned two-pass transform). */
 int aog_generate_screens(aog_env* env, int first, int count, int oversampling, double cn_squared, double outer_scale,
                          double pixel_pitch, void* stream);
+
+/* How aog_generate_screens draws a screen.  Both methods draw the same zero-mean stationary Gaussian field on the N x N pupil up to
+ * max |dC(r)| < 1e-4 C(0) over every lag r of the pupil (tests/test_screen_twoband.py evaluates both covariance functions exactly on
+ * the host in float64), i.e. they are statistically equivalent to hcipy's layer.reset() (AO_env.py:77), not draw-for-draw.
+ *   AOG_SCREENS_TWOBAND (default)  the spectrum samples' variance is split by a smooth radial window into a low band kept on hcipy's
+ *       (oversampling N)^2 frequency grid (non-zero below 2 cycles per pupil diameter: 4 oversampling^2 samples) and a high band drawn
+ *       on the (2 N)^2 grid (period 2 D: its covariance has decayed before the wrap-around lag).  4 N^2 + 4 q^2 samples per screen
+ *       instead of q^2 N^2.  Needs oversampling >= 4 and even, N % 4 == 0; otherwise the literal method is used.
+ *   AOG_SCREENS_HCIPY  the literal (oversampling N)^2 draw described above. */
+enum { AOG_SCREENS_TWOBAND = 0, AOG_SCREENS_HCIPY = 1 };
+int aog_set_screen_method(aog_env* env, int method);
 
 /* Shack-Hartmann baseline controller (AO_env.py:254-290, 396-465).  Tables built on the host by the counterpart of
  * shack_hartmann_init (adaptive_optics_gym_amd/sh_host.py).  HOST pointers, float64. */

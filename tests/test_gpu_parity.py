@@ -747,16 +747,17 @@ def test_dynamic_ring_direct_matches_oracle(N, vel):
     env.close()
 
 
-def test_device_screen_synthesis_statistics():
-    """K8 inside the library (hipFFT + Philox): same variance / structure function as the literal numpy generator and as the
-    discrete integral of the von Karman PSD over the FFT grid; new screens on every call; masked regeneration."""
+@pytest.mark.parametrize("method", ["twoband", "hcipy16"])
+def test_device_screen_synthesis_statistics(method):
+    """K8 inside the library (Philox normals; both synthesis methods): same variance / structure function as the literal numpy generator and
+    as the discrete integral of the von Karman PSD over the FFT grid; new screens on every call; masked regeneration."""
     torch = _torch()
     from adaptive_optics_gym_amd import BatchedAOEnv
     from adaptive_optics_gym_amd.atmosphere_host import cn_squared_from_fried_parameter, screen_numpy, spectral_amplitude
 
     B, N, q = 256, 32, 8
     env = BatchedAOEnv(B, "cuda:0", atm_type="dynamic", atm_vel=1, atm_fried=0.2, act_dim=6, act_type="zernike", obs_dim=2,
-                       num_pupil_pixels=N, seed=5, screen_oversampling=q, screen_source="device", verbose=False)
+                       num_pupil_pixels=N, seed=5, screen_oversampling=q, screen_source="device", screen_method=method, verbose=False)
     dev = env.get_screens().cpu().numpy()
     assert np.isfinite(dev).all()
     cn2 = cn_squared_from_fried_parameter(0.2, 2.2e-6)
@@ -784,12 +785,17 @@ def test_device_screen_synthesis_statistics():
     env.close()
 
 
-@pytest.mark.parametrize("N,q", [(64, 8), (128, 4), (256, 16), (512, 2), (60, 8), (120, 4), (240, 16), (480, 2)])
-def test_pruned_screen_synthesis_matches_full_transform(monkeypatch, N, q):
+@pytest.mark.parametrize("method,N,q", [("hcipy16", 64, 8), ("hcipy16", 128, 4), ("hcipy16", 256, 16), ("hcipy16", 512, 2), ("hcipy16", 60, 8),
+                                        ("hcipy16", 120, 4), ("hcipy16", 240, 16), ("hcipy16", 480, 2),
+                                        ("twoband", 64, 16), ("twoband", 128, 8), ("twoband", 256, 16), ("twoband", 512, 4), ("twoband", 60, 16),
+                                        ("twoband", 120, 8), ("twoband", 240, 16), ("twoband", 480, 16)])
+def test_pruned_screen_synthesis_matches_full_transform(monkeypatch, method, N, q):
     """K8, pupils of 64 R or 60 R pixels (R = 1, 2, 4, 8; 240 is the reference's size): the pruned two-pass synthesis (Philox lines -> length-N transforms in registers/LDS, never the
     (qN)^2 array) gives the same screens as spectrum fill + hipFFT + centred crop on the same Philox stream; only fp32 rounding
     (and the float amplitude law) differs.  Covers 1, 2, 4 and 8 points per lane, one or two b-groups per line, and both the
-    radix-2 64-point and the mixed-radix (2 x 2 x 3 x 5) 60-point in-register transform."""
+    radix-2 64-point and the mixed-radix (2 x 2 x 3 x 5) 60-point in-register transform.  Two-band method: the high band's pruned passes
+    (32 / R lines or columns per wave) against hipFFT on the (2N)^2 grid, and the low band's in-kernel direct sums (twiddles by recurrence)
+    against the one-thread-per-output kernels (every twiddle from an exactly reduced angle)."""
     torch = _torch()
     from adaptive_optics_gym_amd import BatchedAOEnv
 
@@ -799,7 +805,7 @@ def test_pruned_screen_synthesis_matches_full_transform(monkeypatch, N, q):
         else:
             monkeypatch.delenv("AOG_SCREENS_FULLFFT", raising=False)
         env = BatchedAOEnv(3, "cuda:0", atm_type="semi_dynamic", atm_fried=0.15, act_dim=6, act_type="zernike", obs_dim=2,
-                           num_pupil_pixels=N, timesteps_per_episode=5, seed=7, screen_oversampling=q, verbose=False)
+                           num_pupil_pixels=N, timesteps_per_episode=5, seed=7, screen_oversampling=q, screen_method=method, verbose=False)
         env.reset()
         first = np.stack([env.phase_screen(i).cpu().numpy() for i in range(3)])
         env.reset()                                   # semi_dynamic: a new screen per episode
@@ -813,6 +819,37 @@ def test_pruned_screen_synthesis_matches_full_transform(monkeypatch, N, q):
     assert rms > 0 and not np.allclose(f1[0], f1[1]) and not np.allclose(f1[0], f2)
     assert np.abs(p1 - f1).max() < 3e-5 * rms
     assert np.abs(p2 - f2).max() < 3e-5 * rms
+
+
+@pytest.mark.parametrize("method,N", [("twoband", 64), ("twoband", 60), ("twoband", 96), ("hcipy16", 64)])
+def test_device_screens_have_the_literal_covariance(method, N):
+    """Monte-Carlo check of the device output against the EXACT covariance of hcipy's literal method (the cosine sum over its (16 N)^2
+    spectrum, ``atmosphere_host.literal_covariance``; tests/test_screen_twoband.py shows the two-band model's covariance equals it to 2e-5
+    C(0) at every lag): structure function along x, y and the diagonal from 1 pixel to 3/4 of the pupil over 4096 screens (3 sigma of the
+    estimator: ~2 % at short lags, ~7 % at the longest, where a screen contributes about one degree of freedom; the seeds are fixed), and independence of the
+    screens of different envs.  N = 64 / 60: pruned passes (64- and 60-point forms); N = 96: hipFFT route + direct low band."""
+    _torch()
+    from adaptive_optics_gym_amd import BatchedAOEnv
+    from adaptive_optics_gym_amd.atmosphere_host import cn_squared_from_fried_parameter, literal_covariance
+
+    B = 4096
+    env = BatchedAOEnv(B, "cuda:0", atm_type="dynamic", atm_vel=1, atm_fried=0.15, act_dim=6, act_type="zernike", obs_dim=2,
+                       num_pupil_pixels=N, seed=21, screen_source="device", screen_method=method, verbose=False)
+    dev = env.get_screens().cpu().numpy()      # dynamic handle: the full float64 master screens, piston included
+    env.close()
+    assert np.isfinite(dev).all()
+    cn2 = cn_squared_from_fried_parameter(0.15, 2.2e-6)
+    cov = literal_covariance(N, 0.5 / N, 10.0, 16) * cn2
+    c0 = cov[N - 1, N - 1]
+    for r, rtol in ((1, 0.025), (2, 0.025), (4, 0.03), (N // 8, 0.04), (N // 4, 0.06), (N // 2, 0.08), (3 * N // 4, 0.09)):
+        np.testing.assert_allclose(np.mean((dev[:, :, r:] - dev[:, :, :-r]) ** 2), 2 * (c0 - cov[N - 1, N - 1 + r]), rtol=rtol)
+        np.testing.assert_allclose(np.mean((dev[:, r:, :] - dev[:, :-r, :]) ** 2), 2 * (c0 - cov[N - 1 + r, N - 1]), rtol=rtol)
+        np.testing.assert_allclose(np.mean((dev[:, r:, r:] - dev[:, :-r, :-r]) ** 2), 2 * (c0 - cov[N - 1 + r, N - 1 + r]), rtol=rtol)
+        np.testing.assert_allclose(np.mean((dev[:, r:, :-r] - dev[:, :-r, r:]) ** 2), 2 * (c0 - cov[N - 1 + r, N - 1 - r]), rtol=rtol)
+    # screens of different envs are independent: the mean over envs of a product of two envs' centre-pixel differences vanishes
+    tilt = dev[:, N // 2, 3 * N // 4] - dev[:, N // 2, N // 4]
+    assert abs(np.mean(tilt[0::2] * tilt[1::2])) < 4 * tilt.var() / np.sqrt(B / 2)
+    assert abs(np.mean(tilt)) < 4 * tilt.std() / np.sqrt(B)
 
 
 @pytest.mark.parametrize("N", [96, 240])
