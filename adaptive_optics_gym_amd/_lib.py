@@ -16,6 +16,7 @@ AOG_REWARD = {"strehl_ratio": 0, "smf_ssim": 1}
 AOG_PRECISION = {"fast": 0, "fp64": 1}
 AOG_KERNEL = {"auto": 0, "valu": 1, "mfma": 2}
 AOG_SCREENS = {"twoband": 0, "hcipy16": 1}
+AOG_PROF = {"fused": 0, "screen_rows": 1, "screen_cols": 2, "pack": 3, "extrude": 4, "sh_field": 5, "sh_rows_fwd": 6, "sh_cols": 7, "sh_rows_inv": 8}
 
 
 class AogConfig(C.Structure):
@@ -93,9 +94,11 @@ SYMBOLS = {
     "aog_step": (C.c_int, [C.c_void_p] * 9),
     "aog_focal_image": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "aog_focal_images": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "aog_selftest_barrier_timeout": (C.c_int, [C.c_void_p, C.c_void_p]),
     "aog_selftest_sincos": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "aog_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "aog_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "aog_profile_read_kernel": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
 }
 
 _lib = None

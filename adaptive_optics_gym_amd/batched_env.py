@@ -188,10 +188,13 @@ class BatchedAOEnv:
                     r.geometric(0.5, N)
                     r.geometric(0.5, N)
         else:
-            trng = np.random.RandomState(1234 if seed is None else int(seed))
+            base_seed = 1234 if seed is None else int(seed)
+            trng = np.random.RandomState(base_seed)
             wind_u = trng.rand(self.total_envs)[self.global_env_offset:self.global_env_offset + self.num_envs]
             if self.atm_type == "dynamic":
-                layer = build_layer_tables(N, self.params.pupil_pixel, self.params.outer_scale, trng)
+                # the stencil draws have a stream of their own: drawn after the wind directions they would depend on total_envs,
+                # and instances holding different slices of one batch must share the AR matrices whatever total_envs they were given
+                layer = build_layer_tables(N, self.params.pupil_pixel, self.params.outer_scale, np.random.RandomState([base_seed & 0xFFFFFFFF, 0x57E9C11]))
         self.wind_u = np.array(wind_u, dtype=np.float64)
         theta = self.wind_u * 2 * np.pi
         self.velocity_vectors = float(self.velocity) * np.stack([np.cos(theta), np.sin(theta)], axis=1)  # [B, 2] m/s
@@ -567,6 +570,17 @@ class BatchedAOEnv:
         ms, n = C.c_double(), C.c_int()
         _lib.check(self.lib.aog_profile_read(self._handle, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def profile_kernels(self):
+        """{name: (mean ms, launches)} of every kernel id timed since profiling was switched on, as collected by the LAST ``profile_read()``
+        (``_lib.AOG_PROF``: screen synthesis passes, screen packing, extrusion, Shack-Hartmann passes; HIP events on the launch stream)."""
+        out = {}
+        for name, kid in _lib.AOG_PROF.items():
+            ms, n = C.c_double(), C.c_int()
+            _lib.check(self.lib.aog_profile_read_kernel(self._handle, kid, C.byref(ms), C.byref(n)))
+            if n.value:
+                out[name] = (ms.value, n.value)
+        return out
 
     def close(self):
         h, self._handle = getattr(self, "_handle", None), None

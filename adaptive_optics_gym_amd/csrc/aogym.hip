@@ -94,12 +94,12 @@ int pick_pad(int v, const int* opts, int n) {
 const int kApadOpts[] = {16, 32, 64, 128};
 const int kMrwOpts[] = {7, 12, 20, 28};
 
-void launch_fast(aog_env* e, hipStream_t s) {
+int launch_fast(aog_env* e, hipStream_t s) {
   switch (e->A_pad) {
-    case 16: aog_host::launch_fused_apad16(e, s); break;
-    case 32: aog_host::launch_fused_apad32(e, s); break;
-    case 64: aog_host::launch_fused_apad64(e, s); break;
-    default: aog_host::launch_fused_apad128(e, s); break;
+    case 16: return aog_host::launch_fused_apad16(e, s);
+    case 32: return aog_host::launch_fused_apad32(e, s);
+    case 64: return aog_host::launch_fused_apad64(e, s);
+    default: return aog_host::launch_fused_apad128(e, s);
   }
 }
 
@@ -156,32 +156,48 @@ void launch_phase(aog_env* e, hipStream_t s, const _Float16* act16, float* out_t
 
 namespace {
 
+// HIP-event bracket around the launches of one kernel id while profiling is on (aog_profile_read_kernel): the closing record is made by
+// the destructor, on the same stream.
+struct TimedRegion {
+  aog_env* e;
+  hipStream_t s;
+  hipEvent_t ev1 = nullptr;
+  TimedRegion(aog_env* env, hipStream_t stream, int kernel_id, bool on = true) : e(env), s(stream) {
+    if (!e->profile || !on) return;
+    hipEvent_t ev0 = nullptr;
+    if (e->events_used == e->events.size()) {
+      hipEvent_t a = nullptr, b = nullptr;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+      e->events.emplace_back(a, b);
+    }
+    ev0 = e->events[e->events_used].first;
+    ev1 = e->events[e->events_used].second;
+    if (e->event_kernel.size() <= e->events_used) e->event_kernel.resize(e->events_used + 1);
+    e->event_kernel[e->events_used] = kernel_id;
+    ++e->events_used;
+    (void)hipEventRecord(ev0, s);
+  }
+  ~TimedRegion() {
+    if (ev1) (void)hipEventRecord(ev1, s);
+  }
+  TimedRegion(const TimedRegion&) = delete;
+  TimedRegion& operator=(const TimedRegion&) = delete;
+};
+
 int launch_fused(aog_env* e, hipStream_t s) {
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // event timing of one launch block in profile_every: the two records cost ~3 us each on the stream, so a throughput measurement that
   // also wants the kernel's duration samples instead of timing every launch
   // (blocks of 8 consecutive launches, one block in profile_every: a timed launch mostly sees the same neighbours as with every launch timed)
   const bool timed = e->profile && ((e->profile_phase++ >> 3) % (unsigned)e->profile_every) == 0;
-  if (timed) {
-    if (e->events_used == e->events.size()) {
-      HIP_TRY(hipEventCreate(&ev0));
-      HIP_TRY(hipEventCreate(&ev1));
-      e->events.emplace_back(ev0, ev1);
-    }
-    ev0 = e->events[e->events_used].first;
-    ev1 = e->events[e->events_used].second;
-    ++e->events_used;
-    HIP_TRY(hipEventRecord(ev0, s));
-  }
+  TimedRegion tr(e, s, AOG_PROF_FUSED, timed);
   if (e->cfg.precision == AOG_PRECISION_FP64) {
     hipLaunchKernelGGL(aog::k_fused_ref, dim3(e->B), dim3(256), 0, s, e->modes64, e->tabs64, e->psi64, e->act_dm,
                        e->partials, e->n_ap, e->A, e->MRW_used, e->MRS_used, e->Bp, e->cfg.wavelength_wfs,
                        e->cfg.wavelength_sci);
-  } else {
-    launch_fast(e, s);
+  } else if (int rc = launch_fast(e, s)) {
+    return rc;   // (the dynamic-LDS request of this shape was refused: the message names the size)
   }
   HIP_TRY(hipGetLastError());
-  if (timed) HIP_TRY(hipEventRecord(ev1, s));
   return AOG_OK;
 }
 
@@ -303,16 +319,32 @@ int evolve_layer(aog_env* e, hipStream_t s) {
   p.ring = e->ring_direct ? e->psi_ring : nullptr;
   p.ring_ref = e->psi_offset;
   p.ring_inv = 1.0 / (2.0 * M_PI * e->cfg.wavelength_wfs);
+  TimedRegion tr_ext(e, s, AOG_PROF_EXTRUDE);
   if (e->ext_bar && !getenv("AOG_EXTRUDE_SIMPLE") && !getenv("AOG_EXTRUDE_NOSPLIT") && ext_split_lds(e) <= kLdsBytes) {
     // float64 matrix-core form with each 16-env group's rows split over four workgroups + group barrier
     const size_t lds = ext_split_lds(e);
     auto kern = aog::k_extrude16_split<aog::kExtKs>;
     if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, e->device)) return rc;
+    if (!e->ext_resident) {
+      // The four workgroups of a group meet at a spin barrier: they must be resident together.  Ask once per handle how many of these
+      // workgroups a CU holds (registers + this shape's LDS), keep one CU's worth of margin (the query over-reports by one block per CU for
+      // some kernels: MI355X_MICROARCH.md, Residency), and never put more workgroups than that into one launch.
+      int per_cu = 0, cus = 0;
+      HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 256 * aog::kExtKs, lds));
+      HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
+      if (per_cu < 1 || cus < 8) return fail(AOG_ERR_HIP, "k_extrude16_split does not fit a compute unit (occupancy query: %d)", per_cu);
+      e->ext_resident = std::max(1, per_cu > 1 ? per_cu - 1 : 1) * cus;
+      if (const char* v = getenv("AOG_EXTRUDE_RESIDENT")) e->ext_resident = std::max(8 * aog::kExtParts, atoi(v));   // (tests: force several launches)
+    }
     zero_words(e->ext_bar, (size_t)round_up(e->n_ext_groups, 4), s);
     p.origin = e->origin;
     const int groups8 = round_up(e->n_ext_groups, 8);
-    hipLaunchKernelGGL(kern, dim3(groups8 * aog::kExtParts), dim3(256 * aog::kExtKs), lds, s, p, e->B, e->ext_perm, e->ext_bar, e->dev_status,
-                       e->host_flag_dev);
+    const int groups_per_launch = std::max(8, e->ext_resident / aog::kExtParts / 8 * 8);
+    for (int g0 = 0; g0 < groups8; g0 += groups_per_launch) {
+      const int ng = std::min(groups_per_launch, groups8 - g0);
+      hipLaunchKernelGGL(kern, dim3(ng * aog::kExtParts), dim3(256 * aog::kExtKs), lds, s, p, e->B, e->ext_perm, e->ext_bar, e->dev_status,
+                         e->host_flag_dev, g0, e->ext_spin_limit, e->ext_absent_part);
+    }
     HIP_TRY(hipGetLastError());
   } else if (!getenv("AOG_EXTRUDE_SIMPLE") && ext16_lds(e) <= kLdsBytes) {
     // default: float64 matrix-core form, 16 envs per workgroup (a workgroup owns whole envs: no cross-workgroup hazard)
@@ -385,13 +417,36 @@ int set_screens(aog_env* e, const T* psi, int first, int count, hipStream_t s) {
     HIP_TRY(hipGetLastError());
     int rc = e->ring_direct ? ring_from_master(e, first, count, 0, s) : pack_from_master(e, first, count, s);
     if (rc != AOG_OK) return rc;
+  } else if (e->cfg.precision == AOG_PRECISION_FAST && count >= 8) {
+    // batches: aperture means, then tiled conversion with whole-line stores (k_pack_tiles)
+    if (!e->pack_mean) {
+      int rc = dev_alloc(e, &e->pack_mean, (size_t)e->B, false);
+      if (rc != AOG_OK) return rc;
+    }
+    TimedRegion tr(e, s, AOG_PROF_PACK);
+    hipLaunchKernelGGL((aog::k_screen_means<T>), dim3(count), dim3(256), 0, s, psi, e->ap_index, e->pack_mean, N2, e->n_ap);
+    const int et0 = first >> 5, et1 = (first + count - 1) >> 5;
+    hipLaunchKernelGGL((aog::k_pack_tiles<T>), dim3((e->n_ptiles + aog::kPackTiles - 1) / aog::kPackTiles, et1 - et0 + 1), dim3(256), 0, s, psi,
+                       e->ap_index, e->pack_mean, e->psi_rev, e->psi_tile, first, count, N2, e->n_ap, e->n_ptiles, e->Bp, inv);
+    HIP_TRY(hipGetLastError());
   } else {
+    TimedRegion tr(e, s, AOG_PROF_PACK);
     hipLaunchKernelGGL((aog::k_pack_screens<T>), dim3(count), dim3(256), 0, s, psi, e->ap_index, e->psi_rev, e->psi_tile,
                        e->psi64, first, N2, e->n_ap, e->n_ap_pad, e->Bp, inv, (const int32_t*)nullptr, e->cfg.n_pupil);
     HIP_TRY(hipGetLastError());
   }
   e->screens_ready = true;
-  if (first == 0 && count == e->B && e->host_flag && *static_cast<volatile int*>(e->host_flag)) {
+  e->sh_sums_ready = false;   // lenslet sums of an earlier aog_sh_image(NULL) belong to the old screens
+  return AOG_OK;
+}
+
+// New screens for the WHOLE batch make a handle whose extrusion kernel once timed out usable again (see check_poisoned).  Called by the
+// public entry points with the range of the whole call (aog_generate_screens installs large batches in several chunks).  Dynamic handles
+// drain the stream first: a timeout of a launch that is still running would otherwise poison the screens just installed.
+int clear_poison_if_whole(aog_env* e, int first, int count, hipStream_t s) {
+  if (first != 0 || count != e->B || !e->host_flag) return AOG_OK;
+  if (e->cfg.atm_dynamic) HIP_TRY(hipStreamSynchronize(s));
+  if (*static_cast<volatile int*>(e->host_flag)) {
     HIP_TRY(hipStreamSynchronize(s));
     HIP_TRY(hipMemset(e->dev_status, 0, sizeof(int)));
     *static_cast<volatile int*>(e->host_flag) = 0;
@@ -558,7 +613,7 @@ int aog_create(const aog_config* cfg, int device, aog_env** out) {
     TRY_ALLOC(dev_alloc(e, &e->tabs_f32, (size_t)e->n_ap_pad * TROW));
     TRY_ALLOC(dev_alloc(e, &e->tab16, (size_t)e->n_ptiles * 2 * 2 * 64 * 8));
     TRY_ALLOC(dev_alloc(e, &e->sci_tile, (size_t)e->n_ptiles * 32));
-    TRY_ALLOC(dev_alloc(e, &e->psi_rev, (size_t)e->n_quads * e->Bp * 4));
+    if (e->kernel == AOG_KERNEL_VALU) TRY_ALLOC(dev_alloc(e, &e->psi_rev, (size_t)e->n_quads * e->Bp * 4));   // only the VALU kernel reads this layout
     TRY_ALLOC(dev_alloc(e, &e->psi_tile, (size_t)e->n_etiles * e->n_ptiles * 1024));
   } else {
     TRY_ALLOC(dev_alloc(e, &e->modes64, (size_t)e->n_ap * e->A));
@@ -745,11 +800,13 @@ int aog_upload_tables(aog_env* e, const aog_tables* t) {
 }
 
 int aog_set_screens_f64(aog_env* e, const double* psi, int first, int count, void* stream) {
-  return set_screens<double>(e, psi, first, count, static_cast<hipStream_t>(stream));
+  if (int rc = set_screens<double>(e, psi, first, count, static_cast<hipStream_t>(stream))) return rc;
+  return clear_poison_if_whole(e, first, count, static_cast<hipStream_t>(stream));
 }
 
 int aog_set_screens_f32(aog_env* e, const float* psi, int first, int count, void* stream) {
-  return set_screens<float>(e, psi, first, count, static_cast<hipStream_t>(stream));
+  if (int rc = set_screens<float>(e, psi, first, count, static_cast<hipStream_t>(stream))) return rc;
+  return clear_poison_if_whole(e, first, count, static_cast<hipStream_t>(stream));
 }
 
 int aog_upload_layer(aog_env* e, const aog_layer_tables* t) {
@@ -1002,8 +1059,14 @@ static int generate_twoband(aog_env* e, int first, int count, int qf, double cn_
     for (int done = 0; done < count; done += per_launch) {
       const int nb = std::min(per_launch, count - done);
       a.first_local = first + done;
-      hipLaunchKernelGGL(rows, dim3(nHblocks + nLblocks, nb), dim3(256), lds, s, a);
-      hipLaunchKernelGGL(cols, dim3((N + aog::kColsWaves * NL - 1) / (aog::kColsWaves * NL), nb), dim3(64 * aog::kColsWaves), lds_cols, s, a);
+      {
+        TimedRegion tr(e, s, AOG_PROF_SCREEN_ROWS);
+        hipLaunchKernelGGL(rows, dim3(nHblocks + nLblocks, nb), dim3(256), lds, s, a);
+      }
+      {
+        TimedRegion tr(e, s, AOG_PROF_SCREEN_COLS);
+        hipLaunchKernelGGL(cols, dim3((N + aog::kColsWaves * NL - 1) / (aog::kColsWaves * NL), nb), dim3(64 * aog::kColsWaves), lds_cols, s, a);
+      }
       HIP_TRY(hipGetLastError());
       int rc = set_screens<float>(e, e->syn_out, first + done, nb, s);
       if (rc != AOG_OK) return rc;
@@ -1045,7 +1108,7 @@ static int generate_twoband(aog_env* e, int first, int count, int qf, double cn_
   }
   hipLaunchKernelGGL(aog::k_bump_generation, dim3((count + 255) / 256), dim3(256), 0, s, e->screen_gen + first, count);
   HIP_TRY(hipGetLastError());
-  return AOG_OK;
+  return clear_poison_if_whole(e, first, count, s);
 }
 
 int aog_generate_screens(aog_env* e, int first, int count, int oversampling, double cn_squared, double outer_scale, double pixel_pitch,
@@ -1111,15 +1174,21 @@ int aog_generate_screens(aog_env* e, int first, int count, int oversampling, dou
     for (int done = 0; done < count; done += per_launch) {
       const int nb = std::min(per_launch, count - done);
       a.first_local = first + done;
-      hipLaunchKernelGGL(rows, dim3((lines + 3) / 4, nb), dim3(256), lds, s, a);
-      hipLaunchKernelGGL(cols, dim3((N + aog::kColsWaves - 1) / aog::kColsWaves, nb), dim3(64 * aog::kColsWaves), lds_cols, s, a);
+      {
+        TimedRegion tr(e, s, AOG_PROF_SCREEN_ROWS);
+        hipLaunchKernelGGL(rows, dim3((lines + 3) / 4, nb), dim3(256), lds, s, a);
+      }
+      {
+        TimedRegion tr(e, s, AOG_PROF_SCREEN_COLS);
+        hipLaunchKernelGGL(cols, dim3((N + aog::kColsWaves - 1) / aog::kColsWaves, nb), dim3(64 * aog::kColsWaves), lds_cols, s, a);
+      }
       HIP_TRY(hipGetLastError());
       int rc = set_screens<float>(e, e->syn_out, first + done, nb, s);
       if (rc != AOG_OK) return rc;
     }
     hipLaunchKernelGGL(aog::k_bump_generation, dim3((count + 255) / 256), dim3(256), 0, s, e->screen_gen + first, count);
     HIP_TRY(hipGetLastError());
-    return AOG_OK;
+    return clear_poison_if_whole(e, first, count, s);
   }
   if (int rc = ensure_fft_plan(e, m, N)) return rc;
   hipfftHandle plan = (hipfftHandle)(uintptr_t)e->fft_plan;
@@ -1149,7 +1218,7 @@ int aog_generate_screens(aog_env* e, int first, int count, int oversampling, dou
   }
   hipLaunchKernelGGL(aog::k_bump_generation, dim3((count + 255) / 256), dim3(256), 0, s, e->screen_gen + first, count);
   HIP_TRY(hipGetLastError());
-  return AOG_OK;
+  return clear_poison_if_whole(e, first, count, s);
 }
 
 int aog_upload_sh(aog_env* e, const aog_sh_tables* t) {
@@ -1267,8 +1336,12 @@ int aog_sh_image(aog_env* e, double* image_dev, void* stream) {
     const int n = e->B * e->A_pad;
     hipLaunchKernelGGL(aog::k_sh_act16, dim3((n + 255) / 256), dim3(256), 0, s, e->sh_act, e->sh_act16, e->B, e->A, e->A_pad,
                        2.0 / e->cfg.wavelength_wfs);
-    if (e->sh_pruned) aog_host::launch_phase_field(e, s, e->sh_act16, static_cast<float*>(e->sh_in), (size_t)N * N, N);   // phases -> field in one kernel
-    else aog_host::launch_phase(e, s, e->sh_act16, e->sh_phase);
+    if (e->sh_pruned) {
+      TimedRegion tr(e, s, AOG_PROF_SH_FIELD);
+      aog_host::launch_phase_field(e, s, e->sh_act16, static_cast<float*>(e->sh_in), (size_t)N * N, N);   // phases -> field in one kernel
+    } else {
+      aog_host::launch_phase(e, s, e->sh_act16, e->sh_phase);
+    }
   }
   const double norm = 1.0 / (double)per;  // hipFFT's inverse is un-normalised
   const dim3 g_ap((e->n_ap + 255) / 256, e->B), g_per((unsigned)((per + 255) / 256), e->B), g_img((N * N + 255) / 256, e->B);
@@ -1280,7 +1353,8 @@ int aog_sh_image(aog_env* e, double* image_dev, void* stream) {
     const size_t lds = sizeof(float) * 64 * 65 * aog::kShFftWaves, lds_fused = lds + sizeof(double) * 3 * e->sh_n_sub * aog::kShFftWaves;
     const double scale = e->sh_scale * norm * norm;
     // nobody asked for the image (SH_step): photon noise and the estimator's per-lenslet sums are taken inside the last pass
-    const bool fused = image_dev == nullptr;
+    // (when the per-wave lenslet tables do not fit the LDS beside the transform planes, the unfused pass + k_sh_noise + estimator run instead)
+    const bool fused = image_dev == nullptr && lds_fused <= kLdsBytes;
     aog::ShFuseArgs fa{};
     if (fused) {
       e->sh_calls += 1;   // (the noise call the following aog_sh_update(null) would have made)
@@ -1300,10 +1374,18 @@ int aog_sh_image(aog_env* e, double* image_dev, void* stream) {
       if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_sh_rows_fwd<RL, LW>), lds, e->device)) return rc;
       if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_sh_cols<RL, LW>), lds, e->device)) return rc;
       if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_sh_rows_inv<RL, LW, false>), lds, e->device)) return rc;
-      if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_sh_rows_inv<RL, LW, true>), lds_fused, e->device)) return rc;
+      if (fused)
+        if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_sh_rows_inv<RL, LW, true>), lds_fused, e->device)) return rc;
       const dim3 g_rows((N / BC + aog::kShFftWaves - 1) / aog::kShFftWaves, e->B), g_cols((L / BC + aog::kShFftWaves - 1) / aog::kShFftWaves, e->B);
-      hipLaunchKernelGGL((aog::k_sh_rows_fwd<RL, LW>), g_rows, dim3(64 * aog::kShFftWaves), lds, s, field, F1T, tw);
-      hipLaunchKernelGGL((aog::k_sh_cols<RL, LW>), g_cols, dim3(64 * aog::kShFftWaves), lds, s, F1T, GT, reinterpret_cast<const float2*>(e->sh_tfq), tw);
+      {
+        TimedRegion tr(e, s, AOG_PROF_SH_ROWS_FWD);
+        hipLaunchKernelGGL((aog::k_sh_rows_fwd<RL, LW>), g_rows, dim3(64 * aog::kShFftWaves), lds, s, field, F1T, tw);
+      }
+      {
+        TimedRegion tr(e, s, AOG_PROF_SH_COLS);
+        hipLaunchKernelGGL((aog::k_sh_cols<RL, LW>), g_cols, dim3(64 * aog::kShFftWaves), lds, s, F1T, GT, reinterpret_cast<const float2*>(e->sh_tfq), tw);
+      }
+      TimedRegion tr(e, s, AOG_PROF_SH_ROWS_INV);
       if (fused) hipLaunchKernelGGL((aog::k_sh_rows_inv<RL, LW, true>), g_rows, dim3(64 * aog::kShFftWaves), lds_fused, s, GT, e->sh_image, tw, scale, fa);
       else hipLaunchKernelGGL((aog::k_sh_rows_inv<RL, LW, false>), g_rows, dim3(64 * aog::kShFftWaves), lds, s, GT, e->sh_image, tw, scale, fa);
       return AOG_OK;
@@ -1461,6 +1543,7 @@ int aog_set_state(aog_env* e, const void* blob_dev, int64_t timestep, void* stre
   e->timestep = timestep;
   e->rng_seed = tail.rng_seed;
   e->sh_calls = tail.sh_calls;
+  e->sh_sums_ready = false;
   if (e->host_flag && *static_cast<volatile int*>(e->host_flag)) {   // a restored state replaces every screen: the handle is usable again
     HIP_TRY(hipMemset(e->dev_status, 0, sizeof(int)));
     *static_cast<volatile int*>(e->host_flag) = 0;
@@ -1565,6 +1648,7 @@ int aog_step(aog_env* e, const float* action, float* obs_raw, uint16_t* obs, flo
   HIP_TRY(hipSetDevice(e->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
   e->timestep += 1;  // AO_env.py:123
+  e->sh_sums_ready = false;   // (an aog_sh_image(NULL) not followed by its aog_sh_update is void once the env has stepped)
   if (e->cfg.atm_dynamic) {
     int rce = evolve_layer(e, s);
     if (rce != AOG_OK) return rce;
@@ -1680,6 +1764,24 @@ int aog_actor_act(const aog_actor* n, int device, const void* obs_dev, int obs_i
   return AOG_OK;
 }
 
+int aog_selftest_barrier_timeout(aog_env* e, void* stream) {
+  if (!e) return fail(AOG_ERR_INVALID, "aog_selftest_barrier_timeout: null handle");
+  if (!e->cfg.atm_dynamic || !e->layer_ready || !e->screens_ready) return fail(AOG_ERR_STATE, "aog_selftest_barrier_timeout: needs a dynamic handle with layer and screens");
+  if (!e->ext_bar || getenv("AOG_EXTRUDE_SIMPLE") || getenv("AOG_EXTRUDE_NOSPLIT") || ext_split_lds(e) > kLdsBytes)
+    return fail(AOG_ERR_UNSUPPORTED, "aog_selftest_barrier_timeout: this handle does not use the split extrusion kernel");
+  HIP_TRY(hipSetDevice(e->device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  e->ext_spin_limit = 1u << 10;
+  e->ext_absent_part = 1;
+  e->timestep += 1;
+  const int rc = evolve_layer(e, s);
+  e->ext_spin_limit = 1u << 24;
+  e->ext_absent_part = -1;
+  if (rc != AOG_OK) return rc;
+  HIP_TRY(hipStreamSynchronize(s));
+  return AOG_OK;
+}
+
 int aog_selftest_sincos(const float* u_dev, float* sin_dev, float* cos_dev, int n, int flavour, void* stream) {
   if (!u_dev || !sin_dev || !cos_dev || n < 0 || flavour < 0 || flavour > 2) return fail(AOG_ERR_INVALID, "aog_selftest_sincos: bad argument");
   if (n == 0) return AOG_OK;
@@ -1717,17 +1819,30 @@ int aog_profile_enable(aog_env* e, int enable) {
 int aog_profile_read(aog_env* e, double* mean_ms, int* launches) {
   if (!e || !mean_ms || !launches) return fail(AOG_ERR_INVALID, "aog_profile_read: null argument");
   HIP_TRY(hipSetDevice(e->device));
-  double total = 0;
+  for (int k = 0; k < AOG_PROF_COUNT; ++k) {
+    e->prof_ms[k] = 0;
+    e->prof_n[k] = 0;
+  }
   for (size_t i = 0; i < e->events_used; ++i) {
     HIP_TRY(hipEventSynchronize(e->events[i].second));
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, e->events[i].first, e->events[i].second));
-    total += ms;
+    const int k = i < e->event_kernel.size() ? e->event_kernel[i] : AOG_PROF_FUSED;
+    e->prof_ms[k] += ms;
+    e->prof_n[k] += 1;
   }
-  *launches = (int)e->events_used;
-  *mean_ms = e->events_used ? total / (double)e->events_used : 0.0;
+  *launches = e->prof_n[AOG_PROF_FUSED];
+  *mean_ms = e->prof_n[AOG_PROF_FUSED] ? e->prof_ms[AOG_PROF_FUSED] / (double)e->prof_n[AOG_PROF_FUSED] : 0.0;
   e->events_used = 0;
   e->profile_phase = 0;   // the next launch opens a timed block: a short measurement after a read still gets its samples
+  return AOG_OK;
+}
+
+int aog_profile_read_kernel(aog_env* e, int which, double* mean_ms, int* launches) {
+  if (!e || !mean_ms || !launches) return fail(AOG_ERR_INVALID, "aog_profile_read_kernel: null argument");
+  if (which < 0 || which >= AOG_PROF_COUNT) return fail(AOG_ERR_INVALID, "aog_profile_read_kernel: unknown kernel id %d", which);
+  *launches = e->prof_n[which];
+  *mean_ms = e->prof_n[which] ? e->prof_ms[which] / (double)e->prof_n[which] : 0.0;
   return AOG_OK;
 }
 

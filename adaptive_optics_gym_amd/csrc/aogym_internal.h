@@ -93,7 +93,8 @@ struct aog_env {
   float* focal_Tb = nullptr;     // [focal_chunk][n_focal][N] complex64
   int focal_chunk = 0;
   // state
-  float* psi_rev = nullptr;      // [n_quads][Bp][4]
+  float* psi_rev = nullptr;      // [n_quads][Bp][4]  (handles that run the VALU kernel only)
+  double* pack_mean = nullptr;   // [B] aperture means of the screens being installed (k_screen_means -> k_pack_tiles)
   float* psi_tile = nullptr;     // [Bp/32][n_ptiles][4][64][4]
   double* psi64 = nullptr;       // validation: [B][n_ap]
   double* act_dm = nullptr;      // [B][A]
@@ -113,6 +114,9 @@ struct aog_env {
   int* host_flag = nullptr;      // the same flag in pinned, device-mapped host memory: read by the host without a synchronisation
   int* host_flag_dev = nullptr;  // its device address
   int n_ext_groups = 0;
+  int ext_resident = 0;          // workgroups of k_extrude16_split one launch may hold (occupancy query x CUs; 0 = not asked yet)
+  unsigned ext_spin_limit = 1u << 24;   // polls before a barrier wait gives up (seconds)
+  int ext_absent_part = -1;      // aog_selftest_barrier_timeout: the part that never arrives
   int32_t* ext_perm = nullptr;   // [n_ext_groups * 16] group slot -> env id, -1 = padding (envs sorted by wind, see aog_set_wind)
   double max_wind = 0;           // max |component| of any env's velocity (bounds the rounds per step)
   long long timestep = 0;        // AOEnv.timestep: monotone over episodes (AO_env.py:123)
@@ -149,7 +153,10 @@ struct aog_env {
   int profile_every = 1;         // time every n-th launch of the fused kernel (aog_profile_enable(env, n))
   unsigned profile_phase = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  std::vector<int> event_kernel;    // AOG_PROF_* id of each used event pair
   size_t events_used = 0;
+  double prof_ms[AOG_PROF_COUNT] = {};   // totals of the last aog_profile_read, per kernel id
+  int prof_n[AOG_PROF_COUNT] = {};
   std::vector<void*> allocs;
 };
 
@@ -162,11 +169,11 @@ int ensure_dynamic_lds(const void* fn, size_t bytes, int device);
 extern long long* dev_timeline;   // per-wave time stamps of the last fused launch (AOG_DEV_TIMELINE=1)
 #endif
 // Fused-kernel launchers, one translation unit per padded mode count so the build parallelises
-// (fused_inst.hip compiled with -DAOG_INST_APAD=16|32|64|128).
-void launch_fused_apad16(aog_env* e, hipStream_t s);
-void launch_fused_apad32(aog_env* e, hipStream_t s);
-void launch_fused_apad64(aog_env* e, hipStream_t s);
-void launch_fused_apad128(aog_env* e, hipStream_t s);
+// (fused_inst.hip compiled with -DAOG_INST_APAD=16|32|64|128).  Return 0 or the aog_status of a failed dynamic-LDS request.
+int launch_fused_apad16(aog_env* e, hipStream_t s);
+int launch_fused_apad32(aog_env* e, hipStream_t s);
+int launch_fused_apad64(aog_env* e, hipStream_t s);
+int launch_fused_apad128(aog_env* e, hipStream_t s);
 // phase-only contraction u = psi + Mt a for every (pixel, env) with the actuator operands `act16`, written in the psi_tile layout
 void launch_phase(aog_env* e, hipStream_t s, const _Float16* act16, float* out_tile);
 void launch_phase_field(aog_env* e, hipStream_t s, const _Float16* act16, float* field, size_t env_stride, int row_stride);   // complex64 field

@@ -118,6 +118,67 @@ __global__ __launch_bounds__(256) void k_pack_screens(const T* __restrict__ psi,
   }
 }
 
+// The same conversion for whole batches (semi_dynamic resets install thousands of screens at once): k_pack_screens writes 4 bytes per
+// thread into layouts whose contiguous runs are 16 bytes per env, so its stores are what it waits for.  Here a workgroup takes one env
+// tile (32 envs) x kPackTiles pixel tiles, gathers the aperture pixels env by env (coalesced along the packed index), transposes through
+// LDS and stores whole 1-KiB MFMA register groups (psi_tile) / 512-byte quad rows (psi_rev).  Aperture means come from k_screen_means.
+template <typename T>
+__global__ __launch_bounds__(256) void k_screen_means(const T* __restrict__ psi, const int32_t* __restrict__ ap_index, double* __restrict__ mean,
+                                                      int n_pix2, int n_ap) {
+  __shared__ double sm[8];
+  const T* src = psi + (size_t)blockIdx.x * n_pix2;
+  double acc = 0;
+  for (int p = threadIdx.x; p < n_ap; p += blockDim.x) acc += (double)src[ap_index[p]];
+  const double total = block_reduce_sum(acc, sm);
+  if (threadIdx.x == 0) mean[blockIdx.x] = total / (double)n_ap;
+}
+
+constexpr int kPackTiles = 8;   // pixel tiles (of 32 packed pixels) per workgroup
+template <typename T>
+__global__ __launch_bounds__(256) void k_pack_tiles(const T* __restrict__ psi, const int32_t* __restrict__ ap_index, const double* __restrict__ mean,
+                                                    float* __restrict__ psi_rev, float* __restrict__ psi_tile, int first, int count, int n_pix2,
+                                                    int n_ap, int n_ptiles, int Bp, double inv_two_pi_lambda) {
+  __shared__ float tile[kPackTiles * 32][33];   // [packed pixel of the block][env of the tile]
+  const int et = (first >> 5) + blockIdx.y;      // env tile
+  const int pt0 = blockIdx.x * kPackTiles;
+  const int npix = min(kPackTiles, n_ptiles - pt0) * 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // gather: one wave = one env at a time, lanes along the packed pixel index
+  for (int el = wave; el < 32; el += 4) {
+    const int env = et * 32 + el;
+    const bool live = env >= first && env < first + count;   // (wave-uniform)
+    const T* src = psi + (size_t)(live ? env - first : 0) * n_pix2;
+    const double mu = live ? mean[env - first] : 0.0;
+    for (int pl = lane; pl < npix; pl += 64) {
+      const int p = pt0 * 32 + pl;
+      float v = 0.f;
+      if (live && p < n_ap) v = (float)(((double)src[ap_index[p]] - mu) * inv_two_pi_lambda);
+      tile[pl][el] = v;
+    }
+  }
+  __syncthreads();
+  // psi_tile: [env tile][pixel tile][g 4][lane = 32 h + e][r 4], pixel of the tile = 8 g + 4 h + r
+  const int h = lane >> 5, e = lane & 31;
+  const int env = et * 32 + e;
+  const bool mine = env >= first && env < first + count;
+  if (psi_tile && mine) {
+    for (int c = wave; c < (npix >> 5) * 4; c += 4) {
+      const int ptl = c >> 2, g = c & 3;
+      const int pl = ptl * 32 + 8 * g + 4 * h;
+      const float4 v = make_float4(tile[pl][e], tile[pl + 1][e], tile[pl + 2][e], tile[pl + 3][e]);
+      *reinterpret_cast<float4*>(psi_tile + ((((size_t)et * n_ptiles + pt0 + ptl) * 4 + g) * 64 + lane) * 4) = v;
+    }
+  }
+  // psi_rev: [quad][env][4]: two quads per wave instruction (lanes 0-31 / 32-63)
+  if (psi_rev && mine) {
+    for (int c = wave; c < (npix >> 3); c += 4) {
+      const int ql = 2 * c + h;
+      const float4 v = make_float4(tile[4 * ql][e], tile[4 * ql + 1][e], tile[4 * ql + 2][e], tile[4 * ql + 3][e]);
+      *reinterpret_cast<float4*>(psi_rev + ((size_t)(pt0 * 8 + ql) * Bp + env) * 4) = v;
+    }
+  }
+}
+
 // one actuator value (revolutions) -> the hi/lo f16 B-operand layout of k_fused_tab:
 //   act16[env tile][s = i/16][hi|lo][lane = 32*((i/8)&1) + env%32][i%8]   (A_pad is a multiple of 16 for this layout)
 __device__ __forceinline__ void store_act16(_Float16* __restrict__ act16, int env, int i, int A_pad, float ar) {
@@ -1529,7 +1590,10 @@ constexpr int kExtKs = 2;   // slices of the contraction per row block (template
 #ifdef AOG_MAIN_TU
 template <int KS>
 __global__ __launch_bounds__(256 * KS) void k_extrude16_split(ExtrudeArgs p, int B, const int* __restrict__ perm, unsigned* __restrict__ bar, int* __restrict__ status,
-                                                              int* __restrict__ host_flag) {
+                                                              int* __restrict__ host_flag, int group0, unsigned spin_limit, int absent_part) {
+  // group0: first group of this launch (a batch whose groups x 4 workgroups exceed what the chip holds at once is extruded in several
+  // launches: barrier partners must be co-resident).  spin_limit / absent_part: see aog_selftest_barrier_timeout (product launches pass
+  // 1 << 24 and -1).
   extern __shared__ double lds[];  // z [16][zs] | noise [16][ns] | partial sums [KS-1][4][256]
   constexpr int G = kExt16G;
   const int N = p.N;
@@ -1548,9 +1612,10 @@ __global__ __launch_bounds__(256 * KS) void k_extrude16_split(ExtrudeArgs p, int
   // groups are sorted by wind (aog_set_wind): an XCD takes a contiguous run of them, so its workgroups want the same class of
   // matrices at the same time
   const int groups_per_xcd = (int)gridDim.x >> 5;
-  const int group = (L & 7) * groups_per_xcd + (L >> 5);
+  const int group = group0 + (L & 7) * groups_per_xcd + (L >> 5);
   const int env0 = group * G;
   if (env0 >= B) return;   // whole groups only: no barrier partner is left waiting
+  if (part == absent_part) return;   // (self-test: this group's partners wait for a ticket that never comes)
   for (int i = threadIdx.x; i < p.nz_v; i += blockDim.x) st_v[i] = p.stencil_v_yx[i];
   for (int i = threadIdx.x; i < p.nz_h; i += blockDim.x) st_h[i] = p.stencil_h_yx[i];
   if (threadIdx.x < G) {
@@ -1850,7 +1915,7 @@ __global__ __launch_bounds__(256 * KS) void k_extrude16_split(ExtrudeArgs p, int
       unsigned spins = 0;
       while (__hip_atomic_load(&bar[group], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         __builtin_amdgcn_s_sleep(2);
-        if (++spins > (1u << 24)) {   // ~seconds: a partner never arrived (not co-resident).  The launch still terminates, but its
+        if (++spins > spin_limit) {   // ~seconds: a partner never arrived (not co-resident).  The launch still terminates, but its
           atomicExch(status, 1);      // screens are invalid: flag it on the device and in host-visible memory — the host refuses
           __hip_atomic_store(host_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // every later call on the handle
           break;

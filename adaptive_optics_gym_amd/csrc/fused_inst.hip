@@ -10,17 +10,18 @@ namespace {
 using aog_host::round_up;
 // ---- fused kernel dispatch -------------------------------------------------------------------------
 template <int A_PAD, int MRW, int SC>
-void launch_valu(aog_env* e, hipStream_t s) {
+int launch_valu(aog_env* e, hipStream_t s) {
   const int n_groups = e->Bp / 64;
   dim3 grid(e->valu_chunks, (n_groups + 3) / 4);
   const float ratio = (float)(e->cfg.wavelength_wfs / e->cfg.wavelength_sci);
   hipLaunchKernelGGL((aog::k_fused_valu<A_PAD, MRW, 1, SC>), grid, dim3(256), 0, s, e->modes_f32, e->tabs_f32,
                      reinterpret_cast<const float4*>(e->psi_rev), e->act_rev, e->partials, e->n_quads, e->Bp, n_groups,
                      e->valu_qpc, ratio);
+  return 0;
 }
 
 template <int A_PAD, int MRW>
-void launch_tab(aog_env* e, hipStream_t s) {
+int launch_tab(aog_env* e, hipStream_t s) {
   aog::MfmaGeom g;
   g.n_ptiles = e->n_ptiles;
   g.n_etiles = e->n_etiles;
@@ -62,37 +63,35 @@ void launch_tab(aog_env* e, hipStream_t s) {
     dyn.N = e->cfg.n_pupil;
     dyn.RS = e->cfg.n_pupil + 4;
     dyn.B = e->B;
-    aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_fused_tab<A_PAD, MRW, true>), lds_t, e->device);
+    if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_fused_tab<A_PAD, MRW, true>), lds_t, e->device)) return rc;
     hipLaunchKernelGGL((aog::k_fused_tab<A_PAD, MRW, true>), grid, dim3(threads), lds_t, s, reinterpret_cast<const aog::f16x8*>(e->modes16),
                        reinterpret_cast<const aog::f16x8*>(e->tab16), reinterpret_cast<const aog::f32x4*>(e->sci_tile),
                        reinterpret_cast<const aog::f32x4*>(e->psi_tile), reinterpret_cast<const aog::f16x8*>(e->act16), e->partials, g, ratio, dyn);
-    return;
+    return 0;
   }
-  aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_fused_tab<A_PAD, MRW, false>), lds_t, e->device);
+  if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_fused_tab<A_PAD, MRW, false>), lds_t, e->device)) return rc;
   hipLaunchKernelGGL((aog::k_fused_tab<A_PAD, MRW, false>), grid, dim3(threads), lds_t, s, reinterpret_cast<const aog::f16x8*>(e->modes16),
                      reinterpret_cast<const aog::f16x8*>(e->tab16), reinterpret_cast<const aog::f32x4*>(e->sci_tile),
                      reinterpret_cast<const aog::f32x4*>(e->psi_tile), reinterpret_cast<const aog::f16x8*>(e->act16), e->partials, g, ratio, dyn);
+  return 0;
 }
 
 template <int A_PAD, int MRW>
-void launch_fast2(aog_env* e, hipStream_t s) {
-  if (e->kernel == AOG_KERNEL_MFMA) {
-    launch_tab<A_PAD, MRW>(e, s);
-  } else {
-    if (e->sincos_hw) launch_valu<A_PAD, MRW, 1>(e, s); else launch_valu<A_PAD, MRW, 0>(e, s);
-  }
+int launch_fast2(aog_env* e, hipStream_t s) {
+  if (e->kernel == AOG_KERNEL_MFMA) return launch_tab<A_PAD, MRW>(e, s);
+  return e->sincos_hw ? launch_valu<A_PAD, MRW, 1>(e, s) : launch_valu<A_PAD, MRW, 0>(e, s);
 }
 
 template <int A_PAD>
-void launch_fast1(aog_env* e, hipStream_t s) {
+int launch_fast1(aog_env* e, hipStream_t s) {
 #ifdef AOG_FAST_BUILD  // developer builds: only the 8-table kernels
-  launch_fast2<A_PAD, 7>(e, s);
+  return launch_fast2<A_PAD, 7>(e, s);
 #else
   switch (e->MRW) {
-    case 7: launch_fast2<A_PAD, 7>(e, s); break;
-    case 12: launch_fast2<A_PAD, 12>(e, s); break;
-    case 20: launch_fast2<A_PAD, 20>(e, s); break;
-    default: launch_fast2<A_PAD, 28>(e, s); break;
+    case 7: return launch_fast2<A_PAD, 7>(e, s);
+    case 12: return launch_fast2<A_PAD, 12>(e, s);
+    case 20: return launch_fast2<A_PAD, 20>(e, s);
+    default: return launch_fast2<A_PAD, 28>(e, s);
   }
 #endif
 }
@@ -101,5 +100,5 @@ void launch_fast1(aog_env* e, hipStream_t s) {
 namespace aog_host {
 #define AOG_CAT2(a, b) a##b
 #define AOG_CAT(a, b) AOG_CAT2(a, b)
-void AOG_CAT(launch_fused_apad, AOG_INST_APAD)(aog_env* e, hipStream_t s) { launch_fast1<AOG_INST_APAD>(e, s); }
+int AOG_CAT(launch_fused_apad, AOG_INST_APAD)(aog_env* e, hipStream_t s) { return launch_fast1<AOG_INST_APAD>(e, s); }
 }  // namespace aog_host

@@ -19,6 +19,7 @@ the ranks for a central buffer.
 from __future__ import annotations
 
 import math
+import weakref
 
 
 def make_actor(state_dim: int, act_dim: int, hidden_dim: int, init_w: float = 3e-3, device=None):
@@ -63,13 +64,19 @@ def sample_action(mean, cov_var: float = 0.5, generator=None):
     return action, log_prob
 
 
+# rollout()'s DeviceActor per actor module.  Kept here, NOT on the module: a DeviceActor holds the ctypes library handle, which can be
+# neither deep-copied (target networks) nor pickled (torch.save of the module).  Weak keys, and DeviceActor only holds a weak
+# reference back to its module, so neither keeps the other alive.
+_DEVICE_ACTORS = weakref.WeakKeyDictionary()
+
+
 class DeviceActor:
     """The policy query (``Actor.forward`` + ``get_action``, network.py:48-69) as ONE library launch (``aog_actor_act``): the
     weights of a torch module built by ``make_actor`` (or any module exposing ``hidden`` = three ``nn.Linear`` and ``out``)
     are read in place on every call, so a learner may keep updating them.  Dropout masks / Gaussian noise come from the
     library's Philox streams keyed by (seed, call counter, GLOBAL env id, layer, unit), not from torch's generator.  Keep ONE
     instance alive for the whole training run: its call counter is what makes every query draw fresh masks and noise
-    (``rollout`` caches it on the actor module for that reason).  ``env_id_base`` = global id of obs row 0 (multi-GPU: the
+    (``rollout`` caches it per actor module for that reason).  ``env_id_base`` = global id of obs row 0 (multi-GPU: the
     env's ``global_env_offset``), so ranks explore with independent noise and a split batch reproduces the unsplit one."""
 
     def __init__(self, actor, seed: int = 0, dropout_p: float = 0.5, env_id_base: int = 0):
@@ -79,11 +86,18 @@ class DeviceActor:
 
         self._C, self._lib_mod = C, _lib
         self.lib = _lib.load()
-        self.actor = actor
+        self._actor_ref = weakref.ref(actor)
         self.seed = int(seed)
         self.dropout_p = float(dropout_p)
         self.env_id_base = int(env_id_base)
         self.calls = 0
+
+    @property
+    def actor(self):
+        a = self._actor_ref()
+        if a is None:
+            raise RuntimeError("DeviceActor: the actor module it was built for has been garbage-collected")
+        return a
 
     def __call__(self, obs, cov_var: float = 0.5, out=None):
         """obs [B, S] float16 or float32 on the GPU -> (action [B, A] float32, log_prob [B] float32, mean [B, A])."""
@@ -121,8 +135,8 @@ def rollout(env, actor, episodes: int = 1, cov_var: float = 0.5, gatherer=None, 
 
     ``actor_impl``: "hip" = the fused policy-query kernel (``DeviceActor``), "torch" = the module's own forward +
     ``sample_action``, "auto" = "hip" for CUDA modules with the ``make_actor`` structure.  The ``DeviceActor`` (and with it the
-    call counter of its random streams) persists across calls: pass one in as ``dev_actor``, or let this function cache it on
-    the actor module — a training loop that calls ``rollout`` once per iteration (algorithm.py:156) then explores with fresh
+    call counter of its random streams) persists across calls: pass one in as ``dev_actor``, or let this function cache it (in a
+    module-level weak dictionary keyed by the actor: the caller's module stays deep-copyable and picklable) — a training loop that calls ``rollout`` once per iteration (algorithm.py:156) then explores with fresh
     dropout masks and noise in every iteration, like the reference's torch generator does.  Returns a dict of device tensors
     shaped ``[T*E, B, ...]`` (obs, act, log_prob, rew, next_obs, done), ``ep_returns`` ``[E, B_global]`` (gathered over ranks
     when ``gatherer`` is distributed) and ``avg_ep_rew`` (the reference's logged scalar)."""
@@ -141,13 +155,10 @@ def rollout(env, actor, episodes: int = 1, cov_var: float = 0.5, gatherer=None, 
         dev_actor = None
     elif dev_actor is None:
         base = int(getattr(env, "global_env_offset", 0))
-        dev_actor = getattr(actor, "_aog_device_actor", None)
+        dev_actor = _DEVICE_ACTORS.get(actor)
         if dev_actor is None or dev_actor.seed != int(seed) or dev_actor.env_id_base != base or dev_actor.actor is not actor:
             dev_actor = DeviceActor(actor, seed=seed, env_id_base=base)
-            try:
-                object.__setattr__(actor, "_aog_device_actor", dev_actor)   # (plain attribute, not a registered submodule)
-            except Exception:
-                pass
+            _DEVICE_ACTORS[actor] = dev_actor
     import inspect
 
     step_takes_out = "out" in inspect.signature(env.step).parameters

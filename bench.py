@@ -14,7 +14,7 @@ Workloads (BASELINE.json ``configs``; per GPU, weak scaling — the global batch
   --config 2 (default, the headline line)  configs[1]: 1024 envs, quasi_static, 256x256 pupil, num_actuators A=64, o=2,
              strehl_ratio, 30-step episodes.  step = ``BatchedAOEnv.step``; every 30 steps ``reset()`` + all-gather of returns.
   --config 3  configs[2]: 4096 envs, semi_dynamic (requested atm_vel=10 is coerced to 0 like the reference), r0=0.15, o=5,
-             20-step episodes; every reset regenerates all screens on the device (oversampling 16).
+             20-step episodes; every reset regenerates all screens on the device (two-band synthesis, oversampling 16).
   --config 4  configs[3]'s per-GPU shard: 1024 envs, dynamic v=10 m/s (random direction per env), o=2, SAC-style rollout:
              policy query (fused actor kernel, hidden 150) + step + in-place transition writes, 30-step episodes.
   --config 5  configs[4]: 2048 envs, 512x512 pupil, zernike A=20, o=5, smf_ssim, SH_operation=True; step = ``SH_step`` + ``step``.
@@ -45,7 +45,8 @@ WORKLOADS = {
     3: dict(name="configs[2]", batch_per_gpu=4096, n_pupil=256, act_dim=64, obs_dim=5, atm_type="semi_dynamic", atm_vel=10, atm_fried=0.15,
             act_type="num_actuators", rew_type="strehl_ratio", timesteps_per_episode=20, SH_operation=False, rollout=False,
             text="batch=4096 envs/GPU, semi_dynamic (atm_vel=10 coerced to 0 like the reference) atm_fried=0.15, 256x256 pupil, 64 actuators, "
-                 "obs_dim=5, 20-step episodes; every reset regenerates all screens on the device (16x oversampled von Karman synthesis)"),
+                 "obs_dim=5, 20-step episodes; every reset regenerates all screens on the device (two-band von Karman synthesis: hcipy's 16x-oversampled "
+                 "grid below 2 cycles per pupil diameter + the (2N)^2 grid above; same covariance on the pupil to 2e-5 of the variance)"),
     4: dict(name="configs[3] per-GPU shard", batch_per_gpu=1024, n_pupil=256, act_dim=64, obs_dim=2, atm_type="dynamic", atm_vel=10, atm_fried=0.15,
             act_type="num_actuators", rew_type="strehl_ratio", timesteps_per_episode=30, SH_operation=False, rollout=True,
             text="batch=1024 envs/GPU (8192 over 8 GPUs), dynamic atmosphere v=10 m/s random direction per env, 256x256 pupil, 64 actuators, "
@@ -59,7 +60,9 @@ WORKLOADS = {
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 F16_MFMA_PEAK_TFLOPS = 2516.6  # MI355X_MICROARCH.md: dense f16/bf16 matrix peak (256 CUs x 4096 flop/clk x 2.4 GHz)
-VALU_ISSUE_PEAK = 256 * 4 * 2.4e9   # wave-instructions / s: 256 CUs x 4 SIMDs x 2.4 GHz, one vector instruction per SIMD and cycle
+F64_MFMA_PEAK_TFLOPS = 78.6     # v_mfma_f64_16x16x4_f64: 256 CUs x 4 SIMDs x 2048 flop / 64 clk x 2.4 GHz (tools/microbench/mfma_f64.hip: 77 measured)
+ISSUE_CYCLES_PEAK = 256 * 4 * 2.4e9   # SIMD issue cycles / s.  Issue-cycle model of a vector-bound kernel (MI355X_MICROARCH.md, row
+                                      # 'vector-instruction ISSUE cost'): 8 cycles per transcendental and per matrix instruction, 4 per other
 SPINUP_STEPS = 300           # steps (spin-up + warm-up) before the timed region: see main()
 PROFILE_EVERY = 8            # HIP events around one block of 8 launches of the fused kernel in 8 inside the timed region
 
@@ -130,9 +133,10 @@ def _host_cpus():
             usable = min(usable, max(1, int(float(q) / float(per))))
     except Exception:
         pass
-    # a 1-GPU box of this pool gives a job 16 host cores whatever the OS reports: never start more workers than that unless told to
+    # a 1-GPU box of this pool gives a job 16 host cores whatever the OS reports: the "share" figure never starts more workers than that
+    # unless told to; `usable` = min(affinity mask, cgroup quota) is what SURVEY.md section 8d(iii) asks for and is reported beside it
     cap = int(os.environ.get("AOG_CPU_WORKERS", "16"))
-    return total, max(1, min(usable, cap))
+    return total, max(1, usable), max(1, min(usable, cap))
 
 
 def _cpu_model():
@@ -169,20 +173,34 @@ def _run_cpu_workers(w, procs, threads, budget):
 def cpu_baseline(w, budget_s=8.0):
     """(i) 1 process x 1 BLAS thread, (ii) 1 process x default threads, (iii) one single-thread process per usable
     host core.  ``value`` is (iii), the fair "all host cores" number; the other two are in ``modes``."""
-    total, usable = _host_cpus()
+    total, usable, share = _host_cpus()
     one, _, n1 = _run_cpu_workers(w, 1, 1, budget_s)
     dflt, dthreads, n2 = _run_cpu_workers(w, 1, None, budget_s)
-    allc, _, n3 = _run_cpu_workers(w, usable, 1, budget_s)
+    shr, _, n3 = _run_cpu_workers(w, share, 1, budget_s)
+    # SURVEY.md section 8d(iii): one single-thread worker per core of min(affinity, cgroup).  Each worker holds ~0.5 GB (mode matrices,
+    # propagator tables): bounded by the memory the box has free; same budget, so the default run stays within minutes
+    allp, nall = usable, None
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable"):
+                allp = max(1, min(allp, int(int(ln.split()[1]) * 1024 * 0.5 / 0.6e9)))
+    except Exception:
+        pass
+    if allp > share:
+        allc, _, nall = _run_cpu_workers(w, allp, 1, budget_s)
+    else:
+        allc, allp, nall = shr, share, n3
     import numpy as np
 
-    return {"value": allc, "unit": "env-steps/s", "cores": int(usable), "kind": "port",
-            "modes": {"1proc_1thread": one, "1proc_default_threads": dflt, "default_threads": int(dthreads),
-                      f"{usable}procs_1thread": allc},
-            "cpu_model": _cpu_model(), "os_cpu_count": int(total), "usable_cores": int(usable), "numpy": np.__version__,
+    modes = {"1proc_1thread": one, "1proc_default_threads": dflt, "default_threads": int(dthreads), f"{share}procs_1thread": shr}
+    modes[f"{allp}procs_1thread"] = allc
+    return {"value": allc, "unit": "env-steps/s", "cores": int(allp), "kind": "port", "modes": modes,
+            "cpu_model": _cpu_model(), "os_cpu_count": int(total), "usable_cores": int(usable), "share_cores": int(share), "numpy": np.__version__,
             "sample": f"single-env steps of the float64 numpy restatement of the literal HCIPy dataflow (not HCIPy itself) at N={w['n_pupil']}, "
                       f"A={w['act_dim']}, o={w['obs_dim']}, {w['rew_type']}: {n1} steps in {budget_s:.0f} s (1 process, 1 BLAS thread), {n2} steps in "
-                      f"{budget_s:.0f} s (1 process, {dthreads} BLAS threads), {n3} steps in {budget_s:.0f} s ({usable} processes x 1 thread = the cores "
-                      f"this job may use: min(affinity, cgroup quota, 16 per GPU of the box); the OS reports {total})"}
+                      f"{budget_s:.0f} s (1 process, {dthreads} BLAS threads), {n3} steps in {budget_s:.0f} s ({share} processes x 1 thread = the host "
+                      f"share of one GPU of this pool), {nall} steps in {budget_s:.0f} s ({allp} processes x 1 thread = min(affinity, cgroup quota"
+                      f"{', memory' if allp < usable else ''}) = `value`; the OS reports {total} logical cores)"}
 
 
 def parity_check(env, w, actions, torch):
@@ -209,6 +227,64 @@ def parity_check(env, w, actions, torch):
     return out
 
 
+def roofline_dominant(env, w, kernels, steps_range):
+    """Rooflines of the kernels that dominate the workloads other than config 2, from HIP events taken inside the timed region (every
+    launch of these kernels is bracketed on its stream while profiling is on: ``aog_profile_read_kernel``).
+      screen synthesis passes (config 3)  instruction issue: issue cycles per env from the tracked PMC summary (a citation, like
+                                          ``roofline.traffic``) / measured time, against 1024 SIMDs x 2.4 GHz
+      screen packing (config 3)           HBM: 4 N^2 read + 4 n_ap written per env
+      extrusion (config 4)                float64 matrix cores: 2 N (nz + N) flop per one-pixel shift of one env (new = A z + B n)
+      Shack-Hartmann passes (config 5)    HBM: the three-pass layout's 72 N^2 bytes per env"""
+    import numpy as np
+
+    N, B = w["n_pupil"], env.num_envs
+    out = {}
+    cite = {}
+    try:
+        cite = json.load(open(os.path.join(ROOT, "profiles", "reset_pmc_latest.json")))
+    except Exception:
+        pass
+    for name, kname in (("screen_rows", "k_screen2_rows"), ("screen_cols", "k_screen2_cols")):
+        if name in kernels:
+            ms, n = kernels[name]
+            e = {"kernel": kname, "bound": "valu_issue", "ms": ms, "launches": n, "us_per_env": ms * 1e3 / B}
+            c = cite.get(kname)
+            if c and c.get("issue_cycles") and cite.get("envs_per_launch"):
+                cyc = c["issue_cycles"] / cite["envs_per_launch"] * B
+                e.update(achieved=cyc / (ms * 1e-3), peak=ISSUE_CYCLES_PEAK, unit="SIMD issue cycles/s", frac=cyc / (ms * 1e-3) / ISSUE_CYCLES_PEAK,
+                         note="issue cycles per env from profiles/reset_pmc_latest.json (PMC citation), time from this run's HIP events")
+            out[name] = e
+    if "pack" in kernels:
+        ms, n = kernels["pack"]
+        by = (4.0 * N * N + 4.0 * env.info.n_ap_padded) * B
+        out["pack"] = {"kernel": "k_screen_means + k_pack_tiles", "bound": "hbm", "ms": ms, "launches": n, "achieved": by / (ms * 1e-3) / 1e9,
+                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       "note": "algorithmic bytes: 4 N^2 read + 4 n_ap written per env (the kernels read the screen twice: mean, then conversion)"}
+    if "extrude" in kernels and getattr(env, "_layer", None) is not None:
+        from adaptive_optics_gym_amd.atmosphere_host import integer_shifts
+
+        ms, n = kernels["extrude"]
+        shifts = 0
+        for t in range(steps_range[0], steps_range[1]):
+            sh = integer_shifts(env.velocity_vectors, t * env.delta_t, (t + 1) * env.delta_t, env.params.pupil_pixel)
+            shifts += int(np.abs(sh).sum())
+        nz = int(max(env._layer["stencil_vertical"].size, env._layer["stencil_horizontal"].size))
+        flop = 2.0 * N * (nz + N) * shifts
+        out["extrude"] = {"kernel": "k_extrude16_split", "bound": "mfma_f64", "ms": ms, "launches": n, "achieved": flop / (ms * 1e-3 * n) / 1e12,
+                          "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flop / (ms * 1e-3 * n) / 1e12 / F64_MFMA_PEAK_TFLOPS,
+                          "shifts_per_env_step": shifts / max(1, B * (steps_range[1] - steps_range[0])),
+                          "note": "2 N (nz + N) flop per one-pixel shift of one env, shifts recomputed on the host for the timed steps; the "
+                                  "event bracket includes the launch's ticket zero-fill"}
+    if all(k in kernels for k in ("sh_rows_fwd", "sh_cols", "sh_rows_inv")):
+        ms = sum(kernels[k][0] for k in ("sh_rows_fwd", "sh_cols", "sh_rows_inv"))
+        by = 72.0 * N * N * B
+        out["shack_hartmann"] = {"kernel": "k_sh_rows_fwd + k_sh_cols + k_sh_rows_inv", "bound": "hbm", "ms": ms, "launches": kernels["sh_cols"][1],
+                                 "per_pass_ms": {k: kernels[k][0] for k in ("sh_field", "sh_rows_fwd", "sh_cols", "sh_rows_inv") if k in kernels},
+                                 "achieved": by / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "note": "three-pass layout bytes per env: field 8 N^2 read, F1T and GT (2N x N complex64 each) written and read once"}
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------------------------------------
 def spawn_ranks(args, argv):
     """--gpus N without a launcher: start the N ranks as children (this process has not touched the GPU and never will)."""
@@ -224,11 +300,22 @@ def spawn_ranks(args, argv):
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
     rc = 0
-    for p in procs:
-        p.wait()
-        rc = rc or p.returncode
+    live = list(procs)
+    while live and not rc:            # poll every rank: a failed one must not leave its siblings waiting in a collective until it times out
+        time.sleep(0.05)
+        for p in list(live):
+            if p.poll() is not None:
+                live.remove(p)
+                rc = rc or p.returncode
     if rc:
-        print(f"bench.py: a rank exited with status {rc}", file=sys.stderr)
+        for p in live:
+            p.terminate()
+        for p in live:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        print(f"bench.py: a rank exited with status {rc}; the other ranks were stopped", file=sys.stderr)
     return rc
 
 
@@ -357,11 +444,14 @@ def main():
     run(args.warmup)
     fence()
     env.profile_read()                       # discard the warm-up's samples; timing stays on
+    t_first = env.timestep                   # (python-side step counter: the extrusion's shift count of the timed region is recomputed from it)
     t0 = time.perf_counter()
     run(args.steps)
     fence()
     dt = time.perf_counter() - t0
+    steps_range = (t_first, env.timestep)
     kernel_ms, launches = env.profile_read()
+    other_kernels = env.profile_kernels()    # {name: (mean ms, launches)}: reset / extrusion / Shack-Hartmann kernels timed in the same region
     env.profile(False)
     status = env.device_status()
     if distributed:
@@ -394,11 +484,12 @@ def main():
         mfma_flops = (3 * 2 * a_pad + 2 * 3 * 2 * 32) * n_pix_pad * env.info.num_envs_padded
         result = {
             "metric": "env_steps_per_sec", "value": world * B * args.steps / dt, "unit": "env-steps/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "steps": args.steps, "warmup": args.warmup, "warmup_effective": args.warmup + spinup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{w['name']}: {w['text']}", "batch_per_gpu": B, "global_batch": total, "n_pupil": w["n_pupil"],
                        "act_dim": w["act_dim"], "obs_dim": w["obs_dim"], "atm_type": w["atm_type"],
                        "kernel": {1: "valu", 2: "mfma"}.get(env.info.kernel, "ref"), "spinup_steps": spinup,
+                       "collective_backend": (dist.get_backend() if distributed else "none (single process)"),
                        "parallelism": f"envs sharded over {world} GPU(s) by global env id, no data-path collective; one all-gather of "
                                       f"episode returns per episode"},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -409,16 +500,24 @@ def main():
                          "f16_mfma": {"achieved": mfma_flops / k_s / 1e12, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                       "frac": mfma_flops / k_s / 1e12 / F16_MFMA_PEAK_TFLOPS,
                                       "note": "matrix flops as issued (split-f16: 3 products per operand pair, padded tiles)"},
-                         "valu_issue": ({"achieved": pmc["valu_insts_per_launch"] / k_s, "peak": VALU_ISSUE_PEAK, "unit": "wave-instructions/s",
-                                         "frac": pmc["valu_insts_per_launch"] / k_s / VALU_ISSUE_PEAK,
-                                         "note": "SQ_INSTS_VALU per launch (PMC, profiles/traffic_latest.json) / kernel time, against one vector "
-                                                 "instruction per SIMD and cycle"} if pmc.get("valu_insts_per_launch") else None),
+                         "valu_issue": None,   # filled below when the PMC citation is there
                          "note": "achieved = algorithmic bytes (SURVEY.md 8d: 4 N^2 + ... per env-step) x envs per launch / mean HIP-event "
                                  "duration of the fused kernel over the timed region (one block of 8 launches in 8 carries the two event "
                                  "records); achieved_layout = the same with the bytes the aperture-packed layout must move (4 n_ap per "
                                  "screen); traffic = PMC (2*FETCH_SIZE + WRITE_SIZE) per launch from profiles/traffic_latest.json; "
                                  "6.29 TB/s is the measured copy ceiling"},
         }
+        if pmc.get("valu_insts_per_launch") and pmc.get("trans_insts_per_launch") is not None:
+            tr_, mf_ = pmc["trans_insts_per_launch"], pmc.get("mfma_insts_per_launch", 0.0)
+            cyc = 8 * tr_ + 8 * mf_ + 4 * (pmc["valu_insts_per_launch"] - tr_ - mf_)
+            result["roofline"]["valu_issue"] = {
+                "achieved": cyc / k_s, "peak": ISSUE_CYCLES_PEAK, "unit": "SIMD issue cycles/s", "frac": cyc / k_s / ISSUE_CYCLES_PEAK,
+                "note": "issue cycles per launch = 8 x transcendental + 8 x matrix + 4 x other vector instructions (SQ_INSTS_VALU, "
+                        "SQ_INSTS_VALU_TRANS_F32, SQ_INSTS_MFMA per launch: PMC citation from profiles/traffic_latest.json, not measured in "
+                        "this run) / this run's kernel time, against 1024 SIMDs x 2.4 GHz; the binding resource of this kernel"}
+        dom = roofline_dominant(env, w, other_kernels, steps_range)
+        if dom:
+            result["roofline_dominant"] = dom
         if not args.no_parity and w["atm_type"] == "quasi_static" and not w["SH_operation"]:
             result["parity"] = parity_check(env, w, actions[0], torch)
         if not args.no_cpu_baseline and world == 1:

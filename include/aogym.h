@@ -292,6 +292,14 @@ int aog_actor_act(const aog_actor* net, int device, const void* obs_dev, int obs
  * flavour 0 = polynomial, 1 = v_sin_f32/v_cos_f32 after the exact reduction, 2 = v_sin_f32/v_cos_f32 on raw input. */
 int aog_selftest_sincos(const float* u_dev, float* sin_dev, float* cos_dev, int n, int flavour, void* stream);
 
+/* Self-test hook for the failure path of the dynamic atmosphere's inter-workgroup barrier (k_extrude16_split): runs the wind extrusion of
+ * one step with one of every group's four workgroups absent and a short poll limit, so the partners' bounded wait gives up exactly as it
+ * would if they were not co-resident.  Synchronises.  Afterwards aog_device_status() reports 1 and aog_step / aog_reset fail with
+ * AOG_ERR_STATE until new screens are installed for the whole batch or a state is restored; the handle's screens are invalid (that is the
+ * point).  Envs must move by at least one pixel in the step for a barrier to be reached.  AOG_ERR_UNSUPPORTED for handles that do not
+ * use the split extrusion kernel. */
+int aog_selftest_barrier_timeout(aog_env* env, void* stream);
+
 /* Microseconds-resolution timing of the dominant (fused) kernel of the most recent aog_step/aog_reset calls,
  * measured with HIP events on the stream the kernel was launched on.  Enable, run steps, then read the
  * mean duration (ms) and the number of launches averaged.  enable = n > 1 times one block of 8 consecutive launches in n only: the two event records
@@ -299,6 +307,22 @@ int aog_selftest_sincos(const float* u_dev, float* sin_dev, float* cos_dev, int 
  * every step. */
 int aog_profile_enable(aog_env* env, int enable);
 int aog_profile_read(aog_env* env, double* mean_ms, int* launches);
+/* While profiling is enabled the kernels that dominate the other workloads are timed the same way (HIP events on the launch stream,
+ * every launch: they run once per reset or take >= 100 us): which = one of AOG_PROF_*; returns the mean duration and the number of launches
+ * collected by the LAST aog_profile_read (which drains the events of every kernel).  AOG_PROF_FUSED repeats that call's own result. */
+enum {
+  AOG_PROF_FUSED = 0,        /* k_fused_tab / k_fused_valu / k_fused_ref                                   */
+  AOG_PROF_SCREEN_ROWS = 1,  /* k_screen2_rows / k_screen_rows: spectrum draw + row transforms (K8 pass A) */
+  AOG_PROF_SCREEN_COLS = 2,  /* k_screen2_cols / k_screen_cols (K8 pass B)                                 */
+  AOG_PROF_PACK = 3,         /* k_screen_means + k_pack_tiles (or k_pack_screens) of a screen installation */
+  AOG_PROF_EXTRUDE = 4,      /* k_extrude16_split / k_extrude16 / k_extrude (K7)                           */
+  AOG_PROF_SH_FIELD = 5,     /* k_phase_mfma<FIELD> (K10)                                                  */
+  AOG_PROF_SH_ROWS_FWD = 6,  /* k_sh_rows_fwd                                                              */
+  AOG_PROF_SH_COLS = 7,      /* k_sh_cols                                                                  */
+  AOG_PROF_SH_ROWS_INV = 8,  /* k_sh_rows_inv (+ photon noise + lenslet sums when fused)                   */
+  AOG_PROF_COUNT = 9
+};
+int aog_profile_read_kernel(aog_env* env, int which, double* mean_ms, int* launches);
 
 #ifdef __cplusplus
 }

@@ -74,8 +74,8 @@ class ScriptedRNG:
 
 
 def device_mode_stencil_draws(seed, total_envs, n):
-    """The two ``geometric(0.5, n)`` stencil draws of a ``BatchedAOEnv(screen_source='device', seed=seed, total_envs=...)``: its
-    host stream is RandomState(seed): rand(total_envs) wind directions, then the draws of build_layer_tables."""
-    r = np.random.RandomState(seed)
-    r.rand(total_envs)
+    """The two ``geometric(0.5, n)`` stencil draws of a ``BatchedAOEnv(screen_source='device', seed=seed, total_envs=...)``: the stencils
+    come from a stream of their own, RandomState([seed, 0x57E9C11]) — independent of ``total_envs`` (wind directions are
+    RandomState(seed).rand(total_envs)), so instances holding different slices of one batch share the AR matrices."""
+    r = np.random.RandomState([int(seed) & 0xFFFFFFFF, 0x57E9C11])
     return [r.geometric(0.5, n), r.geometric(0.5, n)]

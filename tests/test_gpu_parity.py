@@ -90,8 +90,8 @@ def _compare(got, ref, strehl_reward):
 
 
 @pytest.mark.parametrize("precision,kernel", KERNELS)
-@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))),
-                         ids=lambda p: os.path.basename(p)[:-4])
+@pytest.mark.parametrize("path", sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))
+                                        if not os.path.basename(p).startswith("ref_")), ids=lambda p: os.path.basename(p)[:-4])
 def test_golden_fixtures(path, precision, kernel):
     torch = _torch()
     from adaptive_optics_gym_amd import BatchedAOEnv
@@ -105,6 +105,33 @@ def test_golden_fixtures(path, precision, kernel):
     ref = {k[4:]: z[k] for k in z.files if k.startswith("exp_")}
     _compare(got, ref, kw["rew_type"] == "strehl_ratio")
     _loaded_native()
+    env.close()
+
+
+_REF_FIXTURES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "ref_*.npz")))
+
+
+@pytest.mark.skipif(not _REF_FIXTURES, reason="no tests/golden/ref_*.npz (hcipy-derived vectors of `tools/make_golden.py --from-reference`): hcipy is not "
+                    "importable in the build image")
+@pytest.mark.parametrize("path", _REF_FIXTURES or [None], ids=lambda p: os.path.basename(p)[:-4] if p else "absent")
+def test_reference_derived_fixtures(path):
+    """The HIP path against outputs of the reference's OWN AOEnv (hcipy) on a recorded screen and actions, N = 240: north_star's 1e-5."""
+    torch = _torch()
+    from adaptive_optics_gym_amd import BatchedAOEnv
+
+    z = np.load(path)
+    kw = ast.literal_eval(str(z["kw"]))
+    env = BatchedAOEnv(1, "cuda:0", num_pupil_pixels=240, screens=z["screen"].reshape(1, 240, 240), verbose=False, **kw)
+    env.reset()
+    _assert_obs_close(env.last_obs_raw[0].double().cpu().numpy(), z["obs0_raw"])
+    for t, a in enumerate(z["actions"]):
+        _, r, d, _, info = env.step(torch.from_numpy(a[None].astype(np.float32)).cuda())
+        _assert_obs_close(info["obs_raw"][0].double().cpu().numpy(), z["exp_obs_raw"][t])
+        np.testing.assert_allclose(float(r[0]), z["exp_reward"][t], rtol=RTOL, atol=100 * RTOL if kw["rew_type"] == "strehl_ratio" else 1e-7)
+        np.testing.assert_allclose(float(info["power"][0]), z["exp_power"][t], rtol=RTOL)
+        assert bool(d[0]) == bool(z["exp_done"][t])
+        if bool(d[0]):
+            env.reset()
     env.close()
 
 

@@ -83,3 +83,47 @@ def test_replay_transitions_match_per_env_collection():
         torch.testing.assert_close(rw2[b * T * E:(b + 1) * T * E], out["rew"][:, b])
         assert torch.equal(ns2[b * T * E:(b + 1) * T * E - 1][: T - 1], st2[b * T * E + 1:b * T * E + T])   # next_state of t = state of t + 1
     assert int(dn.sum()) == E * B
+
+
+class _PicklableActor(torch.nn.Module):
+    """Module-level class (picklable) with the structure DeviceActor reads: ``hidden`` = three Linear layers, ``out``."""
+
+    def __init__(self):
+        super().__init__()
+        self.hidden = torch.nn.ModuleList([torch.nn.Linear(4, 8), torch.nn.Linear(8, 8), torch.nn.Linear(8, 8)])
+        self.out = torch.nn.Linear(8, 3)
+
+    def forward(self, x):
+        for layer in self.hidden:
+            x = torch.relu(layer(x.float()))
+        return self.out(x)
+
+
+def test_device_actor_cache_leaves_the_module_copyable_and_picklable():
+    """rollout() keeps its DeviceActor (which holds the ctypes library handle) in a weak dictionary beside the module, not on it:
+    target-network deep copies and torch.save of the module keep working after a rollout, and nothing outlives the module."""
+    import copy
+    import gc
+    import io
+    import pickle
+
+    from adaptive_optics_gym_amd import rollout as ro
+
+    actor = _PicklableActor()
+    da = ro.DeviceActor(actor, seed=3)          # loads libaogym.so (no GPU call)
+    ro._DEVICE_ACTORS[actor] = da               # what rollout(actor_impl="hip") does
+    assert ro._DEVICE_ACTORS.get(actor) is da and da.actor is actor
+    assert not any("aog" in k for k in vars(actor))          # nothing was attached to the caller's module
+    twin = copy.deepcopy(actor)
+    assert twin is not actor and ro._DEVICE_ACTORS.get(twin) is None
+    pickle.loads(pickle.dumps(actor))
+    torch.save(actor, io.BytesIO())
+    n_before = len(ro._DEVICE_ACTORS)
+    del actor, twin
+    gc.collect()
+    assert len(ro._DEVICE_ACTORS) == n_before - 1            # the cache entry went with the module
+    try:
+        da.actor
+        raise AssertionError("expected RuntimeError")
+    except RuntimeError:
+        pass
