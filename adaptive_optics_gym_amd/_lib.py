@@ -94,6 +94,7 @@ SYMBOLS = {
     "aog_step": (C.c_int, [C.c_void_p] * 9),
     "aog_focal_image": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "aog_focal_images": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "aog_selftest_poisson": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_void_p]),
     "aog_selftest_barrier_timeout": (C.c_int, [C.c_void_p, C.c_void_p]),
     "aog_selftest_sincos": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "aog_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),

@@ -1782,6 +1782,14 @@ int aog_selftest_barrier_timeout(aog_env* e, void* stream) {
   return AOG_OK;
 }
 
+int aog_selftest_poisson(const double* lam_dev, double* out_dev, int n_env, int n, uint64_t seed, uint32_t call, void* stream) {
+  if (!lam_dev || !out_dev || n_env < 1 || n < 1) return fail(AOG_ERR_INVALID, "aog_selftest_poisson: bad argument");
+  hipLaunchKernelGGL(aog::k_sh_noise, dim3((unsigned)((n * n + 255) / 256), n_env), dim3(256), 0, static_cast<hipStream_t>(stream), lam_dev, out_dev, n,
+                     (size_t)0, (unsigned long long)seed, call);
+  HIP_TRY(hipGetLastError());
+  return AOG_OK;
+}
+
 int aog_selftest_sincos(const float* u_dev, float* sin_dev, float* cos_dev, int n, int flavour, void* stream) {
   if (!u_dev || !sin_dev || !cos_dev || n < 0 || flavour < 0 || flavour > 2) return fail(AOG_ERR_INVALID, "aog_selftest_sincos: bad argument");
   if (n == 0) return AOG_OK;

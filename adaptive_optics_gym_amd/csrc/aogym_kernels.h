@@ -3230,27 +3230,29 @@ __device__ __forceinline__ void sh_noise_words(size_t line, uint32_t group, bool
   w[0] = c[0]; w[1] = c[1]; w[2] = c[2]; w[3] = c[3];
 }
 constexpr double kShPoissonSwitch = 12.0;
-// Poisson(lam), lam < 12, by inversion on a 32-bit uniform.  exp(-lam) in fp32 (relative error ~1e-7: the uniform is shrunk by 4e-7 so that
-// the accumulated distribution always reaches it), terms and sum in float64.  The wave walks the terms in lockstep (k is wave-uniform,
-// 1 / k comes from a scalar table) until its last lane is done: at most ~30 terms below the switch.
-struct RcpTable { double v[64]; };
-__device__ constexpr RcpTable make_rcp_table() {
-  RcpTable t{};
-  t.v[0] = 0.0;
-  for (int k = 1; k < 64; ++k) t.v[k] = 1.0 / (double)k;
-  return t;
-}
-__constant__ const RcpTable kShRcp = make_rcp_table();
-__device__ __forceinline__ double sh_poisson_small(double lam, uint32_t word, bool active) {
-  const double u = active ? ((double)word + 0.5) * (1.0 / 4294967296.0) * (1.0 - 4e-7) : 0.0;
-  double pk = (double)__expf(-(float)lam), cdf = pk;
-  int kres = 0;
-  for (int k = 1; k < 64; ++k) {
-    const bool more = u > cdf;
-    if (!__any(more ? 1 : 0)) break;
-    const double rk = kShRcp.v[k];
-    if (more) { pk *= lam * rk; cdf += pk; kres = k; }
+// Poisson(lam), lam < 12, by inversion on a 32-bit uniform: k = number of partial sums of the pmf that stay below u.  The wave walks the
+// terms in lockstep (k is wave-uniform, 1 / k is an immediate), FOUR terms per round of the "is any lane still below its u" vote, in fp32:
+// the pmf recurrence p_k = p_{k-1} lam / k and its running sum carry ~1e-6 relative error, i.e. the sampled law differs from Poisson(lam)
+// by ~1e-6 in total variation (the uniform is shrunk by 4e-6 so that the accumulated distribution always reaches it) — three orders
+// below what a chi-square test on 1e6 draws resolves (tests: test_device_poisson_sampler_matches_scipy).  Round 2's form (float64 terms,
+// one vote per term) spent ~70 cycles per term and was half of the fused row pass; this one spends ~25.  At most 48 terms: P(k > 47 | 12) < 1e-14.
+template <int K0>
+__device__ __forceinline__ void sh_poisson_terms(float lam, float u, float& pk, float& cdf, int& kres) {
+  if (!__any(u > cdf ? 1 : 0)) return;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    kres += u > cdf ? 1 : 0;                   // (the sum only grows: once u <= cdf the lane stops counting)
+    pk *= lam * (1.0f / (float)(K0 + j));      // compile-time reciprocal
+    cdf += pk;
   }
+  if constexpr (K0 + 4 < 48) sh_poisson_terms<K0 + 4>(lam, u, pk, cdf, kres);
+}
+__device__ __forceinline__ double sh_poisson_small(double lam_d, uint32_t word, bool active) {
+  const float lam = (float)lam_d;
+  const float u = active ? ((float)(word >> 8) + 0.5f) * (1.0f / 16777216.0f) * (1.0f - 4e-6f) : 0.0f;
+  float pk = __expf(-lam), cdf = pk;
+  int kres = 0;
+  sh_poisson_terms<1>(lam, u, pk, cdf, kres);
   return (double)kres;
 }
 // rounded normal approximation with the Cornish-Fisher skewness term (matches mean, variance and third moment of Poisson(lam))

@@ -292,6 +292,11 @@ int aog_actor_act(const aog_actor* net, int device, const void* obs_dev, int obs
  * flavour 0 = polynomial, 1 = v_sin_f32/v_cos_f32 after the exact reduction, 2 = v_sin_f32/v_cos_f32 on raw input. */
 int aog_selftest_sincos(const float* u_dev, float* sin_dev, float* cos_dev, int n, int flavour, void* stream);
 
+/* Self-test hook: the Shack-Hartmann camera's photon noise (large_poisson, AO_env.py:272-275) on caller-supplied expected counts:
+ * lam_dev / out_dev [n_env][n][n] float64, drawn by the same device code and Philox keying (env, row, column, call) as aog_sh_update(NULL) and the
+ * fused row pass.  For distribution tests of the sampler (exact inversion below 12 counts, skew-corrected rounded normal above). */
+int aog_selftest_poisson(const double* lam_dev, double* out_dev, int n_env, int n, uint64_t seed, uint32_t call, void* stream);
+
 /* Self-test hook for the failure path of the dynamic atmosphere's inter-workgroup barrier (k_extrude16_split): runs the wind extrusion of
  * one step with one of every group's four workgroups absent and a short poll limit, so the partners' bounded wait gives up exactly as it
  * would if they were not co-resident.  Synchronises.  Afterwards aog_device_status() reports 1 and aog_step / aog_reset fail with

@@ -994,6 +994,51 @@ def test_shack_hartmann_device_noise_closed_loop():
     env.close()
 
 
+@pytest.mark.parametrize("lam", [0.02, 0.5, 3.0, 11.0, 11.99, 40.0, 2000.0])
+def test_device_poisson_sampler_matches_scipy(lam):
+    """The camera's photon-noise sampler (``large_poisson``, AO_env.py:272-275; device: exact inversion below 12 counts walked four terms
+    per wave vote in fp32, skew-corrected rounded normal above) against ``scipy.stats.poisson``: chi-square of 1.05 M draws over the bins
+    with expectation >= 20, plus mean / variance / third central moment.  Below the switch the law is Poisson to ~1e-6 in total
+    variation, so the statistic is chi-square distributed; above it the rounded normal matches three moments but not every bin, so there
+    only the moments are held (the sensor reads flux-weighted centroids)."""
+    import ctypes as C
+
+    from scipy import stats
+
+    torch = _torch()
+    from adaptive_optics_gym_amd import _lib
+
+    lib = _lib.load()
+    n_env, n = 16, 256
+    x = torch.full((n_env, n, n), float(lam), dtype=torch.float64, device="cuda")
+    out = torch.empty_like(x)
+    _lib.check(lib.aog_selftest_poisson(C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), n_env, n, 77, 3, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    k = out.cpu().numpy().ravel()
+    assert np.all(k >= 0) and np.all(k == np.rint(k))
+    m = k.size
+    se_mean = np.sqrt(lam / m)
+    assert abs(k.mean() - lam) < 5 * se_mean
+    assert abs(k.var() - lam) < 5 * lam * np.sqrt(2.0 / m + 1.0 / (lam * m))           # var of the sample variance of a Poisson law
+    mu3 = np.mean((k - k.mean()) ** 3)
+    assert abs(mu3 - lam) < 6 * np.sqrt((15 * lam ** 3 + 25 * lam ** 2 + lam) / m) + 0.02 * lam   # third central moment of Poisson = lam
+    if lam < 12:
+        kmax = int(k.max())
+        obs = np.bincount(k.astype(np.int64), minlength=kmax + 1).astype(np.float64)
+        exp = stats.poisson.pmf(np.arange(kmax + 1), lam) * m
+        keep = exp >= 20
+        obs_k, exp_k = obs[keep], exp[keep]
+        obs_rest, exp_rest = obs[~keep].sum(), m - exp_k.sum()
+        chi2 = ((obs_k - exp_k) ** 2 / exp_k).sum() + ((obs_rest - exp_rest) ** 2 / exp_rest if exp_rest >= 5 else 0.0)
+        dof = keep.sum() - 1 + (1 if exp_rest >= 5 else 0)
+        assert chi2 < stats.chi2.ppf(1 - 1e-4, dof), (chi2, dof)
+    # different call index / env: different draws
+    _lib.check(lib.aog_selftest_poisson(C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), n_env, n, 77, 4, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    k2 = out.cpu().numpy().ravel()
+    assert not np.array_equal(k, k2) and not np.array_equal(k[:n * n], k[n * n:2 * n * n])
+
+
 def test_state_save_restore_resumes_bit_identically():
     """get_state / set_state (checkpointing; the reference has none for the env): a dynamic-atmosphere batch with Shack-Hartmann
     state resumes from a snapshot with bit-identical observations, rewards and screens."""

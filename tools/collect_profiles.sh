@@ -5,7 +5,7 @@
 # PMC tables of the fused kernel, HBM traffic) and profiles/<tag>_next_rows.md (kernel stats of bench.py --config 3/4/5, the K4 and
 # Shack-Hartmann loops).  Counters are collected in their own passes with --kernel-trace only.
 # gpurun only brings gpurun_out/ back: run the collection on the box, then `bash tools/collect_profiles.sh r02 summarize` here.
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 if [ "$2" != "summarize" ]; then
@@ -28,11 +28,30 @@ python3 $R/tools/k4_loop.py > $OUT/${TAG}_k4_loop.log 2>&1
 python3 $R/tools/dyn_loop.py 1024 200 > $OUT/${TAG}_dyn_loop.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_sh -- python3 $R/tools/sh_loop2.py 1024 256 64 single > $OUT/${TAG}_prof_sh.log 2>&1
 python3 $R/tools/single_env_latency.py > $OUT/${TAG}_single.log 2>&1
+# 4. config-2 shape at B = 4096 (screens + tables 0.9 GB: four times the 256 MiB Infinity Cache): bench line, kernel stats, PMC of the fused kernel
+python3 $R/bench.py --batch 4096 --no-cpu-baseline --no-parity > $OUT/${TAG}_bench_c2_b4096.json 2> $OUT/${TAG}_bench_c2_b4096.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_c2_b4096 -- python3 $R/bench.py --batch 4096 --no-cpu-baseline --no-parity > $OUT/${TAG}_prof_c2_b4096.log 2>&1
+bash $R/tools/pmc_collect.sh gpurun_out/${TAG}_pmc_b4096 --B 4096 > $OUT/${TAG}_pmc_b4096.log 2>&1
+# 5. PMC of the reset kernels (semi_dynamic reset of 4096 envs: two-band synthesis + packing) and of the other rows' dominant kernels
+bash $R/tools/pmc_kernels.sh gpurun_out/${TAG}_pmc_reset $R/tools/reset_loop.py --B 4096 --episodes 1 > $OUT/${TAG}_pmc_reset.log 2>&1
 fi
 cd $R
 # 4. summaries (from the raw files under gpurun_out/)
 python3 tools/summarize_prof.py --stats gpurun_out/${TAG}_prof_c2 --pmc gpurun_out/${TAG}_pmc --pmc-mem gpurun_out/${TAG}_pmc_mem --tag ${TAG}_config2 \
         --bench-json gpurun_out/${TAG}_bench_c2.json > /dev/null
+python3 tools/summarize_prof.py --stats gpurun_out/${TAG}_prof_c2_b4096 --pmc gpurun_out/${TAG}_pmc_b4096 --tag ${TAG}_config2_b4096 \
+        --bench-json gpurun_out/${TAG}_bench_c2_b4096.json --traffic-json ${TAG}_traffic_b4096.json > /dev/null
+{
+  echo "# ${TAG}_reset_pmc — counters of the semi_dynamic reset kernels (tools/reset_loop.py --B 4096 --episodes 1: launches of 4096 envs)"; echo
+  python3 tools/summarize_pmc.py gpurun_out/${TAG}_pmc_reset --tag ${TAG}_reset --kernels k_screen2_rows k_screen2_cols k_screen_means k_pack_tiles
+} > profiles/${TAG}_reset_pmc.md
+python3 - <<PY
+import json
+d = json.load(open("profiles/${TAG}_reset_pmc.json"))
+d["envs_per_launch"] = 4096
+d["source"] = "${TAG}_reset_pmc"
+json.dump(d, open("profiles/reset_pmc_latest.json", "w"), indent=1)
+PY
 {
   echo "# ${TAG}_next_rows — bench lines and per-kernel time of the other BASELINE configs and of the SURVEY 8(f) rows (rocprofv3 --kernel-trace --stats, 1x MI355X)"
   echo

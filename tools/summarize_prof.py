@@ -14,6 +14,7 @@ import argparse, collections, csv, glob, json, os
 ap = argparse.ArgumentParser()
 ap.add_argument("--stats"); ap.add_argument("--pmc"); ap.add_argument("--pmc-mem"); ap.add_argument("--tag", required=True)
 ap.add_argument("--bench-json"); ap.add_argument("--out", default="profiles")
+ap.add_argument("--traffic-json", default="traffic_latest.json", help="name of the JSON the fused kernel's traffic / instruction counts go to ('' = none)")
 args = ap.parse_args()
 os.makedirs(args.out, exist_ok=True)
 lines = [f"# {args.tag}", ""]
@@ -67,7 +68,7 @@ if args.pmc:
                         lines.append(f"- {c} / SQ_WAVE_CYCLES = {sum(v[c]) / len(v[c]) / wc:.3f}")
                 lines.append("")
 open(os.path.join(args.out, args.tag + ".md"), "w").write("\n".join(lines) + "\n")
-if traffic is not None:
+if traffic is not None and args.traffic_json:
     json.dump({"hbm_bytes_per_launch": traffic, "source": args.tag, **{k: x for k, x in extra.items() if x is not None}},
-              open(os.path.join(args.out, "traffic_latest.json"), "w"))
+              open(os.path.join(args.out, args.traffic_json), "w"))
 print("\n".join(lines[:60]))
