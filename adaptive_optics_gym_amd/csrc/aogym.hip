@@ -336,14 +336,17 @@ int evolve_layer(aog_env* e, hipStream_t s) {
       e->ext_resident = std::max(1, per_cu > 1 ? per_cu - 1 : 1) * cus;
       if (const char* v = getenv("AOG_EXTRUDE_RESIDENT")) e->ext_resident = std::max(8 * aog::kExtParts, atoi(v));   // (tests: force several launches)
     }
-    zero_words(e->ext_bar, (size_t)round_up(e->n_ext_groups, 4), s);
     p.origin = e->origin;
     const int groups8 = round_up(e->n_ext_groups, 8);
+    // two ticket sets alternate between steps: this step's launches poll `bar` and zero `bar_next` (both start zeroed at creation)
+    unsigned* bar = e->ext_bar + (size_t)(e->ext_bar_phase & 1) * groups8;
+    unsigned* bar_next = e->ext_bar + (size_t)((e->ext_bar_phase ^ 1) & 1) * groups8;
+    e->ext_bar_phase ^= 1;
     const int groups_per_launch = std::max(8, e->ext_resident / aog::kExtParts / 8 * 8);
     for (int g0 = 0; g0 < groups8; g0 += groups_per_launch) {
       const int ng = std::min(groups_per_launch, groups8 - g0);
-      hipLaunchKernelGGL(kern, dim3(ng * aog::kExtParts), dim3(256 * aog::kExtKs), lds, s, p, e->B, e->ext_perm, e->ext_bar, e->dev_status,
-                         e->host_flag_dev, g0, e->ext_spin_limit, e->ext_absent_part);
+      hipLaunchKernelGGL(kern, dim3(ng * aog::kExtParts), dim3(256 * aog::kExtKs), lds, s, p, e->B, e->ext_perm, bar, e->dev_status,
+                         e->host_flag_dev, g0, e->ext_spin_limit, e->ext_absent_part, bar_next);
     }
     HIP_TRY(hipGetLastError());
   } else if (!getenv("AOG_EXTRUDE_SIMPLE") && ext16_lds(e) <= kLdsBytes) {
@@ -591,7 +594,7 @@ int aog_create(const aog_config* cfg, int device, aog_env** out) {
     TRY_ALLOC(dev_alloc(e, &e->psi_master, (size_t)e->B * N2));
     TRY_ALLOC(dev_alloc(e, &e->origin, (size_t)e->B * 2));
     e->n_ext_groups = (e->B + aog::kExt16G - 1) / aog::kExt16G;
-    TRY_ALLOC(dev_alloc(e, &e->ext_bar, (size_t)round_up(e->n_ext_groups, 8)));
+    TRY_ALLOC(dev_alloc(e, &e->ext_bar, (size_t)2 * round_up(e->n_ext_groups, 8)));   // two ticket sets (see evolve_layer)
     TRY_ALLOC(dev_alloc(e, &e->ext_perm, (size_t)e->n_ext_groups * aog::kExt16G));
     {
       std::vector<int32_t> ident((size_t)e->n_ext_groups * aog::kExt16G, -1);
@@ -1031,8 +1034,7 @@ static int generate_twoband(aog_env* e, int first, int count, int qf, double cn_
   const int LW = N % 64 == 0 ? 64 : (N % 60 == 0 ? 60 : 0);
   const int R = LW ? N / LW : 0;
   if ((R == 1 || R == 2 || R == 4 || R == 8) && !getenv("AOG_SCREENS_FULLFFT")) {
-    const int linesT = N + 1 + KL;
-    const size_t per_env = (size_t)linesT * N * 2;   // floats of T
+    const size_t per_env = aog::screen2_T_elems(N, KL, 32 / R) * 2;   // floats of T (column tiles of 32 / R outputs)
     if (e->syn_m != -Mf) {   // (workspace key: negative = two-band layout)
       int rc;
       const int batch = (int)std::max<size_t>(1, std::min<size_t>((size_t)e->B, ((size_t)4 << 30) / (per_env * sizeof(float))));

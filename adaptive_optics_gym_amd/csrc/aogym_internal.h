@@ -109,7 +109,8 @@ struct aog_env {
   float* psi_ring = nullptr;     // [B][N][N + 4] fp32, see aog::DynPsi
   uint32_t* quad_desc = nullptr; // [n_ptiles * 2][4]
   uint32_t* quad_cont = nullptr; // [n_ptiles * 2][4]
-  unsigned* ext_bar = nullptr;   // group-barrier tickets of k_extrude16_split (zeroed before every launch)
+  unsigned* ext_bar = nullptr;   // group-barrier tickets of k_extrude16_split: two sets that alternate between steps (each launch zeroes the other set)
+  int ext_bar_phase = 0;
   int* dev_status = nullptr;     // sticky device-side error word (1 = a bounded spin timed out)
   int* host_flag = nullptr;      // the same flag in pinned, device-mapped host memory: read by the host without a synchronisation
   int* host_flag_dev = nullptr;  // its device address

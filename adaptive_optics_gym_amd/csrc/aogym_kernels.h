@@ -128,7 +128,18 @@ __global__ __launch_bounds__(256) void k_screen_means(const T* __restrict__ psi,
   __shared__ double sm[8];
   const T* src = psi + (size_t)blockIdx.x * n_pix2;
   double acc = 0;
-  for (int p = threadIdx.x; p < n_ap; p += blockDim.x) acc += (double)src[ap_index[p]];
+  // (same order of additions as k_pack_screens' loop — the two conversion paths must agree bit for bit — but eight gathers in flight)
+  for (int p0 = threadIdx.x; p0 < n_ap; p0 += 8 * blockDim.x) {
+    T v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int p = p0 + u * (int)blockDim.x;
+      v[u] = p < n_ap ? src[ap_index[p]] : (T)0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (p0 + u * (int)blockDim.x < n_ap) acc += (double)v[u];
+  }
   const double total = block_reduce_sum(acc, sm);
   if (threadIdx.x == 0) mean[blockIdx.x] = total / (double)n_ap;
 }
@@ -143,17 +154,32 @@ __global__ __launch_bounds__(256) void k_pack_tiles(const T* __restrict__ psi, c
   const int pt0 = blockIdx.x * kPackTiles;
   const int npix = min(kPackTiles, n_ptiles - pt0) * 32;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // gather: one wave = one env at a time, lanes along the packed pixel index
-  for (int el = wave; el < 32; el += 4) {
-    const int env = et * 32 + el;
+  // gather: one wave = one env at a time, lanes along the packed pixel index; a wave's 8 envs x 4 pixels per lane are requested together
+  constexpr int PL = kPackTiles * 32 / 64;   // pixels per lane
+  int flat[PL];
+#pragma unroll
+  for (int u = 0; u < PL; ++u) {
+    const int p = pt0 * 32 + lane + 64 * u;
+    flat[u] = (lane + 64 * u < npix && p < n_ap) ? ap_index[p] : -1;
+  }
+  T raw[8][PL];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int env = et * 32 + wave + 4 * j;
     const bool live = env >= first && env < first + count;   // (wave-uniform)
     const T* src = psi + (size_t)(live ? env - first : 0) * n_pix2;
+#pragma unroll
+    for (int u = 0; u < PL; ++u) raw[j][u] = (live && flat[u] >= 0) ? src[flat[u]] : (T)0;
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int el = wave + 4 * j, env = et * 32 + el;
+    const bool live = env >= first && env < first + count;
     const double mu = live ? mean[env - first] : 0.0;
-    for (int pl = lane; pl < npix; pl += 64) {
-      const int p = pt0 * 32 + pl;
-      float v = 0.f;
-      if (live && p < n_ap) v = (float)(((double)src[ap_index[p]] - mu) * inv_two_pi_lambda);
-      tile[pl][el] = v;
+#pragma unroll
+    for (int u = 0; u < PL; ++u) {
+      const int pl = lane + 64 * u;
+      if (pl < npix) tile[pl][el] = (live && flat[u] >= 0) ? (float)(((double)raw[j][u] - mu) * inv_two_pi_lambda) : 0.f;
     }
   }
   __syncthreads();
@@ -1581,7 +1607,7 @@ __global__ __launch_bounds__(512) void k_extrude16(ExtrudeArgs p, int B) {
 // writes it in place; before the next round reads those rows they meet at a group barrier: plain stores -> every wave
 // s_waitcnt vmcnt(0) -> __syncthreads -> lane 0: agent-scope release fence, ticket add on the group's counter, relaxed poll
 // (bounded) until all four tickets of this round are in, agent-scope acquire fence -> __syncthreads (cdna_hip_programming.md
-// Guideline 16, counter form).  Counters are zeroed by a memset ahead of every launch.  Workgroup L sits on XCD L % 8; the map
+// Guideline 16, counter form).  Two sets of counters alternate between launches; a launch zeroes the set of the next one.  Workgroup L sits on XCD L % 8; the map
 // below keeps a group's four workgroups on one XCD (speed only).  A timed-out spin sets *status and *host_flag (pinned host memory the
 // library polls without synchronising) and the kernel still terminates; aog_step / aog_reset then fail with AOG_ERR_STATE.
 constexpr int kExtParts = 4;
@@ -1590,7 +1616,8 @@ constexpr int kExtKs = 2;   // slices of the contraction per row block (template
 #ifdef AOG_MAIN_TU
 template <int KS>
 __global__ __launch_bounds__(256 * KS) void k_extrude16_split(ExtrudeArgs p, int B, const int* __restrict__ perm, unsigned* __restrict__ bar, int* __restrict__ status,
-                                                              int* __restrict__ host_flag, int group0, unsigned spin_limit, int absent_part) {
+                                                              int* __restrict__ host_flag, int group0, unsigned spin_limit, int absent_part,
+                                                              unsigned* __restrict__ bar_next) {
   // group0: first group of this launch (a batch whose groups x 4 workgroups exceed what the chip holds at once is extruded in several
   // launches: barrier partners must be co-resident).  spin_limit / absent_part: see aog_selftest_barrier_timeout (product launches pass
   // 1 << 24 and -1).
@@ -1615,6 +1642,8 @@ __global__ __launch_bounds__(256 * KS) void k_extrude16_split(ExtrudeArgs p, int
   const int group = group0 + (L & 7) * groups_per_xcd + (L >> 5);
   const int env0 = group * G;
   if (env0 >= B) return;   // whole groups only: no barrier partner is left waiting
+  // the tickets of the NEXT launch live in the other half of the ticket array: zeroed here, by one lane per group (no zero-fill launch per step)
+  if (part == 0 && threadIdx.x == 0) bar_next[group] = 0u;
   if (part == absent_part) return;   // (self-test: this group's partners wait for a ticket that never comes)
   for (int i = threadIdx.x; i < p.nz_v; i += blockDim.x) st_v[i] = p.stencil_v_yx[i];
   for (int i = threadIdx.x; i < p.nz_h; i += blockDim.x) st_h[i] = p.stencil_h_yx[i];
@@ -2817,8 +2846,12 @@ __global__ __launch_bounds__(64 * kColsWaves) void k_screen_cols(ScreenSynthArgs
 // 4 N^2 + 4 KL^2 samples instead of 256 N^2.  The high band runs through the same pruned two-pass transform with q = 2; a line then
 // fills only 2 R of the 64 lanes of the 64-point stage, so one wave carries NL = 32 / R lines (pass A) or columns (pass B) at once.
 // ------------------------------------------------------------------------------------------------
+// T is stored in column tiles of NL = 32 / R outputs: element (line v, output i) of an env at ((i / NL) * linesT + v) * NL + i % NL, so
+// that pass B's wave (NL adjacent columns, a line per lane) reads ONE contiguous run of linesT x NL x 8 bytes instead of 64 bytes out of
+// every 2 KB (PMC of the row-major form: two thirds of pass B's wave-cycles waiting for those loads)
+__host__ __device__ inline size_t screen2_T_elems(int N, int KL, int NL) { return (size_t)((N + NL - 1) / NL) * (size_t)(N + 1 + KL) * NL; }
 struct Screen2Args {
-  float2* T;                 // [env in batch][N + 1 + KL][N] complex64: high-band lines 0 .. N after pass A, then the KL low-band lines
+  float2* T;                 // [env in batch][column tile][N + 1 + KL][NL] complex64: high-band lines 0 .. N after pass A, then the KL low-band lines
   float* out;                // [env in batch][N][N]
   int N, qf, KL, first_local, env_base;
   unsigned long long seed;
@@ -2947,7 +2980,9 @@ __global__ __launch_bounds__(256, 2) void k_screen2_rows(Screen2Args p) {
   const int nHgroups = (linesH + NL - 1) / NL, nHblocks = (nHgroups + 3) / 4;
   const uint32_t generation = p.gen[p.first_local + b] + 1u;
   const uint32_t env_global = (uint32_t)(p.env_base + p.first_local + b);
-  float2* Tenv = p.T + (size_t)b * (linesH + p.KL) * N;
+  const int linesT = linesH + p.KL;
+  float2* Tenv = p.T + (size_t)b * screen2_T_elems(N, p.KL, NL);
+  auto t_at = [&](int v, int i) { return Tenv + ((size_t)(i / NL) * linesT + v) * NL + (i % NL); };
   if ((int)blockIdx.x < nHblocks) {
     const int grp = blockIdx.x * 4 + wave;
     if (grp >= nHgroups) return;
@@ -2987,10 +3022,9 @@ __global__ __launch_bounds__(256, 2) void k_screen2_rows(Screen2Args p) {
     if (lane < LW) {
 #pragma unroll
       for (int l = 0; l < NL; ++l) {
-        float2* dst = Tenv + (size_t)(v0 + l) * N + (size_t)R * lane;
         if (v0 + l < linesH) {
 #pragma unroll
-          for (int pp = 0; pp < R; ++pp) dst[pp] = make_float2(acc[l][pp].x, acc[l][pp].y);
+          for (int pp = 0; pp < R; ++pp) *t_at(v0 + l, R * lane + pp) = make_float2(acc[l][pp].x, acc[l][pp].y);
         }
       }
     }
@@ -3037,9 +3071,8 @@ __global__ __launch_bounds__(256, 2) void k_screen2_rows(Screen2Args p) {
     }
   }
   if (lane < LW) {
-    float2* dst = Tenv + (size_t)(linesH + ky) * N + (size_t)R * lane;
 #pragma unroll
-    for (int pp = 0; pp < R; ++pp) dst[pp] = make_float2(acc[pp].x, acc[pp].y);
+    for (int pp = 0; pp < R; ++pp) *t_at(linesH + ky, R * lane + pp) = make_float2(acc[pp].x, acc[pp].y);
   }
 }
 
@@ -3056,7 +3089,7 @@ __global__ __launch_bounds__(64 * kColsWaves) void k_screen2_cols(Screen2Args p)
   const int b = blockIdx.y;
   if (ix0 >= N) return;
   const float sgn = (lane & 1) ? -1.f : 1.f;
-  const float2* __restrict__ Tenv = p.T + (size_t)b * linesT * N;
+  const float2* __restrict__ Tenv = p.T + (size_t)b * screen2_T_elems(N, p.KL, NL) + (size_t)(ix0 / NL) * linesT * NL;   // this wave's column tile
   const int a0 = min(lane, LW - 1);
   cf32 pend[R];
   auto load = [&](auto gc, cf32 (&x)[R]) {
@@ -3066,7 +3099,7 @@ __global__ __launch_bounds__(64 * kColsWaves) void k_screen2_cols(Screen2Args p)
       for (int r = 0; r < R; ++r) {
         const int vv = Q * (a0 + LW * r) + bg;
         float4 t = make_float4(0.f, 0.f, 0.f, 0.f);   // the conjugate half plane is folded into the lines 0 .. N
-        if (vv < linesH && ix0 + l < N) t = *reinterpret_cast<const float4*>(Tenv + (size_t)vv * N + ix0 + l);
+        if (vv < linesH && ix0 + l < N) t = *reinterpret_cast<const float4*>(Tenv + (size_t)vv * NL + l);
         x[r] = cf32{sgn * t.x, sgn * t.y};
         pend[r] = cf32{sgn * t.z, sgn * t.w};
       }
@@ -3087,20 +3120,27 @@ __global__ __launch_bounds__(64 * kColsWaves) void k_screen2_cols(Screen2Args p)
     st[pp] = unit_root(1, yp[pp], Mf);
     tw[pp] = cf32{1.f, 0.f};
   }
-  const float2* __restrict__ TL = Tenv + (size_t)linesH * N + ix0;
+  const float2* __restrict__ TL = Tenv + (size_t)linesH * NL;
+  // the low-band values of a line are wave-uniform (scalar loads): line ky + 1 is requested before line ky is used, otherwise every
+  // iteration starts with a scalar-memory round trip that two waves per SIMD cannot cover (PMC: 66 % of the wave-cycles waiting)
+  float2 cn[NL];
+#pragma unroll
+  for (int l = 0; l < NL; ++l) cn[l] = TL[l];   // (columns past N of a last partial tile: in the workspace, never used)
   for (int ky = 0; ky < p.KL; ++ky) {
     if ((ky & 15) == 0 && ky) {
 #pragma unroll
       for (int pp = 0; pp < R; ++pp) tw[pp] = unit_root(ky, yp[pp], Mf);
     }
+    float2 cc[NL];
 #pragma unroll
-    for (int l = 0; l < NL; ++l) {
-      if (ix0 + l < N) {
-        const float2 c = TL[(size_t)ky * N + l];   // wave-uniform address
+    for (int l = 0; l < NL; ++l) cc[l] = cn[l];
+    const int kn = min(ky + 1, p.KL - 1);
 #pragma unroll
-        for (int pp = 0; pp < R; ++pp) acc[l][pp].x = fmaf(c.x, tw[pp].x, fmaf(-c.y, tw[pp].y, acc[l][pp].x));
-      }
-    }
+    for (int l = 0; l < NL; ++l) cn[l] = TL[(size_t)kn * NL + l];
+#pragma unroll
+    for (int l = 0; l < NL; ++l)   // (columns past N of a last partial tile carry workspace garbage through: never stored)
+#pragma unroll
+      for (int pp = 0; pp < R; ++pp) acc[l][pp].x = fmaf(cc[l].x, tw[pp].x, fmaf(-cc[l].y, tw[pp].y, acc[l][pp].x));
 #pragma unroll
     for (int pp = 0; pp < R; ++pp) tw[pp] = cmul(tw[pp], st[pp]);
   }
