@@ -368,6 +368,19 @@ class BatchedAOEnv:
         self._noise_dev = n   # kept alive until the step has run
         _lib.check(self.lib.aog_set_extrusion_noise(self._handle, C.c_void_p(n.data_ptr()), int(n.shape[1]), self._stream()))
 
+    def set_screen_method(self, screen_method):
+        """Switch the device screen synthesis between 'twoband' and 'hcipy16' (``aog_set_screen_method``); takes effect at the next
+        regeneration (semi_dynamic ``reset``).  The workspace of the method that is no longer used is given back then."""
+        if screen_method not in _lib.AOG_SCREENS:
+            raise ValueError("screen_method must be 'twoband' or 'hcipy16'")
+        _lib.check(self.lib.aog_set_screen_method(self._handle, _lib.AOG_SCREENS[screen_method]))
+        self.screen_method = screen_method
+
+    def device_bytes(self):
+        """Bytes of HBM the library handle owns right now (``aog_info.device_bytes``)."""
+        _lib.check(self.lib.aog_get_info(self._handle, C.byref(self.info)))
+        return int(self.info.device_bytes)
+
     def get_screens(self, first=0, count=None):
         """Current achromatic screens (hcipy's ``layer._achromatic_screen``: phase * lambda) of envs [first, first + count), default
         all: [count, N, N] float64.  Dynamic atmosphere: the float64 master screens.  Otherwise the stored screen exactly as the step

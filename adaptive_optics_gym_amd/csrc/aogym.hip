@@ -80,6 +80,7 @@ int dev_alloc(aog_env* e, T** out, size_t count, bool zero = true) {
   HIP_TRY(hipMalloc(&p, bytes));
   if (zero) HIP_TRY(hipMemset(p, 0, bytes));
   e->allocs.push_back(p);
+  e->alloc_bytes.push_back(bytes);
   e->dev_bytes += (int64_t)bytes;
   *out = static_cast<T*>(p);
   return AOG_OK;
@@ -401,6 +402,22 @@ int check_poisoned(const aog_env* e, const char* who) {
     return fail(AOG_ERR_STATE, "%s: an inter-workgroup wait of the dynamic-atmosphere kernel timed out in an earlier step; the screens of "
                 "this handle are invalid (install new screens or restore a saved state)", who);
   return AOG_OK;
+}
+
+// give a work buffer of the handle back (workspaces that are re-sized when the caller changes the synthesis method or oversampling:
+// without this every change would keep the old gigabytes until aog_destroy)
+template <typename T>
+void dev_release(aog_env* e, T** ptr) {
+  if (!*ptr) return;
+  for (size_t i = 0; i < e->allocs.size(); ++i)
+    if (e->allocs[i] == static_cast<void*>(*ptr)) {
+      e->dev_bytes -= (int64_t)e->alloc_bytes[i];   // (aog_info.device_bytes stays what the handle owns)
+      e->allocs.erase(e->allocs.begin() + (long)i);
+      e->alloc_bytes.erase(e->alloc_bytes.begin() + (long)i);
+      break;
+    }
+  (void)hipFree(*ptr);
+  *ptr = nullptr;
 }
 
 template <typename T>
@@ -986,10 +1003,13 @@ int aog_set_screen_method(aog_env* e, int method) {
 static int ensure_fft_plan(aog_env* e, int m, int N) {
   if (e->fft_m == m) return AOG_OK;
   if (e->fft_plan) {
+    HIP_TRY(hipDeviceSynchronize());   // (the old plan's work buffers may still be in use on the caller's stream)
     hipfftDestroy((hipfftHandle)(uintptr_t)e->fft_plan);
     e->fft_plan = nullptr;
     e->fft_m = 0;
   }
+  dev_release(e, &e->fft_work);
+  dev_release(e, &e->fft_crop);
   // batch so that the complex64 work buffer stays under ~2 GiB
   const size_t per = (size_t)m * m * 8;
   int batch = (int)std::max<size_t>(1, std::min<size_t>((size_t)e->B, ((size_t)2 << 30) / per));
@@ -1038,8 +1058,9 @@ static int generate_twoband(aog_env* e, int first, int count, int qf, double cn_
     if (e->syn_m != -Mf) {   // (workspace key: negative = two-band layout)
       int rc;
       const int batch = (int)std::max<size_t>(1, std::min<size_t>((size_t)e->B, ((size_t)4 << 30) / (per_env * sizeof(float))));
-      e->syn_T = nullptr;
-      e->syn_out = nullptr;
+      if (e->syn_T) HIP_TRY(hipDeviceSynchronize());   // (a workspace of another method / oversampling may still be in use)
+      dev_release(e, &e->syn_T);
+      dev_release(e, &e->syn_out);
       if ((rc = dev_alloc(e, &e->syn_T, per_env * batch, false)) != AOG_OK) return rc;
       if ((rc = dev_alloc(e, &e->syn_out, (size_t)batch * N * N, false)) != AOG_OK) return rc;
       e->syn_batch = batch;
@@ -1080,8 +1101,9 @@ static int generate_twoband(aog_env* e, int first, int count, int qf, double cn_
     if (hipfftSetStream(plan, s) != HIPFFT_SUCCESS) return fail(AOG_ERR_HIP, "hipfftSetStream failed");
     if (!e->low_c || e->low_key != KL * 65536 + e->fft_batch) {
       int rc;
-      e->low_c = nullptr;
-      e->low_T = nullptr;
+      if (e->low_c) HIP_TRY(hipDeviceSynchronize());
+      dev_release(e, &e->low_c);
+      dev_release(e, &e->low_T);
       if ((rc = dev_alloc(e, &e->low_c, (size_t)e->fft_batch * KL * 2 * KL * 2, false)) != AOG_OK) return rc;
       if ((rc = dev_alloc(e, &e->low_T, (size_t)e->fft_batch * KL * N * 2, false)) != AOG_OK) return rc;
       e->low_key = KL * 65536 + e->fft_batch;
@@ -1138,10 +1160,11 @@ int aog_generate_screens(aog_env* e, int first, int count, int oversampling, dou
     const int lines = m / 2 + 1;                 // half-plane synthesis: spectrum lines 0 .. m/2 (k_screen_rows)
     const size_t per_env = (size_t)lines * N * 2;   // floats of T
     int batch = (int)std::max<size_t>(1, std::min<size_t>((size_t)e->B, ((size_t)2 << 30) / (per_env * sizeof(float))));
-    if (e->syn_m != m) {   // (a different oversampling later on allocates afresh; the old workspace is released with the handle)
+    if (e->syn_m != m) {   // (a different oversampling or method: the old workspace is given back first)
       int rc;
-      e->syn_T = nullptr;
-      e->syn_out = nullptr;
+      if (e->syn_T) HIP_TRY(hipDeviceSynchronize());
+      dev_release(e, &e->syn_T);
+      dev_release(e, &e->syn_out);
       if ((rc = dev_alloc(e, &e->syn_T, per_env * batch, false)) != AOG_OK) return rc;
       if ((rc = dev_alloc(e, &e->syn_out, (size_t)batch * N * N, false)) != AOG_OK) return rc;
       e->syn_batch = batch;
@@ -1705,7 +1728,7 @@ int aog_focal_images(aog_env* e, int first, int count, float* field_dev, void* s
     // work buffers on first use: phases of the whole batch (the contraction runs on whole env tiles), E and T for a chunk of envs
     e->focal_chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)e->B, ((size_t)256 << 20) / (N2 * 8)));
     if ((rc = dev_alloc(e, &e->focal_phase, (size_t)e->n_etiles * e->n_ptiles * 1024, false)) != AOG_OK) return rc;
-    if ((rc = dev_alloc(e, &e->focal_Eb, (size_t)e->focal_chunk * N2 * 2, false)) != AOG_OK) return rc;
+    if ((rc = dev_alloc(e, &e->focal_Eb, (size_t)e->focal_chunk * N2 * 2, true)) != AOG_OK) return rc;   // zeroed ONCE: only aperture pixels are ever written
     if ((rc = dev_alloc(e, &e->focal_Tb, (size_t)e->focal_chunk * nf * N * 2, false)) != AOG_OK) return rc;
   }
   // psi_tile is always current for quasi_static / semi_dynamic handles; dynamic ones refresh it here when the step kernel does not use it
@@ -1720,7 +1743,6 @@ int aog_focal_images(aog_env* e, int first, int count, float* field_dev, void* s
   aog_host::launch_phase(e, s, e->act16, e->focal_phase);
   for (int done = 0; done < count; done += e->focal_chunk) {
     const int nb = std::min(e->focal_chunk, count - done);
-    zero_words(e->focal_Eb, (size_t)2 * N2 * nb, s);
     hipLaunchKernelGGL(aog::k_focal_E_batched, dim3((e->n_ap + 255) / 256, nb), dim3(256), 0, s, e->focal_phase, e->ap_index,
                        reinterpret_cast<float2*>(e->focal_Eb), first + done, e->n_ap, e->n_ptiles, (int)N2);
     // T[b] = m1 (nf x N) . E[b] (N x N);   F[b] = T[b] (nf x N) . m2 (N x nf)

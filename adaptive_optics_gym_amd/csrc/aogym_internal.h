@@ -159,6 +159,7 @@ struct aog_env {
   double prof_ms[AOG_PROF_COUNT] = {};   // totals of the last aog_profile_read, per kernel id
   int prof_n[AOG_PROF_COUNT] = {};
   std::vector<void*> allocs;
+  std::vector<size_t> alloc_bytes;   // size of allocs[i] (dev_release gives work buffers back before the handle is destroyed)
 };
 
 namespace aog_host {

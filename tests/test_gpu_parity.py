@@ -848,6 +848,31 @@ def test_pruned_screen_synthesis_matches_full_transform(monkeypatch, method, N, 
     assert np.abs(p2 - f2).max() < 3e-5 * rms
 
 
+def test_switching_the_screen_method_gives_the_workspace_back():
+    """``aog_set_screen_method`` between resets: each method draws its own (reproducible) stream, and the workspace of the method that is
+    left is released instead of piling up until ``aog_destroy`` (the literal form's is 4 MB per env at N = 64, q = 16)."""
+    _torch()
+    from adaptive_optics_gym_amd import BatchedAOEnv
+
+    env = BatchedAOEnv(64, "cuda:0", atm_type="semi_dynamic", act_dim=6, act_type="zernike", obs_dim=2, num_pupil_pixels=64, seed=3, verbose=False)
+    env.reset()
+    two = env.phase_screen(1).cpu().numpy()
+    base = env.device_bytes()
+    sizes = []
+    for _ in range(3):
+        env.set_screen_method("hcipy16")
+        env.reset()
+        lit = env.phase_screen(1).cpu().numpy()
+        sizes.append(env.device_bytes())
+        env.set_screen_method("twoband")
+        env.reset()
+        sizes.append(env.device_bytes())
+    assert np.isfinite(lit).all() and lit.std() > 0 and not np.array_equal(lit, two)
+    assert sizes[0] == sizes[2] == sizes[4] and sizes[1] == sizes[3] == sizes[5] == base     # nothing accumulates
+    assert sizes[0] > base                                                                   # (the literal workspace is the larger one)
+    env.close()
+
+
 @pytest.mark.parametrize("method,N", [("twoband", 64), ("twoband", 60), ("twoband", 96), ("hcipy16", 64)])
 def test_device_screens_have_the_literal_covariance(method, N):
     """Monte-Carlo check of the device output against the EXACT covariance of hcipy's literal method (the cosine sum over its (16 N)^2

@@ -14,7 +14,7 @@ L0 = 10.0
 D = 0.5
 
 
-@pytest.mark.parametrize("N,q", [(32, 16), (64, 16), (60, 16), (128, 16), (256, 16), (64, 8), (128, 4)])
+@pytest.mark.parametrize("N,q", [(32, 16), (64, 16), (60, 16), (128, 16), (240, 16), (256, 16), (64, 8), (128, 4)])   # 240: the reference's pupil
 def test_twoband_covariance_equals_literal_covariance_at_every_lag(N, q):
     delta = D / N
     lit = literal_covariance(N, delta, L0, q)
