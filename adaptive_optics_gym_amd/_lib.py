@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libaogym.so")
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 AOG_REWARD = {"strehl_ratio": 0, "smf_ssim": 1}
 AOG_PRECISION = {"fast": 0, "fp64": 1}
@@ -73,6 +73,7 @@ SYMBOLS = {
     "aog_set_screens_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "aog_upload_layer": (C.c_int, [C.c_void_p, C.POINTER(AogLayerTables)]),
     "aog_set_wind": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]),
+    "aog_set_lookahead": (C.c_int, [C.c_void_p, C.c_int]),
     "aog_set_extrusion_noise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "aog_set_rng_seed": (C.c_int, [C.c_void_p, C.c_uint64]),
     "aog_get_screens_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

@@ -368,6 +368,17 @@ class BatchedAOEnv:
         self._noise_dev = n   # kept alive until the step has run
         _lib.check(self.lib.aog_set_extrusion_noise(self._handle, C.c_void_p(n.data_ptr()), int(n.shape[1]), self._stream()))
 
+    def lookahead(self, enable=True):
+        """Dynamic atmosphere, device random stream: let every ``step`` launch the NEXT step's wind extrusion on a stream of the library's
+        own, beside its epilogue and the caller's policy query (``aog_set_lookahead``).  Same results bit for bit; between two steps of an
+        episode ``reset`` / ``get_screens`` / ``get_state`` / ``phase_screen`` / ``focal_image(s)`` / ``sh_image`` raise (the screens already
+        stand at the next step) — at episode boundaries they work as ever.  Opt-in (``rollout(lookahead=True)``, ``bench.py --config 4
+        --lookahead``): measured on ROCm 7.2 the two cross-stream event hand-offs cost ~20 us each, which is what the overlap saves."""
+        if self.atm_type != "dynamic" or self._host_rng:
+            return False
+        _lib.check(self.lib.aog_set_lookahead(self._handle, int(bool(enable))))
+        return bool(enable)
+
     def set_screen_method(self, screen_method):
         """Switch the device screen synthesis between 'twoband' and 'hcipy16' (``aog_set_screen_method``); takes effect at the next
         regeneration (semi_dynamic ``reset``).  The workspace of the method that is no longer used is given back then."""

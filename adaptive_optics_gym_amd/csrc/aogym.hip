@@ -285,7 +285,8 @@ size_t ext_split_lds(const aog_env* e) {
           (size_t)(aog::kExtKs - 1) * 4 * 256) * sizeof(double) + (size_t)(e->nz_v + e->nz_h) * sizeof(int32_t);
 }
 
-int evolve_layer(aog_env* e, hipStream_t s) {
+// step_index: the AOEnv.timestep this extrusion brings the layer to (layer.t = step_index * delta_t)
+int evolve_layer(aog_env* e, hipStream_t s, long long step_index) {
   if (!e->layer_ready) return fail(AOG_ERR_STATE, "dynamic atmosphere: aog_upload_layer / aog_set_wind not called");
   aog::ExtrudeArgs p{};
   p.master = e->psi_master;
@@ -311,8 +312,8 @@ int evolve_layer(aog_env* e, hipStream_t s) {
   p.nz_h = e->nz_h;
   p.near_v = e->near_v;
   p.near_h = e->near_h;
-  p.t_prev = (double)(e->timestep - 1) * e->delta_t;
-  p.t_new = (double)e->timestep * e->delta_t;
+  p.t_prev = (double)(step_index - 1) * e->delta_t;
+  p.t_new = (double)step_index * e->delta_t;
   p.pitch = e->pitch;
   p.sqrt_cn2 = e->sqrt_cn2;
   p.seed = e->rng_seed;
@@ -406,6 +407,15 @@ int check_poisoned(const aog_env* e, const char* who) {
 
 // give a work buffer of the handle back (workspaces that are re-sized when the caller changes the synthesis method or oversampling:
 // without this every change would keep the old gigabytes until aog_destroy)
+// With lookahead on, between aog_step(t) and aog_step(t + 1) the screens already stand at step t + 1: anything that reads or replaces
+// them then would see (or break) a state the env is not in.  Episode boundaries are safe: the last step of an episode does not look ahead.
+int refuse_pre_evolved(const aog_env* e, const char* who) {
+  if (e->pre_evolved)
+    return fail(AOG_ERR_STATE, "%s: the atmosphere of this handle has been advanced to the next step already (aog_set_lookahead): call it at an "
+                "episode boundary (after a step that returned done), or switch lookahead off and take one more step first", who);
+  return AOG_OK;
+}
+
 template <typename T>
 void dev_release(aog_env* e, T** ptr) {
   if (!*ptr) return;
@@ -426,6 +436,7 @@ int set_screens(aog_env* e, const T* psi, int first, int count, hipStream_t s) {
   if (!e->tables_ready) return fail(AOG_ERR_STATE, "aog_set_screens before aog_upload_tables");
   if (first < 0 || count < 0 || first + count > e->B)
     return fail(AOG_ERR_INVALID, "aog_set_screens: env range [%d,%d) outside [0,%d)", first, first + count, e->B);
+  if (int rc = refuse_pre_evolved(e, "aog_set_screens")) return rc;
   if (count == 0) return AOG_OK;
   HIP_TRY(hipSetDevice(e->device));
   const double inv = 1.0 / (2.0 * M_PI * e->cfg.wavelength_wfs);
@@ -650,6 +661,12 @@ void aog_destroy(aog_env* e) {
   (void)hipSetDevice(e->device);
   for (void* p : e->allocs) (void)hipFree(p);
   if (e->host_flag) (void)hipHostFree(e->host_flag);
+  if (e->ext_stream) {
+    (void)hipStreamSynchronize(e->ext_stream);
+    (void)hipStreamDestroy(e->ext_stream);
+    (void)hipEventDestroy(e->ev_fused_done);
+    (void)hipEventDestroy(e->ev_ext_done);
+  }
   if (e->fft_plan) hipfftDestroy((hipfftHandle)(uintptr_t)e->fft_plan);
   if (e->sh_plan) hipfftDestroy((hipfftHandle)(uintptr_t)e->sh_plan);
   for (auto& ev : e->events) {
@@ -974,6 +991,7 @@ int aog_set_rng_seed(aog_env* e, uint64_t seed) {
 int aog_get_screens_f64(aog_env* e, double* psi_dev, int first, int count, void* stream) {
   if (!e || !psi_dev) return fail(AOG_ERR_INVALID, "aog_get_screens_f64: null argument");
   if (!e->screens_ready) return fail(AOG_ERR_STATE, "aog_get_screens_f64 before any screen was installed");
+  if (int rc = refuse_pre_evolved(e, "aog_get_screens_f64")) return rc;
   if (first < 0 || count < 0 || first + count > e->B) return fail(AOG_ERR_INVALID, "aog_get_screens_f64: env range outside [0,%d)", e->B);
   if (count == 0) return AOG_OK;
   HIP_TRY(hipSetDevice(e->device));
@@ -1350,6 +1368,7 @@ int aog_upload_sh(aog_env* e, const aog_sh_tables* t) {
 int aog_sh_image(aog_env* e, double* image_dev, void* stream) {
   if (!e) return fail(AOG_ERR_INVALID, "aog_sh_image: null handle");
   if (!e->sh_ready || !e->screens_ready) return fail(AOG_ERR_STATE, "aog_sh_image before aog_upload_sh / aog_set_screens");
+  if (int rcp = refuse_pre_evolved(e, "aog_sh_image")) return rcp;
   HIP_TRY(hipSetDevice(e->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int N = e->cfg.n_pupil;
@@ -1526,7 +1545,7 @@ namespace {
 struct StateTail {  // host-side counters that steer the device RNG streams; stored in the last 256 bytes of the blob
   int64_t timestep;
   uint64_t rng_seed;
-  uint32_t sh_calls, reserved;
+  uint32_t sh_calls, steps_since_reset;
 };
 }  // namespace
 
@@ -1539,13 +1558,14 @@ int64_t aog_state_bytes(const aog_env* e) {
 
 int aog_get_state(aog_env* e, void* blob_dev, int64_t* timestep_out, void* stream) {
   if (!e || !blob_dev) return fail(AOG_ERR_INVALID, "aog_get_state: null argument");
+  if (int rc = refuse_pre_evolved(e, "aog_get_state")) return rc;
   HIP_TRY(hipSetDevice(e->device));
   size_t off = 0;
   for (const auto& p : state_parts(e)) {
     HIP_TRY(hipMemcpyAsync(static_cast<char*>(blob_dev) + off, p.ptr, p.bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
     off += (p.bytes + 255) / 256 * 256;
   }
-  StateTail tail{e->timestep, e->rng_seed, e->sh_calls, 0u};
+  StateTail tail{e->timestep, e->rng_seed, e->sh_calls, (uint32_t)e->steps_since_reset};
   HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
   HIP_TRY(hipMemcpy(static_cast<char*>(blob_dev) + off, &tail, sizeof tail, hipMemcpyHostToDevice));
   if (timestep_out) *timestep_out = e->timestep;
@@ -1556,6 +1576,10 @@ int aog_set_state(aog_env* e, const void* blob_dev, int64_t timestep, void* stre
   if (!e || !blob_dev) return fail(AOG_ERR_INVALID, "aog_set_state: null argument");
   if (!e->tables_ready) return fail(AOG_ERR_STATE, "aog_set_state before aog_upload_tables");
   HIP_TRY(hipSetDevice(e->device));
+  if (e->pre_evolved) {   // a restored state replaces everything the pending extrusion touches: let it finish, then forget it
+    HIP_TRY(hipStreamSynchronize(e->ext_stream));
+    e->pre_evolved = false;
+  }
   hipStream_t s = static_cast<hipStream_t>(stream);
   size_t off = 0;
   for (const auto& p : state_parts(e)) {
@@ -1568,6 +1592,7 @@ int aog_set_state(aog_env* e, const void* blob_dev, int64_t timestep, void* stre
   e->timestep = timestep;
   e->rng_seed = tail.rng_seed;
   e->sh_calls = tail.sh_calls;
+  e->steps_since_reset = tail.steps_since_reset;
   e->sh_sums_ready = false;
   if (e->host_flag && *static_cast<volatile int*>(e->host_flag)) {   // a restored state replaces every screen: the handle is usable again
     HIP_TRY(hipMemset(e->dev_status, 0, sizeof(int)));
@@ -1591,6 +1616,7 @@ int aog_get_phase_screen(aog_env* e, int env_index, float* phase_dev, void* stre
   if (!e->screens_ready) return fail(AOG_ERR_STATE, "aog_get_phase_screen before aog_set_screens");
   if (e->cfg.precision != AOG_PRECISION_FAST) return fail(AOG_ERR_UNSUPPORTED, "aog_get_phase_screen: fast precision handles only");
   if (env_index < 0 || env_index >= e->B) return fail(AOG_ERR_INVALID, "aog_get_phase_screen: env %d outside [0,%d)", env_index, e->B);
+  if (int rcp = refuse_pre_evolved(e, "aog_get_phase_screen")) return rcp;
   HIP_TRY(hipSetDevice(e->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
   const size_t N2 = (size_t)e->cfg.n_pupil * e->cfg.n_pupil;
@@ -1647,8 +1673,10 @@ int aog_reset(aog_env* e, const uint8_t* mask, float* obs_raw, uint16_t* obs, vo
   if (!e) return fail(AOG_ERR_INVALID, "aog_reset: null handle");
   if (!e->tables_ready || !e->screens_ready) return fail(AOG_ERR_STATE, "aog_reset before aog_upload_tables/aog_set_screens");
   if (int rc = check_poisoned(e, "aog_reset")) return rc;
+  if (int rc = refuse_pre_evolved(e, "aog_reset")) return rc;
   HIP_TRY(hipSetDevice(e->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (!mask) e->steps_since_reset = 0;
   {
     const int n = e->B * e->A;
     hipLaunchKernelGGL(aog::k_reset_state, dim3((n + 255) / 256), dim3(256), 0, s, mask, e->act_dm, e->t_render, e->B, e->A,
@@ -1673,19 +1701,38 @@ int aog_step(aog_env* e, const float* action, float* obs_raw, uint16_t* obs, flo
   HIP_TRY(hipSetDevice(e->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
   e->timestep += 1;  // AO_env.py:123
+  e->steps_since_reset += 1;
+  bool join_ext = false;
   e->sh_sums_ready = false;   // (an aog_sh_image(NULL) not followed by its aog_sh_update is void once the env has stepped)
   if (e->cfg.atm_dynamic) {
-    int rce = evolve_layer(e, s);
-    if (rce != AOG_OK) return rce;
+    if (e->pre_evolved) {   // the previous step launched this step's extrusion on the library's stream: join it
+      if (e->next_noise) return fail(AOG_ERR_STATE, "aog_step: extrusion normals were supplied for a step whose extrusion already ran (lookahead "
+                                     "draws from the device stream; switch it off for host-supplied normals)");
+      join_ext = true;   // (joined just ahead of the fused kernel: the prologue does not read the screens)
+      e->pre_evolved = false;
+    } else {
+      int rce = evolve_layer(e, s, e->timestep);
+      if (rce != AOG_OK) return rce;
+    }
   }
   // each fused kernel reads one operand layout: write only that one (the float64 device kernel and the VALU kernel read act_rev)
   const bool mfma_fast = e->kernel == AOG_KERNEL_MFMA && e->cfg.precision == AOG_PRECISION_FAST && !e->sh_ready;
-  hipLaunchKernelGGL(aog::k_prologue, dim3((e->B + aog::kProEnvs - 1) / aog::kProEnvs), dim3(64 * aog::kProEnvs), 0, s, action, e->gram, e->act_dm,
+  hipLaunchKernelGGL(join_ext ? aog::k_prologue<false> : aog::k_prologue<true>, dim3((e->B + aog::kProEnvs - 1) / aog::kProEnvs), dim3(64 * aog::kProEnvs), 0, s, action, e->gram, e->act_dm,
                      mfma_fast ? nullptr : e->act_rev, e->act16, e->B, e->A,
                      e->A_pad, e->Bp, e->cfg.sh_operation, e->cfg.surface_rms_target, 2.0 / e->cfg.wavelength_wfs);
   HIP_TRY(hipGetLastError());
+  if (join_ext) HIP_TRY(hipStreamWaitEvent(s, e->ev_ext_done, 0));
   int rc = launch_fused(e, s);
   if (rc != AOG_OK) return rc;
+  // lookahead: step t + 1's wind shift needs nothing from this step's outputs (AO_env.py:125 vs :132-142), only that the fused kernel
+  // has finished reading the ring.  Not on an episode's last step: reset() observes the atmosphere as this step left it (AO_env.py:84).
+  if (e->cfg.atm_dynamic && e->lookahead && !e->next_noise && e->steps_since_reset < e->cfg.max_steps) {
+    HIP_TRY(hipEventRecord(e->ev_fused_done, s));
+    HIP_TRY(hipStreamWaitEvent(e->ext_stream, e->ev_fused_done, 0));
+    if (int rce = evolve_layer(e, e->ext_stream, e->timestep + 1)) return rce;
+    HIP_TRY(hipEventRecord(e->ev_ext_done, e->ext_stream));
+    e->pre_evolved = true;
+  }
   return launch_epilogue(e, true, obs_raw, obs, reward, done, power, strehl, s);
 }
 
@@ -1694,6 +1741,7 @@ int aog_focal_image(aog_env* e, int env_index, float* field_dev, void* stream) {
   if (!e->tables_ready || !e->screens_ready) return fail(AOG_ERR_STATE, "aog_focal_image before aog_upload_tables/aog_set_screens");
   if (!e->n_focal) return fail(AOG_ERR_STATE, "aog_focal_image: focal_m1/focal_m2 were not uploaded");
   if (env_index < 0 || env_index >= e->B) return fail(AOG_ERR_INVALID, "aog_focal_image: env %d outside [0,%d)", env_index, e->B);
+  if (int rcp = refuse_pre_evolved(e, "aog_focal_image")) return rcp;
   const bool fast = e->cfg.precision == AOG_PRECISION_FAST;
   if (fast && e->focal_m1f) return aog_focal_images(e, env_index, 1, field_dev, stream);   // the batched matrix-core path
   HIP_TRY(hipSetDevice(e->device));
@@ -1718,6 +1766,7 @@ int aog_focal_images(aog_env* e, int first, int count, float* field_dev, void* s
   if (first < 0 || count < 0 || first + count > e->B) return fail(AOG_ERR_INVALID, "aog_focal_images: env range outside [0,%d)", e->B);
   if (e->cfg.precision != AOG_PRECISION_FAST || !e->focal_m1f)
     return fail(AOG_ERR_UNSUPPORTED, "aog_focal_images: fast-precision handles only (use aog_focal_image on a float64 validation handle)");
+  if (int rcp = refuse_pre_evolved(e, "aog_focal_images")) return rcp;
   if (count == 0) return AOG_OK;
   HIP_TRY(hipSetDevice(e->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1788,17 +1837,31 @@ int aog_actor_act(const aog_actor* n, int device, const void* obs_dev, int obs_i
   return AOG_OK;
 }
 
+int aog_set_lookahead(aog_env* e, int enable) {
+  if (!e) return fail(AOG_ERR_INVALID, "aog_set_lookahead: null handle");
+  if (!e->cfg.atm_dynamic) return fail(AOG_ERR_STATE, "aog_set_lookahead: only dynamic-atmosphere handles evolve their screens inside aog_step");
+  HIP_TRY(hipSetDevice(e->device));
+  if (enable && !e->ext_stream) {
+    HIP_TRY(hipStreamCreateWithFlags(&e->ext_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&e->ev_fused_done, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&e->ev_ext_done, hipEventDisableTiming));
+  }
+  e->lookahead = enable != 0;   // (an extrusion already launched ahead stays valid: the next aog_step joins it)
+  return AOG_OK;
+}
+
 int aog_selftest_barrier_timeout(aog_env* e, void* stream) {
   if (!e) return fail(AOG_ERR_INVALID, "aog_selftest_barrier_timeout: null handle");
   if (!e->cfg.atm_dynamic || !e->layer_ready || !e->screens_ready) return fail(AOG_ERR_STATE, "aog_selftest_barrier_timeout: needs a dynamic handle with layer and screens");
   if (!e->ext_bar || getenv("AOG_EXTRUDE_SIMPLE") || getenv("AOG_EXTRUDE_NOSPLIT") || ext_split_lds(e) > kLdsBytes)
     return fail(AOG_ERR_UNSUPPORTED, "aog_selftest_barrier_timeout: this handle does not use the split extrusion kernel");
+  if (int rcp = refuse_pre_evolved(e, "aog_selftest_barrier_timeout")) return rcp;
   HIP_TRY(hipSetDevice(e->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
   e->ext_spin_limit = 1u << 10;
   e->ext_absent_part = 1;
   e->timestep += 1;
-  const int rc = evolve_layer(e, s);
+  const int rc = evolve_layer(e, s, e->timestep);
   e->ext_spin_limit = 1u << 24;
   e->ext_absent_part = -1;
   if (rc != AOG_OK) return rc;

@@ -121,6 +121,13 @@ struct aog_env {
   int32_t* ext_perm = nullptr;   // [n_ext_groups * 16] group slot -> env id, -1 = padding (envs sorted by wind, see aog_set_wind)
   double max_wind = 0;           // max |component| of any env's velocity (bounds the rounds per step)
   long long timestep = 0;        // AOEnv.timestep: monotone over episodes (AO_env.py:123)
+  // lookahead (aog_set_lookahead): the wind extrusion of step t + 1 is launched by aog_step(t) on a stream of the library's own, behind
+  // the fused kernel of step t, and runs beside the step's epilogue and whatever the caller does before aog_step(t + 1) (its policy query)
+  bool lookahead = false;
+  bool pre_evolved = false;      // the master screens / ring already stand at timestep + 1
+  long long steps_since_reset = 0;   // steps since the last whole-batch aog_reset (lock-step episodes end at cfg.max_steps)
+  hipStream_t ext_stream = nullptr;
+  hipEvent_t ev_fused_done = nullptr, ev_ext_done = nullptr;
   double* psi_master = nullptr;  // [B][N*N] float64 toroidal screens
   int32_t* origin = nullptr;     // [B][2]
   uint32_t* ext_counter = nullptr;  // [B]

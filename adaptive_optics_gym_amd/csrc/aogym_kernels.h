@@ -228,6 +228,10 @@ __device__ __forceinline__ void store_act16(_Float16* __restrict__ act16, int en
 // ------------------------------------------------------------------------------------------------
 #ifdef AOG_MAIN_TU
 constexpr int kProEnvs = 4;   // envs (= waves) per workgroup: they share one copy of the Gram matrix in LDS
+// SHARED_GRAM = false: the Gram matrix is read through the caches instead of a 32 KB LDS copy — same arithmetic in the same order (bit-
+// identical), 1 us slower, but the workgroup then fits beside a resident extrusion workgroup (146 KB of a CU's 160 KB LDS): the form
+// aog_step uses while the next step's extrusion runs on the library's stream (aog_set_lookahead)
+template <bool SHARED_GRAM>
 __global__ __launch_bounds__(64 * kProEnvs) void k_prologue(const float* __restrict__ action, const double* __restrict__ gram,
                                                             double* __restrict__ act_dm, float* __restrict__ act_rev,
                                                             _Float16* __restrict__ act16, int B, int A, int A_pad, int Bp,
@@ -235,13 +239,13 @@ __global__ __launch_bounds__(64 * kProEnvs) void k_prologue(const float* __restr
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int env = blockIdx.x * kProEnvs + wave;
   const bool live = env < B;
-  __shared__ double Gs[64 * 64];           // G[j][i] at j * 64 + i (A <= 64); lane i then reads a conflict-free row per j
+  __shared__ double Gs[SHARED_GRAM ? 64 * 64 : 1];   // G[j][i] at j * 64 + i (A <= 64); lane i then reads a conflict-free row per j
   __shared__ double aps[kProEnvs][256];
   double* ap = aps[wave];
   // A <= 64 (every fast-path config of the reference): the Gram matrix crosses L2 -> LDS ONCE per workgroup, every load of it in
   // flight together with the action loads: one memory round trip in front of the arithmetic (4 K multiply-adds per env).  Round 1
   // had every env pull its own 32 KB copy through L2 (33 MB per step at B = 1024).
-  const bool pre = !sh_operation && A <= 64;
+  const bool pre = SHARED_GRAM && !sh_operation && A <= 64;
   if (pre) {
     constexpr int PER = 64 * 64 / (64 * kProEnvs);
     double g[PER];

@@ -130,7 +130,7 @@ class DeviceActor:
 
 
 def rollout(env, actor, episodes: int = 1, cov_var: float = 0.5, gatherer=None, generator=None, actor_impl: str = "auto", seed: int = 0,
-            dev_actor=None):
+            dev_actor=None, lookahead: bool = False):
     """Collect ``episodes`` lock-step episodes from ``env`` (a ``BatchedAOEnv``).
 
     ``actor_impl``: "hip" = the fused policy-query kernel (``DeviceActor``), "torch" = the module's own forward +
@@ -162,6 +162,11 @@ def rollout(env, actor, episodes: int = 1, cov_var: float = 0.5, gatherer=None, 
     import inspect
 
     step_takes_out = "out" in inspect.signature(env.step).parameters
+    # lookahead=True (dynamic atmosphere on the device stream): the next step's wind extrusion is launched on the library's own stream
+    # beside this step's epilogue and the policy query — bit-identical results; the screens are off limits between two steps of an
+    # episode, which this loop never touches.  Off by default: on ROCm 7.2 the two cross-stream event hand-offs it needs cost what the
+    # overlap saves.
+    looking_ahead = bool(env.lookahead(True)) if (lookahead and callable(getattr(env, "lookahead", None))) else False
     n = T * episodes
     out = None
     ep_returns = []
@@ -202,6 +207,8 @@ def rollout(env, actor, episodes: int = 1, cov_var: float = 0.5, gatherer=None, 
                 out["obs"][i0 + 1:i0 + T].copy_(out["next_obs"][i0:i0 + T - 1])   # obs of step t+1 = next_obs of step t
             gatherer.add(out["rew"][i0:i0 + T].sum(0))
             ep_returns.append(gatherer.finish_episode().clone())
+    if looking_ahead:
+        env.lookahead(False)
     out["ep_returns"] = torch.stack(ep_returns)
     out["avg_ep_rew"] = float(out["ep_returns"].mean().item()) / T
     return out

@@ -332,6 +332,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-spinup", action="store_true")
+    ap.add_argument("--lookahead", action="store_true", help="config 4: launch each step's wind extrusion one step ahead on the library's own stream")
     args = ap.parse_args()
     w = dict(WORKLOADS[args.config])
     if args.batch:
@@ -393,6 +394,7 @@ def main():
     if w["rollout"]:
         from adaptive_optics_gym_amd.rollout import DeviceActor, make_actor
 
+        env.lookahead(args.lookahead)   # opt-in (rollout(lookahead=True)): the next step's extrusion beside this step's epilogue + policy query
         torch.manual_seed(10)
         actor = make_actor(w["obs_dim"] ** 2, w["act_dim"], 150, device=device)        # SAC actor, hidden 150 (main.py:170)
         dev_actor = DeviceActor(actor, seed=10, env_id_base=rank * B)
@@ -490,6 +492,7 @@ def main():
                        "act_dim": w["act_dim"], "obs_dim": w["obs_dim"], "atm_type": w["atm_type"],
                        "kernel": {1: "valu", 2: "mfma"}.get(env.info.kernel, "ref"), "spinup_steps": spinup,
                        "collective_backend": (dist.get_backend() if distributed else "none (single process)"),
+                       "lookahead": bool(w["rollout"] and args.lookahead),
                        "parallelism": f"envs sharded over {world} GPU(s) by global env id, no data-path collective; one all-gather of "
                                       f"episode returns per episode"},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define AOG_ABI_VERSION 14
+#define AOG_ABI_VERSION 15
 
 typedef struct aog_env aog_env;
 
@@ -149,6 +149,17 @@ int aog_upload_layer(aog_env* env, const aog_layer_tables* layer);
  * max_abs_component >= max over envs of max(|vx|, |vy|): bounds the whole-pixel shifts per step.
  * Reads the velocities back once to group envs of similar wind for the extrusion kernel: synchronises `stream`. */
 int aog_set_wind(aog_env* env, const double* velocity_dev, double max_abs_component, void* stream);
+
+/* Lookahead for rollouts over a dynamic atmosphere.  The wind shift of step t + 1 (layer.t = ..., AO_env.py:125) depends on nothing
+ * step t computes — only the product of the field with the evolved screen does (AO_env.py:132).  With lookahead on, aog_step(t) launches
+ * the extrusion of step t + 1 on a stream of the library's own as soon as its fused kernel has finished reading the screens; it then runs
+ * beside the step's epilogue and beside whatever the caller enqueues before aog_step(t + 1) (its policy query), and aog_step(t + 1) joins it.
+ * Results are bit-identical with and without (same kernels, same random streams).  What changes: between the two calls the handle's screens
+ * already stand at step t + 1, so aog_reset, aog_get_screens_f64, aog_get_state, aog_set_screens_*, aog_get_phase_screen, aog_focal_image(s)
+ * and aog_sh_image return AOG_ERR_STATE there.  The last step of a lock-step episode (cfg.max_steps steps after the last whole-batch aog_reset)
+ * never looks ahead, so all of them are available at episode boundaries — where a rollout calls them.  Needs the device random stream
+ * (supplying normals with aog_set_extrusion_noise switches lookahead off for that step).  Off by default. */
+int aog_set_lookahead(aog_env* env, int enable);
 
 /* Standard normals for the extrusions of the NEXT aog_step: [B][max_ext][N] float64, consumed in hcipy's order (x shifts
  * first, then y).  NULL (default) = on-device Philox4x32-10 stream seeded by aog_set_rng_seed. */
