@@ -273,8 +273,7 @@ def roofline_dominant(env, w, kernels, steps_range):
         out["extrude"] = {"kernel": "k_extrude16_split", "bound": "mfma_f64", "ms": ms, "launches": n, "achieved": flop / (ms * 1e-3 * n) / 1e12,
                           "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flop / (ms * 1e-3 * n) / 1e12 / F64_MFMA_PEAK_TFLOPS,
                           "shifts_per_env_step": shifts / max(1, B * (steps_range[1] - steps_range[0])),
-                          "note": "2 N (nz + N) flop per one-pixel shift of one env, shifts recomputed on the host for the timed steps; the "
-                                  "event bracket includes the launch's ticket zero-fill"}
+                          "note": "2 N (nz + N) flop per one-pixel shift of one env, shifts recomputed on the host for the timed steps"}
     if all(k in kernels for k in ("sh_rows_fwd", "sh_cols", "sh_rows_inv")):
         ms = sum(kernels[k][0] for k in ("sh_rows_fwd", "sh_cols", "sh_rows_inv"))
         by = 72.0 * N * N * B
