@@ -437,6 +437,10 @@ def main():
     # clocks).  With a caller-chosen warm-up shorter than that, the difference is run here, ahead of the W warm-up steps, so that the K
     # timed steps measure the steady state a long-running job sees.  Config 2 only (the other configs' steps are 5-100x longer).
     spinup = max(0, SPINUP_STEPS - args.warmup) if (args.config == 2 and not args.no_spinup) else 0
+    if spinup and args.steps < T:
+        # a timed window shorter than an episode would otherwise sit between two episode ends (300 = 10 episodes of 30): shift the spin-up so
+        # that the window straddles one — the workload is "episodes with reset + all-gather of returns", and a short window should pay for one
+        spinup += (T - args.steps // 2 - (spinup + args.warmup)) % T
     start_episode()
     if spinup:
         run(spinup)
