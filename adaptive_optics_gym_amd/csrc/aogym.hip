@@ -122,15 +122,18 @@ static void launch_phase_t(aog_env* e, hipStream_t s, const _Float16* act16, flo
                      reinterpret_cast<const aog::f16x8*>(act16), reinterpret_cast<aog::f32x4*>(out_tile), e->n_ptiles, e->n_etiles);
 }
 template <int A_PAD>
-static void launch_phase_field_t(aog_env* e, hipStream_t s, const _Float16* act16, const aog::PhaseFieldArgs& fa) {
-  hipLaunchKernelGGL((aog::k_phase_mfma<A_PAD, true>), dim3((e->n_ptiles + 3) / 4, e->n_etiles), dim3(256), 0, s,
+static void launch_phase_field_t(aog_env* e, hipStream_t s, const _Float16* act16, const aog::PhaseFieldArgs& fa, bool grid) {
+  auto kern = grid ? aog::k_phase_mfma<A_PAD, true, true> : aog::k_phase_mfma<A_PAD, true, false>;
+  hipLaunchKernelGGL(kern, dim3((e->n_ptiles + 3) / 4, e->n_etiles), dim3(256), 0, s,
                      reinterpret_cast<const aog::f16x8*>(e->modes16), reinterpret_cast<const aog::f32x4*>(e->psi_tile),
                      reinterpret_cast<const aog::f16x8*>(act16), static_cast<aog::f32x4*>(nullptr), e->n_ptiles, e->n_etiles, fa);
 }
-void launch_phase_field(aog_env* e, hipStream_t s, const _Float16* act16, float* field, size_t env_stride, int row_stride) {
+// grid = true: one float per pixel (reduced phase) instead of the complex field: see k_phase_mfma<.., GRID>
+void launch_phase_field(aog_env* e, hipStream_t s, const _Float16* act16, float* field, size_t env_stride, int row_stride, bool grid) {
   aog::PhaseFieldArgs fa{};
   fa.ap_yx = e->sh_ap_yx;
   fa.mla32 = reinterpret_cast<const float2*>(e->sh_mla32);
+  fa.mla_rev = e->sh_ftab;
   fa.field = reinterpret_cast<float2*>(field);
   fa.env_stride = env_stride;
   fa.row_stride = row_stride;
@@ -139,10 +142,10 @@ void launch_phase_field(aog_env* e, hipStream_t s, const _Float16* act16, float*
   fa.N = e->cfg.n_pupil;
   fa.amplitude = (float)e->sh_amp;
   switch (e->A_pad) {
-    case 16: launch_phase_field_t<16>(e, s, act16, fa); break;
-    case 32: launch_phase_field_t<32>(e, s, act16, fa); break;
-    case 64: launch_phase_field_t<64>(e, s, act16, fa); break;
-    default: launch_phase_field_t<128>(e, s, act16, fa); break;
+    case 16: launch_phase_field_t<16>(e, s, act16, fa, grid); break;
+    case 32: launch_phase_field_t<32>(e, s, act16, fa, grid); break;
+    case 64: launch_phase_field_t<64>(e, s, act16, fa, grid); break;
+    default: launch_phase_field_t<128>(e, s, act16, fa, grid); break;
   }
 }
 void launch_phase(aog_env* e, hipStream_t s, const _Float16* act16, float* out_tile) {
@@ -1332,6 +1335,17 @@ int aog_upload_sh(aog_env* e, const aog_sh_tables* t) {
     for (size_t i = 0; i < N2 * 2; ++i) mla32[i] = (float)t->mla_phase[i];
     if ((rc = up(&e->sh_ap_yx, yx.data(), yx.size())) != AOG_OK) return rc;
     if ((rc = up(&e->sh_mla32, mla32.data(), mla32.size())) != AOG_OK) return rc;
+    // the micro-lens factor's argument in revolutions per packed aperture pixel: added to the phase by k_phase_mfma<.., GRID>; the phase
+    // grid the first pass reads starts out as "outside the aperture" everywhere (only aperture pixels are ever written)
+    std::vector<float> mrev((size_t)e->n_ap);
+    for (int i = 0; i < e->n_ap; ++i)
+      mrev[i] = (float)(atan2(t->mla_phase[(size_t)apidx[i] * 2 + 1], t->mla_phase[(size_t)apidx[i] * 2]) / (2.0 * M_PI));
+    if ((rc = up(&e->sh_ftab, mrev.data(), mrev.size())) != AOG_OK) return rc;
+    {
+      std::vector<float> fill((size_t)N2, aog::kShOutside);
+      for (int b = 0; b < e->B; ++b)
+        HIP_TRY(hipMemcpy(static_cast<float*>(e->sh_in) + (size_t)b * N2, fill.data(), sizeof(float) * N2, hipMemcpyHostToDevice));
+    }
   } else {
     const size_t cbytes = e->sh_double ? sizeof(double) * 2 : sizeof(float) * 2;
     char* p1 = nullptr;
@@ -1382,7 +1396,7 @@ int aog_sh_image(aog_env* e, double* image_dev, void* stream) {
                        2.0 / e->cfg.wavelength_wfs);
     if (e->sh_pruned) {
       TimedRegion tr(e, s, AOG_PROF_SH_FIELD);
-      aog_host::launch_phase_field(e, s, e->sh_act16, static_cast<float*>(e->sh_in), (size_t)N * N, N);   // phases -> field in one kernel
+      aog_host::launch_phase_field(e, s, e->sh_act16, static_cast<float*>(e->sh_in), (size_t)N * N, N, true);   // reduced phases on the pupil grid: the first pass forms the field
     } else {
       aog_host::launch_phase(e, s, e->sh_act16, e->sh_phase);
     }
@@ -1415,7 +1429,7 @@ int aog_sh_image(aog_env* e, double* image_dev, void* stream) {
     auto run = [&](auto rlc, auto lwc) -> int {
       constexpr int RL = decltype(rlc)::v, LW = decltype(lwc)::v, BC = 64 / RL;
       const int L = LW * RL;
-      if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_sh_rows_fwd<RL, LW>), lds, e->device)) return rc;
+      if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_sh_rows_fwd<RL, LW, true>), lds, e->device)) return rc;
       if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_sh_cols<RL, LW>), lds, e->device)) return rc;
       if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_sh_rows_inv<RL, LW, false>), lds, e->device)) return rc;
       if (fused)
@@ -1423,7 +1437,7 @@ int aog_sh_image(aog_env* e, double* image_dev, void* stream) {
       const dim3 g_rows((N / BC + aog::kShFftWaves - 1) / aog::kShFftWaves, e->B), g_cols((L / BC + aog::kShFftWaves - 1) / aog::kShFftWaves, e->B);
       {
         TimedRegion tr(e, s, AOG_PROF_SH_ROWS_FWD);
-        hipLaunchKernelGGL((aog::k_sh_rows_fwd<RL, LW>), g_rows, dim3(64 * aog::kShFftWaves), lds, s, field, F1T, tw);
+        hipLaunchKernelGGL((aog::k_sh_rows_fwd<RL, LW, true>), g_rows, dim3(64 * aog::kShFftWaves), lds, s, field, F1T, tw, (float)e->sh_amp);
       }
       {
         TimedRegion tr(e, s, AOG_PROF_SH_COLS);

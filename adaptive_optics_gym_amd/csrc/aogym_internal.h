@@ -62,6 +62,7 @@ struct aog_env {
   float* sh_tw = nullptr;         // [L] complex64 e^{+2 pi i j / L}
   int32_t* sh_ap_yx = nullptr;    // [n_ap] iy << 16 | ix of aperture pixel p
   float* sh_mla32 = nullptr;      // [N*N] complex64 micro-lens phase factor
+  float* sh_ftab = nullptr;       // [n_ap] argument of the micro-lens factor in revolutions per packed aperture pixel (pruned route)
   double* sh_sums = nullptr;      // [B][n_sub][3] noisy per-lenslet sums of the fused row pass (aog_sh_image without an image pointer)
   bool sh_sums_ready = false;     // set by that call, consumed by the next aog_sh_update(null)
   float* sh_tfq = nullptr;        // [L / BC][64][64] complex64 transfer function in the column pass's lane / register order
@@ -185,5 +186,5 @@ int launch_fused_apad64(aog_env* e, hipStream_t s);
 int launch_fused_apad128(aog_env* e, hipStream_t s);
 // phase-only contraction u = psi + Mt a for every (pixel, env) with the actuator operands `act16`, written in the psi_tile layout
 void launch_phase(aog_env* e, hipStream_t s, const _Float16* act16, float* out_tile);
-void launch_phase_field(aog_env* e, hipStream_t s, const _Float16* act16, float* field, size_t env_stride, int row_stride);   // complex64 field
+void launch_phase_field(aog_env* e, hipStream_t s, const _Float16* act16, float* field, size_t env_stride, int row_stride, bool grid);   // complex64 field, or (grid) one float of reduced phase per pixel
 }  // namespace aog_host

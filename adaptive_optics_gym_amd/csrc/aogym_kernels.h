@@ -918,15 +918,21 @@ __global__ __launch_bounds__(512, 2) void k_fused_tab(const f16x8* __restrict__ 
 // (iy, ix) of the env's image (compact N x N for the pruned passes), through a [32 envs][32 pixels] tile in LDS so that a store instruction
 // writes 256 contiguous bytes per env (k_sh_field re-read the phases through the tile layout and wrote 8 bytes per thread: 0.23 ms per
 // 1024 envs at N = 256 on top of this kernel's 0.11).
+constexpr float kShOutside = 2.0f;   // phase-grid value of a pixel outside the aperture (reduced phases lie in [-1/2, 1/2])
 struct PhaseFieldArgs {
   const int32_t* ap_yx;      // [n_ap] iy << 16 | ix
   const float2* mla32;       // [N*N] micro-lens phase factor, complex64
+  const float* mla_rev;      // [n_ap] its argument in revolutions per packed aperture pixel (GRID form)
   float2* field;
   size_t env_stride;
   int row_stride, n_ap, B, N;
   float amplitude;
 };
-template <int A_PAD, bool FIELD = false>
+// GRID (with FIELD): only a phase leaves this kernel — w = u + (micro-lens phase of the pixel), reduced to [-1/2, 1/2] revolutions, as ONE
+// float at (iy, ix) — and the first propagation pass forms E = amplitude e^{2 pi i w} itself while it loads: 4 bytes written and read per
+// pixel instead of 8, one load per pixel as before.  Pixels outside the aperture hold kShOutside (written once at upload): field 0.
+// (A first form kept the micro-lens factor as a complex table multiplied in by the pass: its second load per pixel cost the pass 1.4 ms.)
+template <int A_PAD, bool FIELD = false, bool GRID = false>
 __global__ __launch_bounds__(256) void k_phase_mfma(const f16x8* __restrict__ modes16, const f32x4* __restrict__ psi_tile,
                                                     const f16x8* __restrict__ act16, f32x4* __restrict__ out_tile, int n_ptiles,
                                                     int n_etiles, PhaseFieldArgs fa = PhaseFieldArgs{}) {
@@ -965,11 +971,16 @@ __global__ __launch_bounds__(256) void k_phase_mfma(const f16x8* __restrict__ mo
       for (int r = 0; r < 4; ++r) {
         const int q = 8 * g + 4 * h + r;
         const int pix = min(t * 32 + q, fa.n_ap - 1);
-        const int yx = fa.ap_yx[pix], iy = yx >> 16, ix = yx & 0xffff;
-        float sn, cs;
-        sincospif(2.0f * (o[r] - rintf(o[r])), &sn, &cs);
-        const float2 m = fa.mla32[iy * fa.N + ix];
-        field_tile[(lane & 31) * 33 + q] = make_float2(fa.amplitude * (cs * m.x - sn * m.y), fa.amplitude * (cs * m.y + sn * m.x));
+        [[maybe_unused]] const int yx = GRID ? 0 : fa.ap_yx[pix], iy = yx >> 16, ix = yx & 0xffff;
+        if constexpr (GRID) {
+          const float w = (o[r] - rintf(o[r])) + fa.mla_rev[pix];   // + the micro-lens phase of this pixel, in revolutions
+          field_tile[(lane & 31) * 33 + q] = make_float2(w - rintf(w), 0.f);
+        } else {
+          float sn, cs;
+          sincospif(2.0f * (o[r] - rintf(o[r])), &sn, &cs);
+          const float2 m = fa.mla32[iy * fa.N + ix];
+          field_tile[(lane & 31) * 33 + q] = make_float2(fa.amplitude * (cs * m.x - sn * m.y), fa.amplitude * (cs * m.y + sn * m.x));
+        }
       }
     }
   }
@@ -979,11 +990,14 @@ __global__ __launch_bounds__(256) void k_phase_mfma(const f16x8* __restrict__ mo
     const int q = lane & 31, pix = t * 32 + q;
     if (pix < fa.n_ap) {
       const int yx = fa.ap_yx[pix];
-      float2* dst = fa.field + (size_t)(yx >> 16) * fa.row_stride + (yx & 0xffff);
+      const size_t at = (size_t)(yx >> 16) * fa.row_stride + (yx & 0xffff);
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const int el = 2 * j + (lane >> 5), env_j = etile * 32 + el;
-        if (env_j < fa.B) dst[(size_t)env_j * fa.env_stride] = field_tile[el * 33 + q];
+        if (env_j < fa.B) {
+          if constexpr (GRID) reinterpret_cast<float*>(fa.field)[(size_t)env_j * fa.env_stride + at] = field_tile[el * 33 + q].x;
+          else fa.field[(size_t)env_j * fa.env_stride + at] = field_tile[el * 33 + q];
+        }
       }
     }
   }
@@ -3449,21 +3463,41 @@ __device__ __forceinline__ void sh_fft_b2a(cf32 (&v)[64], float* __restrict__ lb
 
 constexpr int kShFftWaves = 4;
 // rows, forward over x:  field [B][N][N] -> F1T [B][L][N]
-template <int RL, int LW>
-__global__ __launch_bounds__(64 * kShFftWaves, 2) void k_sh_rows_fwd(const float2* __restrict__ field, float2* __restrict__ F1T, const float2* __restrict__ tw) {
+// GRID: `field` holds one float per pixel, the phase (atmosphere + mirror + micro-lens) in revolutions reduced to [-1/2, 1/2], or kShOutside
+// (k_phase_mfma<.., true, true>): the field amplitude e^{2 pi i w} is formed here, in registers
+template <int RL, int LW, bool GRID = false>
+__global__ __launch_bounds__(64 * kShFftWaves, 2) void k_sh_rows_fwd(const float2* __restrict__ field, float2* __restrict__ F1T, const float2* __restrict__ tw,
+                                                                     float amplitude = 0.f) {
   extern __shared__ float lds_shfft[];
   constexpr int L = LW * RL, N = L / 2, BC = 64 / RL;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int iy0 = (blockIdx.x * kShFftWaves + wave) * BC;
   if (iy0 >= N) return;
-  const float2* src = field + ((size_t)blockIdx.y * N + iy0) * N + min(lane, LW - 1);
   cf32 v[64];
-  static_for<64>([&](auto ic) {
-    constexpr int i = decltype(ic)::v;
-    constexpr int bb = i / RL, r = i % RL;
-    if constexpr (r < RL / 2) { const float2 t = src[(size_t)bb * N + LW * r]; v[i] = cf32{t.x, t.y}; }
-    else v[i] = cf32{0.f, 0.f};   // the zero padding
-  });
+  if constexpr (GRID) {
+    const float* ph = reinterpret_cast<const float*>(field) + ((size_t)blockIdx.y * N + iy0) * N + min(lane, LW - 1);
+    static_for<64>([&](auto ic) {
+      constexpr int i = decltype(ic)::v;
+      constexpr int bb = i / RL, r = i % RL;
+      if constexpr (r < RL / 2) {
+        const float u = ph[(size_t)bb * N + LW * r];
+        const float a = u > 1.0f ? 0.f : amplitude;
+        float sn, cs;
+        sincospif(2.0f * u, &sn, &cs);
+        v[i] = cf32{a * cs, a * sn};
+      } else {
+        v[i] = cf32{0.f, 0.f};   // the zero padding
+      }
+    });
+  } else {
+    const float2* src = field + ((size_t)blockIdx.y * N + iy0) * N + min(lane, LW - 1);
+    static_for<64>([&](auto ic) {
+      constexpr int i = decltype(ic)::v;
+      constexpr int bb = i / RL, r = i % RL;
+      if constexpr (r < RL / 2) { const float2 t = src[(size_t)bb * N + LW * r]; v[i] = cf32{t.x, t.y}; }
+      else v[i] = cf32{0.f, 0.f};   // the zero padding
+    });
+  }
   sh_fft_a2b<RL, true, LW>(v, lds_shfft + (size_t)wave * 64 * 65, tw);
   // tiled intermediate: element (row y, column kx) lives in tile (kx / RL, y / BC) at [kx % RL][y % BC] — 64 elements = 512 bytes = exactly
   // what the 64 lanes (p, bb) of layout B hold for one k2: one fully coalesced store per k2 (a plain [kx][y] array took eight 64-byte
