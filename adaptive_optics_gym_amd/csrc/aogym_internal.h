@@ -66,6 +66,9 @@ struct aog_env {
   double* sh_sums = nullptr;      // [B][n_sub][3] noisy per-lenslet sums of the fused row pass (aog_sh_image without an image pointer)
   bool sh_sums_ready = false;     // set by that call, consumed by the next aog_sh_update(null)
   float* sh_tfq = nullptr;        // [L / BC][64][64] complex64 transfer function in the column pass's lane / register order
+  int sh_sep_rl = 0;              // RL of the separable two-pass propagation (transfer function = hx(kx) hy(ky)); 0 = three-pass form
+  float* sh_hxq = nullptr;        // [LW][64] complex64 hx[lane / BC + RL k2]   (pass 1, layout B)
+  float* sh_hyq = nullptr;        // [RL][64] complex64 hy[lane + LW r]         (pass 2, layout A)
   double sh_amp = 0, sh_scale = 0, sh_gain = 0, sh_leak = 0;
   uint32_t sh_calls = 0;
   // device screen synthesis (K8)

@@ -3321,10 +3321,12 @@ __device__ __forceinline__ double sh_poisson_large(double lam, uint32_t word_r, 
   return fmax(0.0, rint(lam + (double)(g * sqrtf((float)lam) + (g * g - 1.0f) * (1.0f / 6.0f))));
 }
 // one pixel on its own (k_sh_noise: pupils the pruned passes do not cover, caller-visible images)
-__device__ __forceinline__ double sh_noisy_value(double lam, size_t ge, int y, int x, int N, unsigned long long seed, uint32_t call) {
+// sep_rl > 0 (handles on the separable two-pass propagation, whose last pass holds 32 rows y = p + RL k2 of ONE column per lane): the same
+// scheme with the roles of the axes exchanged — pixel (ge, y, x) takes word k2 & 3 of the call with counter ((ge N + x) 64 + p, group k2 >> 2)
+__device__ __forceinline__ double sh_noisy_value(double lam, size_t ge, int y, int x, int N, unsigned long long seed, uint32_t call, int sep_rl = 0) {
   const int lw = spectrum_lane_width(N);
-  const size_t line = (ge * N + y) * 64 + (x % lw);
-  const uint32_t r = (uint32_t)(x / lw);
+  const size_t line = sep_rl ? (ge * N + x) * 64 + (size_t)(y % sep_rl) : (ge * N + y) * 64 + (x % lw);
+  const uint32_t r = sep_rl ? (uint32_t)(y / sep_rl) : (uint32_t)(x / lw);
   uint32_t w[4];
   sh_noise_words(line, r >> 2, false, seed, call, w);
   const bool small = lam < kShPoissonSwitch;
@@ -3654,12 +3656,161 @@ __global__ __launch_bounds__(64 * kShFftWaves, 2) void k_sh_rows_inv(const float
   }
 }
 
-__global__ void k_sh_noise(const double* __restrict__ image, double* __restrict__ noisy, int N, size_t env_base, unsigned long long seed, uint32_t call) {
+__global__ void k_sh_noise(const double* __restrict__ image, double* __restrict__ noisy, int N, size_t env_base, unsigned long long seed, uint32_t call,
+                           int sep_rl) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= N * N) return;
   const size_t il = (size_t)blockIdx.y * N * N + idx;
   const int y = idx / N;
-  noisy[il] = sh_noisy_value(image[il], env_base + blockIdx.y, y, idx - y * N, N, seed, call);
+  noisy[il] = sh_noisy_value(image[il], env_base + blockIdx.y, y, idx - y * N, N, seed, call, sep_rl);
+}
+
+// ---- separable form of the same propagation (the default whenever the transfer function factorises, which the paraxial Fresnel one does:
+// exp(-i z (kx^2 + ky^2) / 2k) = hx(kx) hy(ky)) ------------------------------------------------------------------------------------------
+// pad -> FFT2 -> x H -> IFFT2 -> crop  ==  [rows: pad, FFT_x, x hx, IFFT_x, keep x < N]  then  [columns: pad, FFT_y, x hy, IFFT_y, keep y < N]:
+// the x operation acts per row (rows y >= N of the padded field are zero and stay zero), the y operation per column (columns x >= N are
+// dropped at the end, so they are dropped before it).  TWO passes over an N x N complex64 intermediate instead of three over 2N x N ones:
+// 20 N^2 bytes per env instead of 68 N^2, and 4 N line transforms instead of 6 N (the three-pass column kernel transformed all 2N columns).
+//   pass 1  k_sh_rows_sep: phase row (layout A) -> forward -> x hx (layout B) -> inverse -> layout A, x < N kept
+//           -> G1[x / BC][y][x % BC]  (column groups of BC = 64 / RL: what a wave of pass 2 reads is one contiguous N x BC block)
+//   pass 2  k_sh_cols_sep: its BC columns in layout B (lane (p, bb): rows y = p + RL k2 of column bb: 512 contiguous bytes per k2)
+//           -> forward -> x hy (layout A) -> inverse -> layout B, y < N kept -> |.|^2 x scale -> image, or (FUSED) photon noise + lenslet sums
+// hxq: [LW][64] = hx[lane / BC + RL k2];  hyq: [RL][64] = hy[lane + LW r]  (arranged on the host)
+template <int RL, int LW>
+__global__ __launch_bounds__(64 * kShFftWaves, 2) void k_sh_rows_sep(const float* __restrict__ phase, float2* __restrict__ G1, const float2* __restrict__ tw,
+                                                                     const float2* __restrict__ hxq, float amplitude) {
+  extern __shared__ float lds_shfft[];
+  constexpr int L = LW * RL, N = L / 2, BC = 64 / RL;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int iy0 = (blockIdx.x * kShFftWaves + wave) * BC;
+  if (iy0 >= N) return;
+  const int la = min(lane, LW - 1);
+  cf32 v[64];
+  const float* ph = phase + ((size_t)blockIdx.y * N + iy0) * N + la;
+  static_for<64>([&](auto ic) {
+    constexpr int i = decltype(ic)::v;
+    constexpr int bb = i / RL, r = i % RL;
+    if constexpr (r < RL / 2) {
+      const float u = ph[(size_t)bb * N + LW * r];
+      const float a = u > 1.0f ? 0.f : amplitude;
+      float sn, cs;
+      sincospif(2.0f * u, &sn, &cs);
+      v[i] = cf32{a * cs, a * sn};
+    } else {
+      v[i] = cf32{0.f, 0.f};   // the zero padding
+    }
+  });
+  float* lbuf = lds_shfft + (size_t)wave * 64 * 65;
+  sh_fft_a2b<RL, true, LW>(v, lbuf, tw);
+  const float2* hq = hxq + lane;
+  static_for<8>([&](auto gc) {   // (eight table loads at a time, as in k_sh_cols)
+    constexpr int g8 = decltype(gc)::v;
+    float2 t8[8];
+    static_for<8>([&](auto jc) { constexpr int k2 = 8 * g8 + decltype(jc)::v; if constexpr (k2 < LW) t8[decltype(jc)::v] = hq[k2 * 64]; });
+    static_for<8>([&](auto jc) {
+      constexpr int k2 = 8 * g8 + decltype(jc)::v;
+      if constexpr (k2 < LW) v[k2] = cmul(v[k2], cf32{t8[decltype(jc)::v].x, t8[decltype(jc)::v].y});
+    });
+    __builtin_amdgcn_sched_barrier(0);
+  });
+  sh_fft_b2a<RL, false, LW>(v, lbuf, tw);
+  if (LW == 64 || lane < LW) {
+    float2* dst = G1 + (size_t)blockIdx.y * N * N;
+    static_for<64>([&](auto ic) {
+      constexpr int i = decltype(ic)::v;
+      constexpr int bb = i / RL, r = i % RL;
+      if constexpr (r < RL / 2) {
+        const int x = lane + LW * r;
+        dst[((size_t)(x / BC) * N + (iy0 + bb)) * BC + (x % BC)] = make_float2(v[i].x, v[i].y);
+      }
+    });
+  }
+}
+
+template <int RL, int LW, bool FUSED>
+__global__ __launch_bounds__(64 * kShFftWaves, 2) void k_sh_cols_sep(const float2* __restrict__ G1, double* __restrict__ image, const float2* __restrict__ tw,
+                                                                     const float2* __restrict__ hyq, double scale, ShFuseArgs f) {
+  extern __shared__ float lds_shfft[];
+  constexpr int L = LW * RL, N = L / 2, BC = 64 / RL, NK = N / RL;   // NK rows y = p + RL k2 per lane
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int cg = blockIdx.x * kShFftWaves + wave;
+  if (cg * BC >= N) return;
+  const int pp = lane / BC, bb = lane - pp * BC;
+  const int x = cg * BC + bb;
+  double* tab = reinterpret_cast<double*>(lds_shfft + (size_t)kShFftWaves * 64 * 65) + (size_t)wave * 3 * f.n_sub;   // [n_sub][3], this wave's
+  if constexpr (FUSED) {
+    for (int i = lane; i < 3 * f.n_sub; i += 64) tab[i] = 0.0;
+  }
+  const float2* src = G1 + (size_t)blockIdx.y * N * N + (size_t)cg * N * BC + lane;   // element (y = pp + RL k2, bb) at (y BC + bb) = lane + 64 k2
+  cf32 v[64];
+  static_for<64>([&](auto kc) {
+    constexpr int k2 = decltype(kc)::v;
+    if constexpr (k2 < NK) { const float2 t = src[(size_t)k2 * 64]; v[k2] = cf32{t.x, t.y}; }
+    else v[k2] = cf32{0.f, 0.f};   // the zero padding (y >= N)
+  });
+  float* lbuf = lds_shfft + (size_t)wave * 64 * 65;
+  sh_fft_b2a<RL, true, LW>(v, lbuf, tw);
+  static_for<RL>([&](auto rc) {
+    constexpr int r = decltype(rc)::v;
+    const float2 h = hyq[r * 64 + lane];
+    static_for<BC>([&](auto bc) { constexpr int i = decltype(bc)::v * RL + r; v[i] = cmul(v[i], cf32{h.x, h.y}); });
+  });
+  sh_fft_a2b<RL, false, LW>(v, lbuf, tw);
+  if constexpr (!FUSED) {
+    double* dst = image + (size_t)blockIdx.y * N * N + x;
+    static_for<NK>([&](auto kc) {
+      constexpr int k2 = decltype(kc)::v;
+      dst[(size_t)(pp + RL * k2) * N] = ((double)v[k2].x * (double)v[k2].x + (double)v[k2].y * (double)v[k2].y) * scale;
+    });
+  } else {
+    // this lane: NK rows of ONE column; running sums while consecutive rows of the lane (RL apart) stay in the same lenslet
+    const double xd = f.x_det[x];
+    int cur = -1;
+    double s0 = 0.0, sy = 0.0;
+    auto flush = [&](int slot, double a0, double ay) {
+      if (slot >= 0) {
+        atomicAdd(&tab[3 * slot], a0);
+        atomicAdd(&tab[3 * slot + 1], a0 * xd);
+        atomicAdd(&tab[3 * slot + 2], ay);
+      }
+    };
+    const size_t line = ((f.env_base + blockIdx.y) * N + x) * 64 + pp;   // (sh_noisy_value's key, sep_rl form)
+    uint32_t wa[4] = {0, 0, 0, 0}, wb[4] = {0, 0, 0, 0};
+    bool have_b = false;
+    static_for<NK>([&](auto kc) {
+      constexpr int k2 = decltype(kc)::v;
+      const int y = pp + RL * k2;
+      if constexpr ((k2 & 3) == 0) {
+        sh_noise_words(line, k2 >> 2, false, f.seed, f.call, wa);
+        have_b = false;
+      }
+      const double lam = ((double)v[k2].x * (double)v[k2].x + (double)v[k2].y * (double)v[k2].y) * scale;
+      const int slot = f.sub_slot[y * N + x];
+      if (slot != cur) {
+        flush(cur, s0, sy);
+        cur = slot; s0 = 0.0; sy = 0.0;
+      }
+      const bool small = slot >= 0 && lam < kShPoissonSwitch;
+      double out = sh_poisson_small(small ? lam : 0.0, wa[k2 & 3], small);   // (the wave's loop: every lane takes part)
+      if (slot >= 0) {
+        if (!small) {
+          if (!have_b) { sh_noise_words(line, k2 >> 2, true, f.seed, f.call, wb); have_b = true; }
+          out = sh_poisson_large(lam, wa[k2 & 3], wb[k2 & 3]);
+        }
+        const double w = out + 1e-10;   // estimate([image + 1e-10]) (AO_env.py:277)
+        s0 += w;
+        sy = fma(w, f.x_det[y], sy);
+      }
+    });
+    flush(cur, s0, sy);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    double* out = f.sums + (size_t)blockIdx.y * 3 * f.n_sub;
+    for (int i = lane; i < 3 * f.n_sub; i += 64) {
+      const double t = tab[i];
+      if (t != 0.0) atomicAdd(&out[i], t);
+    }
+  }
 }
 
 struct ShEstimateArgs {

@@ -234,7 +234,7 @@ def roofline_dominant(env, w, kernels, steps_range):
                                           ``roofline.traffic``) / measured time, against 1024 SIMDs x 2.4 GHz
       screen packing (config 3)           HBM: 4 N^2 read + 4 n_ap written per env
       extrusion (config 4)                float64 matrix cores: 2 N (nz + N) flop per one-pixel shift of one env (new = A z + B n)
-      Shack-Hartmann passes (config 5)    HBM: the three-pass layout's 72 N^2 bytes per env"""
+      Shack-Hartmann passes (config 5)    HBM: the layout's bytes per env (separable two-pass form: 20 N^2; three-pass form: 68 N^2)"""
     import numpy as np
 
     N, B = w["n_pupil"], env.num_envs
@@ -274,13 +274,17 @@ def roofline_dominant(env, w, kernels, steps_range):
                           "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flop / (ms * 1e-3 * n) / 1e12 / F64_MFMA_PEAK_TFLOPS,
                           "shifts_per_env_step": shifts / max(1, B * (steps_range[1] - steps_range[0])),
                           "note": "2 N (nz + N) flop per one-pixel shift of one env, shifts recomputed on the host for the timed steps"}
-    if all(k in kernels for k in ("sh_rows_fwd", "sh_cols", "sh_rows_inv")):
-        ms = sum(kernels[k][0] for k in ("sh_rows_fwd", "sh_cols", "sh_rows_inv"))
-        by = 72.0 * N * N * B
-        out["shack_hartmann"] = {"kernel": "k_sh_rows_fwd + k_sh_cols + k_sh_rows_inv", "bound": "hbm", "ms": ms, "launches": kernels["sh_cols"][1],
+    if all(k in kernels for k in ("sh_rows_fwd", "sh_cols")):
+        three = "sh_rows_inv" in kernels                      # (transfer functions that do not factorise keep the three-pass form)
+        names = ("sh_rows_fwd", "sh_cols", "sh_rows_inv") if three else ("sh_rows_fwd", "sh_cols")
+        ms = sum(kernels[k][0] for k in names)
+        by = (68.0 if three else 20.0) * N * N * B
+        out["shack_hartmann"] = {"kernel": "k_sh_rows_fwd + k_sh_cols + k_sh_rows_inv" if three else "k_sh_rows_sep + k_sh_cols_sep", "bound": "hbm", "ms": ms,
+                                 "launches": kernels["sh_cols"][1],
                                  "per_pass_ms": {k: kernels[k][0] for k in ("sh_field", "sh_rows_fwd", "sh_cols", "sh_rows_inv") if k in kernels},
                                  "achieved": by / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                 "note": "three-pass layout bytes per env: field 8 N^2 read, F1T and GT (2N x N complex64 each) written and read once"}
+                                 "note": ("three-pass layout bytes per env: phase grid 4 N^2 read, F1T and GT (2N x N complex64 each) written and read once" if three else
+                                          "separable two-pass layout bytes per env: phase grid 4 N^2 read, the N x N complex64 intermediate written and read once")}
     return out
 
 
