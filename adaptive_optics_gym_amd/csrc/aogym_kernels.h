@@ -3763,7 +3763,16 @@ __global__ __launch_bounds__(64 * kShFftWaves, 2) void k_sh_cols_sep(const float
       dst[(size_t)(pp + RL * k2) * N] = ((double)v[k2].x * (double)v[k2].x + (double)v[k2].y * (double)v[k2].y) * scale;
     });
   } else {
-    // this lane: NK rows of ONE column; running sums while consecutive rows of the lane (RL apart) stay in the same lenslet
+    // this lane: NK rows of ONE column; running sums while consecutive rows of the lane (RL apart) stay in the same lenslet.
+    // The intensities go through the wave's LDS plane (each lane its own NK doubles) and the pixels are walked by a REAL loop, four per
+    // Philox call: fully unrolled, the 32 pixels x 12-level Poisson chain made a 20 000-line kernel (more code than the instruction cache
+    // holds, fetched once per wave) whose register allocation spilled 76 - 360 registers.
+    static_assert((size_t)NK * 64 * sizeof(double) <= (size_t)64 * 65 * sizeof(float), "the intensities of a wave fit its transform plane");
+    double* lamp = reinterpret_cast<double*>(lbuf) + lane;
+    static_for<NK>([&](auto kc) {
+      constexpr int k2 = decltype(kc)::v;
+      lamp[k2 * 64] = ((double)v[k2].x * (double)v[k2].x + (double)v[k2].y * (double)v[k2].y) * scale;
+    });
     const double xd = f.x_det[x];
     int cur = -1;
     double s0 = 0.0, sy = 0.0;
@@ -3775,33 +3784,36 @@ __global__ __launch_bounds__(64 * kShFftWaves, 2) void k_sh_cols_sep(const float
       }
     };
     const size_t line = ((f.env_base + blockIdx.y) * N + x) * 64 + pp;   // (sh_noisy_value's key, sep_rl form)
-    uint32_t wa[4] = {0, 0, 0, 0}, wb[4] = {0, 0, 0, 0};
-    bool have_b = false;
-    static_for<NK>([&](auto kc) {
-      constexpr int k2 = decltype(kc)::v;
-      const int y = pp + RL * k2;
-      if constexpr ((k2 & 3) == 0) {
-        sh_noise_words(line, k2 >> 2, false, f.seed, f.call, wa);
-        have_b = false;
-      }
-      const double lam = ((double)v[k2].x * (double)v[k2].x + (double)v[k2].y * (double)v[k2].y) * scale;
-      const int slot = f.sub_slot[y * N + x];
-      if (slot != cur) {
-        flush(cur, s0, sy);
-        cur = slot; s0 = 0.0; sy = 0.0;
-      }
-      const bool small = slot >= 0 && lam < kShPoissonSwitch;
-      double out = sh_poisson_small(small ? lam : 0.0, wa[k2 & 3], small);   // (the wave's loop: every lane takes part)
-      if (slot >= 0) {
-        if (!small) {
-          if (!have_b) { sh_noise_words(line, k2 >> 2, true, f.seed, f.call, wb); have_b = true; }
-          out = sh_poisson_large(lam, wa[k2 & 3], wb[k2 & 3]);
+    const int32_t* slot_col = f.sub_slot + x;
+#pragma unroll 1
+    for (int k4 = 0; k4 < (NK + 3) / 4; ++k4) {
+      uint32_t wa[4], wb[4] = {0, 0, 0, 0};
+      sh_noise_words(line, (uint32_t)k4, false, f.seed, f.call, wa);
+      bool have_b = false;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k2 = 4 * k4 + j;
+        if (NK % 4 != 0 && k2 >= NK) break;   // (lines of 60 RL: NK = 30)
+        const int y = pp + RL * k2;
+        const double lam = lamp[k2 * 64];
+        const int slot = slot_col[(size_t)y * N];
+        if (slot != cur) {
+          flush(cur, s0, sy);
+          cur = slot; s0 = 0.0; sy = 0.0;
         }
-        const double w = out + 1e-10;   // estimate([image + 1e-10]) (AO_env.py:277)
-        s0 += w;
-        sy = fma(w, f.x_det[y], sy);
+        const bool small = slot >= 0 && lam < kShPoissonSwitch;
+        double out = sh_poisson_small(small ? lam : 0.0, wa[j], small);   // (the wave's loop: every lane takes part)
+        if (slot >= 0) {
+          if (!small) {
+            if (!have_b) { sh_noise_words(line, (uint32_t)k4, true, f.seed, f.call, wb); have_b = true; }
+            out = sh_poisson_large(lam, wa[j], wb[j]);
+          }
+          const double w = out + 1e-10;   // estimate([image + 1e-10]) (AO_env.py:277)
+          s0 += w;
+          sy = fma(w, f.x_det[y], sy);
+        }
       }
-    });
+    }
     flush(cur, s0, sy);
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
