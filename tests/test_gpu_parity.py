@@ -1001,6 +1001,34 @@ def test_shack_hartmann_pruned_propagation_matches_2d_transforms(N, B):
     plain.close()
 
 
+def test_shack_hartmann_three_pass_form_matches_the_separable_form(monkeypatch):
+    """The separable two-pass propagation (default: hcipy's Fresnel transfer function factorises) and the three-pass form kept for transfer
+    functions that do not (forced here with AOG_SH_THREE_PASS=1) give the same camera image to complex64 rounding, and each form's fused
+    noise + lenslet-sum path closes the loop (the two forms key the photon-noise stream differently, so only statistics are shared)."""
+    torch = _torch()
+    from adaptive_optics_gym_amd import BatchedAOEnv
+
+    B, N = 3, 256
+    scr = smooth_screens(B, N, 9) * 0.5
+    kw = dict(act_type="zernike", act_dim=8, obs_dim=2, timesteps_per_episode=50, num_pupil_pixels=N, SH_operation=True, verbose=False, seed=4)
+    sep = BatchedAOEnv(B, "cuda:0", screens=scr, **kw)
+    monkeypatch.setenv("AOG_SH_THREE_PASS", "1")
+    three = BatchedAOEnv(B, "cuda:0", screens=scr, **kw)
+    monkeypatch.delenv("AOG_SH_THREE_PASS")
+    sep.reset(); three.reset()
+    a = sep.sh_image().cpu().numpy()
+    b = three.sh_image().cpu().numpy()
+    for e in range(B):
+        np.testing.assert_allclose(a[e], b[e], rtol=0, atol=5e-6 * b[e].max())
+    s0 = sep.step(torch.zeros((B, 8), device="cuda"))[4]["strehl"].cpu().numpy()
+    for env in (sep, three):
+        for _ in range(10):
+            act, _ = env.SH_step()
+            s1 = env.step(act)[4]["strehl"].cpu().numpy()
+        assert np.all(s1 > s0)          # both controllers flatten the wavefront
+        env.close()
+
+
 def test_shack_hartmann_device_noise_closed_loop():
     torch = _torch()
     from adaptive_optics_gym_amd import BatchedAOEnv
