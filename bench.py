@@ -279,7 +279,17 @@ def roofline_dominant(env, w, kernels, steps_range):
         names = ("sh_rows_fwd", "sh_cols", "sh_rows_inv") if three else ("sh_rows_fwd", "sh_cols")
         ms = sum(kernels[k][0] for k in names)
         by = (68.0 if three else 20.0) * N * N * B
+        issue = None
+        try:   # PMC citation (profiles/sh_pmc_latest.json: instruction counts at the same pupil size): the separable passes are bound by vector issue
+            c = json.load(open(os.path.join(ROOT, "profiles", "sh_pmc_latest.json")))
+            if not three and c.get("n_pupil") == N and c.get("envs_per_launch"):
+                cyc = sum(c[k]["issue_cycles"] for k in ("k_sh_rows_sep", "k_sh_cols_sep")) / c["envs_per_launch"] * B
+                issue = {"achieved": cyc / (ms * 1e-3), "peak": ISSUE_CYCLES_PEAK, "unit": "SIMD issue cycles/s", "frac": cyc / (ms * 1e-3) / ISSUE_CYCLES_PEAK,
+                         "note": "issue cycles per env from profiles/sh_pmc_latest.json (PMC citation), time from this run's HIP events"}
+        except Exception:
+            issue = None
         out["shack_hartmann"] = {"kernel": "k_sh_rows_fwd + k_sh_cols + k_sh_rows_inv" if three else "k_sh_rows_sep + k_sh_cols_sep", "bound": "hbm", "ms": ms,
+                                 "valu_issue": issue,
                                  "launches": kernels["sh_cols"][1],
                                  "per_pass_ms": {k: kernels[k][0] for k in ("sh_field", "sh_rows_fwd", "sh_cols", "sh_rows_inv") if k in kernels},
                                  "achieved": by / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -34,6 +34,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_c2_b409
 bash $R/tools/pmc_collect.sh gpurun_out/${TAG}_pmc_b4096 --B 4096 > $OUT/${TAG}_pmc_b4096.log 2>&1
 # 5. PMC of the reset kernels (semi_dynamic reset of 4096 envs: two-band synthesis + packing) and of the other rows' dominant kernels
 bash $R/tools/pmc_kernels.sh gpurun_out/${TAG}_pmc_reset $R/tools/reset_loop.py --B 4096 --episodes 1 > $OUT/${TAG}_pmc_reset.log 2>&1
+bash $R/tools/pmc_kernels.sh gpurun_out/${TAG}_pmc_sh $R/tools/sh_loop2.py 1024 512 20 single > $OUT/${TAG}_pmc_sh.log 2>&1
 fi
 cd $R
 # 4. summaries (from the raw files under gpurun_out/)
@@ -45,12 +46,21 @@ python3 tools/summarize_prof.py --stats gpurun_out/${TAG}_prof_c2_b4096 --pmc gp
   echo "# ${TAG}_reset_pmc — counters of the semi_dynamic reset kernels (tools/reset_loop.py --B 4096 --episodes 1: launches of 4096 envs)"; echo
   python3 tools/summarize_pmc.py gpurun_out/${TAG}_pmc_reset --tag ${TAG}_reset --kernels k_screen2_rows k_screen2_cols k_screen_means k_pack_tiles
 } > profiles/${TAG}_reset_pmc.md
+{
+  echo "# ${TAG}_sh_pmc — counters of the Shack-Hartmann kernels at config 5's pupil (tools/sh_loop2.py 1024 512 20 single: launches of 1024 envs, N = 512)"; echo
+  python3 tools/summarize_pmc.py gpurun_out/${TAG}_pmc_sh --tag ${TAG}_sh --kernels k_phase_mfma k_sh_rows_sep k_sh_cols_sep
+} > profiles/${TAG}_sh_pmc.md
 python3 - <<PY
 import json
 d = json.load(open("profiles/${TAG}_reset_pmc.json"))
 d["envs_per_launch"] = 4096
 d["source"] = "${TAG}_reset_pmc"
 json.dump(d, open("profiles/reset_pmc_latest.json", "w"), indent=1)
+d = json.load(open("profiles/${TAG}_sh_pmc.json"))
+d["envs_per_launch"] = 1024
+d["n_pupil"] = 512
+d["source"] = "${TAG}_sh_pmc"
+json.dump(d, open("profiles/sh_pmc_latest.json", "w"), indent=1)
 PY
 {
   echo "# ${TAG}_next_rows — bench lines and per-kernel time of the other BASELINE configs and of the SURVEY 8(f) rows (rocprofv3 --kernel-trace --stats, 1x MI355X)"
