@@ -1304,12 +1304,6 @@ int aog_upload_sh(aog_env* e, const aog_sh_tables* t) {
     // pruned three-pass propagation (k_sh_rows_fwd / k_sh_cols / k_sh_rows_inv): F1T [B][2N][N] in sh_pad; compact field [B][N][N] and
     // GT [B][2N][N] in sh_in (zeroed once: pixels outside the aperture are never written)
     const int L = 2 * N, RL = e->sh_pruned, BC = 64 / RL;
-    char* p1 = nullptr;
-    char* p2 = nullptr;
-    if ((rc = dev_alloc(e, &p1, (size_t)e->B * N2 * 2 * sizeof(float) * 2, false)) != AOG_OK) return rc;
-    if ((rc = dev_alloc(e, &p2, (size_t)e->B * N2 * 3 * sizeof(float) * 2, true)) != AOG_OK) return rc;
-    e->sh_pad = p1;
-    e->sh_in = p2;
     std::vector<float> tw((size_t)L * 2), tfq((size_t)(L / BC) * 64 * 64 * 2);
     for (int j = 0; j < L; ++j) {
       tw[2 * j] = (float)cos(2.0 * M_PI * j / L);
@@ -1348,6 +1342,16 @@ int aog_upload_sh(aog_env* e, const aog_sh_tables* t) {
           }
       }
       e->sh_sep_rl = (worst <= 1e-9 && !getenv("AOG_SH_THREE_PASS")) ? RL : 0;
+      // work buffers.  Separable form: phase grid [B][N][N] fp32 (sh_in) + the one intermediate G1 [B][N][N] complex64 (sh_pad).  Three-pass
+      // form: phase grid + GT [B][2N][N] complex64 (sh_in, zeroed once) + F1T [B][2N][N] complex64 (sh_pad).
+      char* p1 = nullptr;
+      char* p2 = nullptr;
+      const size_t pad_bytes = e->sh_sep_rl ? (size_t)e->B * N2 * sizeof(float) * 2 : (size_t)e->B * N2 * 2 * sizeof(float) * 2;
+      const size_t in_bytes = e->sh_sep_rl ? (size_t)e->B * N2 * sizeof(float) : (size_t)e->B * N2 * 3 * sizeof(float) * 2;
+      if ((rc = dev_alloc(e, &p1, pad_bytes, false)) != AOG_OK) return rc;
+      if ((rc = dev_alloc(e, &p2, in_bytes, true)) != AOG_OK) return rc;
+      e->sh_pad = p1;
+      e->sh_in = p2;
       if (e->sh_sep_rl) {
         std::vector<float> hxq((size_t)sh_lw * 64 * 2), hyq((size_t)RL * 64 * 2, 0.f);
         for (int k2 = 0; k2 < sh_lw; ++k2)
