@@ -848,6 +848,36 @@ def test_pruned_screen_synthesis_matches_full_transform(monkeypatch, method, N, 
     assert np.abs(p2 - f2).max() < 3e-5 * rms
 
 
+@pytest.mark.parametrize("first,count,B", [(0, 70, 70), (5, 70, 100), (33, 8, 64), (31, 34, 65)])
+def test_batched_screen_installation_equals_one_by_one(first, count, B):
+    """``set_screens`` converts batches of >= 8 screens with the tiled kernels (k_screen_means + k_pack_tiles: whole-line stores per env
+    tile) and fewer with k_pack_screens (one workgroup per env): both must store bit-identical values, for env ranges that start and end
+    inside env tiles of 32, and must leave the envs outside the range alone."""
+    torch = _torch()
+    from adaptive_optics_gym_amd import BatchedAOEnv
+
+    N = 64
+    rng = np.random.RandomState(first * 100 + count)
+    base = smooth_screens(B, N, 3)
+    new = smooth_screens(count, N, 4) * 1.7 + 1e-6 * rng.randn(count, N, N)
+    kw = dict(act_type="zernike", act_dim=6, obs_dim=2, num_pupil_pixels=N, verbose=False)
+    a = BatchedAOEnv(B, "cuda:0", screens=base, **kw)
+    b = BatchedAOEnv(B, "cuda:0", screens=base, **kw)
+    a.set_screens(new, first=first)                         # one call: the tiled path
+    for i in range(count):
+        b.set_screens(new[i:i + 1], first=first + i)        # one env at a time: k_pack_screens
+    sa, sb = a.get_screens().cpu(), b.get_screens().cpu()
+    assert torch.equal(sa, sb)
+    untouched = [i for i in range(B) if not (first <= i < first + count)]
+    if untouched:
+        ref = BatchedAOEnv(B, "cuda:0", screens=base, **kw)
+        assert torch.equal(sa[untouched], ref.get_screens().cpu()[untouched])
+        ref.close()
+    act = torch.from_numpy(rng.randn(B, 6).astype(np.float32)).cuda()
+    assert torch.equal(a.step(act)[4]["obs_raw"], b.step(act)[4]["obs_raw"])
+    a.close(); b.close()
+
+
 def test_switching_the_screen_method_gives_the_workspace_back():
     """``aog_set_screen_method`` between resets: each method draws its own (reproducible) stream, and the workspace of the method that is
     left is released instead of piling up until ``aog_destroy`` (the literal form's is 4 MB per env at N = 64, q = 16)."""
