@@ -148,6 +148,32 @@ void launch_phase_field(aog_env* e, hipStream_t s, const _Float16* act16, float*
     default: launch_phase_field_t<128>(e, s, act16, fa, grid); break;
   }
 }
+// K4: reduced phases of env tiles [etile0, etile0 + n_et) as one float per pixel on a dense [env][rows][row_stride] grid (no micro-lens term)
+template <int A_PAD>
+static void launch_phase_grid_t(aog_env* e, hipStream_t s, const _Float16* act16, const aog::PhaseFieldArgs& fa, int etile0, int n_et) {
+  hipLaunchKernelGGL((aog::k_phase_mfma<A_PAD, true, true>), dim3((e->n_ptiles + 3) / 4, n_et), dim3(256), 0, s,
+                     reinterpret_cast<const aog::f16x8*>(e->modes16), reinterpret_cast<const aog::f32x4*>(e->psi_tile) + (size_t)etile0 * e->n_ptiles * 4 * 64,
+                     reinterpret_cast<const aog::f16x8*>(act16) + (size_t)etile0 * (A_PAD / 16) * 2 * 64, static_cast<aog::f32x4*>(nullptr), e->n_ptiles,
+                     n_et, fa);
+}
+void launch_phase_grid(aog_env* e, hipStream_t s, const _Float16* act16, float* grid, size_t env_stride, int row_stride, int etile0, int n_et) {
+  aog::PhaseFieldArgs fa{};
+  fa.ap_yx = e->focal_ap_yx;
+  fa.mla_rev = nullptr;
+  fa.act_ll = reinterpret_cast<const aog::f16x8*>(e->focal_act_ll) + (size_t)etile0 * (e->A_pad / 16) * 64;
+  fa.field = reinterpret_cast<float2*>(grid);   // grid row 0 = env etile0 * 32
+  fa.env_stride = env_stride;
+  fa.row_stride = row_stride;
+  fa.n_ap = e->n_ap;
+  fa.B = e->B - etile0 * 32;
+  fa.N = e->cfg.n_pupil;
+  switch (e->A_pad) {
+    case 16: launch_phase_grid_t<16>(e, s, act16, fa, etile0, n_et); break;
+    case 32: launch_phase_grid_t<32>(e, s, act16, fa, etile0, n_et); break;
+    case 64: launch_phase_grid_t<64>(e, s, act16, fa, etile0, n_et); break;
+    default: launch_phase_grid_t<128>(e, s, act16, fa, etile0, n_et); break;
+  }
+}
 void launch_phase(aog_env* e, hipStream_t s, const _Float16* act16, float* out_tile) {
   switch (e->A_pad) {
     case 16: launch_phase_t<16>(e, s, act16, out_tile); break;
@@ -822,16 +848,56 @@ int aog_upload_tables(aog_env* e, const aog_tables* t) {
     if ((rc = dev_alloc(e, &e->focal_T, (size_t)nf * N * 2)) != AOG_OK) return rc;
     HIP_TRY(hipMemcpy(e->focal_m1, t->focal_m1, sizeof(double) * nf * N * 2, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->focal_m2, t->focal_m2, sizeof(double) * nf * N * 2, hipMemcpyHostToDevice));
-    if (e->cfg.precision == AOG_PRECISION_FAST) {   // complex64 copies for the batched matrix-core path
-      std::vector<float> f1((size_t)nf * N * 2), f2((size_t)nf * N * 2);
-      for (size_t i = 0; i < f1.size(); ++i) {
-        f1[i] = (float)t->focal_m1[i];
-        f2[i] = (float)t->focal_m2[i];
-      }
-      if ((rc = dev_alloc(e, &e->focal_m1f, f1.size(), false)) != AOG_OK) return rc;
-      if ((rc = dev_alloc(e, &e->focal_m2f, f2.size(), false)) != AOG_OK) return rc;
-      HIP_TRY(hipMemcpy(e->focal_m1f, f1.data(), sizeof(float) * f1.size(), hipMemcpyHostToDevice));
-      HIP_TRY(hipMemcpy(e->focal_m2f, f2.data(), sizeof(float) * f2.size(), hipMemcpyHostToDevice));
+    if (e->cfg.precision == AOG_PRECISION_FAST) {   // split-f16 operand tables of the batched matrix-core path (k_focal_pass1 / k_focal_pass2)
+      const int Nxp = round_up(N, 128), Nyp = round_up(N, 16), nfp = round_up(nf, 128);
+      // power-of-two scales: the largest component of a table lands in [1/2, 1)
+      auto scale_of = [](const double* v, size_t n) {
+        double mx = 0.0;
+        for (size_t i = 0; i < n; ++i) mx = std::max(mx, std::fabs(v[i]));
+        return mx > 0.0 ? std::ldexp(1.0, -(std::ilogb(mx) + 1)) : 1.0;
+      };
+      const double s1 = scale_of(t->focal_m1, (size_t)nf * N * 2), s2 = scale_of(t->focal_m2, (size_t)nf * N * 2);
+      auto put = [](std::vector<_Float16>& tab, size_t tile, int lane, int slot, double re, double im) {
+        const double c[2] = {re, im};
+        for (int q = 0; q < 2; ++q) {
+          const _Float16 hi = (_Float16)(float)c[q];   // round to nearest, like the kernels' split8
+          tab[((tile * 4 + 2 * q) * 64 + lane) * 8 + slot] = hi;
+          tab[((tile * 4 + 2 * q + 1) * 64 + lane) * 8 + slot] = (_Float16)(float)(c[q] - (double)(float)hi);
+        }
+      };
+      // m1s [v block][k-step over y]: lane l = column v = 32 vb + (l & 31), slot j = y = 16 ks + 8 (l >> 5) + j
+      std::vector<_Float16> m1s((size_t)(nfp / 32) * (Nyp / 16) * 4 * 64 * 8, (_Float16)0.f);
+      for (int vb = 0; vb < nfp / 32; ++vb)
+        for (int ks = 0; ks < Nyp / 16; ++ks)
+          for (int l = 0; l < 64; ++l)
+            for (int j = 0; j < 8; ++j) {
+              const int v = 32 * vb + (l & 31), y = 16 * ks + 8 * (l >> 5) + j;
+              if (v < nf && y < N)
+                put(m1s, (size_t)vb * (Nyp / 16) + ks, l, j, t->focal_m1[((size_t)v * N + y) * 2] * s1, t->focal_m1[((size_t)v * N + y) * 2 + 1] * s1);
+            }
+      // m2s [u block][x tile][s]: lane l = column u = 32 ub + (l & 31), slot j = x = 32 xt + (r & 3) + 8 (r >> 2) + 4 (l >> 5), r = 8 s + j
+      // (the order in which pass 1's accumulator registers hold x)
+      std::vector<_Float16> m2s((size_t)(nfp / 32) * (Nxp / 32) * 2 * 4 * 64 * 8, (_Float16)0.f);
+      for (int ub = 0; ub < nfp / 32; ++ub)
+        for (int xt = 0; xt < Nxp / 32; ++xt)
+          for (int s2i = 0; s2i < 2; ++s2i)
+            for (int l = 0; l < 64; ++l)
+              for (int j = 0; j < 8; ++j) {
+                const int r = 8 * s2i + j, x = 32 * xt + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), u = 32 * ub + (l & 31);
+                if (u < nf && x < N)
+                  put(m2s, ((size_t)ub * (Nxp / 32) + xt) * 2 + s2i, l, j, t->focal_m2[((size_t)x * nf + u) * 2] * s2,
+                      t->focal_m2[((size_t)x * nf + u) * 2 + 1] * s2);
+              }
+      if ((rc = dev_alloc(e, &e->focal_m1s, m1s.size(), false)) != AOG_OK) return rc;
+      if ((rc = dev_alloc(e, &e->focal_m2s, m2s.size(), false)) != AOG_OK) return rc;
+      HIP_TRY(hipMemcpy(e->focal_m1s, m1s.data(), sizeof(_Float16) * m1s.size(), hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(e->focal_m2s, m2s.data(), sizeof(_Float16) * m2s.size(), hipMemcpyHostToDevice));
+      e->focal_unscale = (float)(1.0 / (s1 * s2));
+      std::vector<int32_t> apidx((size_t)e->n_ap), yx((size_t)e->n_ap);
+      HIP_TRY(hipMemcpy(apidx.data(), e->ap_index, sizeof(int32_t) * e->n_ap, hipMemcpyDeviceToHost));
+      for (int i = 0; i < e->n_ap; ++i) yx[i] = ((apidx[i] / N) << 16) | (apidx[i] % N);
+      if ((rc = dev_alloc(e, &e->focal_ap_yx, yx.size(), false)) != AOG_OK) return rc;
+      HIP_TRY(hipMemcpy(e->focal_ap_yx, yx.data(), sizeof(int32_t) * yx.size(), hipMemcpyHostToDevice));
     }
     e->n_focal = nf;
   }
@@ -1821,7 +1887,7 @@ int aog_focal_image(aog_env* e, int env_index, float* field_dev, void* stream) {
   if (env_index < 0 || env_index >= e->B) return fail(AOG_ERR_INVALID, "aog_focal_image: env %d outside [0,%d)", env_index, e->B);
   if (int rcp = refuse_pre_evolved(e, "aog_focal_image")) return rcp;
   const bool fast = e->cfg.precision == AOG_PRECISION_FAST;
-  if (fast && e->focal_m1f) return aog_focal_images(e, env_index, 1, field_dev, stream);   // the batched matrix-core path
+  if (fast && e->focal_m1s) return aog_focal_images(e, env_index, 1, field_dev, stream);   // the batched matrix-core path
   HIP_TRY(hipSetDevice(e->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int N = e->cfg.n_pupil, nf = e->n_focal;
@@ -1842,21 +1908,27 @@ int aog_focal_images(aog_env* e, int first, int count, float* field_dev, void* s
   if (!e->tables_ready || !e->screens_ready) return fail(AOG_ERR_STATE, "aog_focal_images before aog_upload_tables/aog_set_screens");
   if (!e->n_focal) return fail(AOG_ERR_STATE, "aog_focal_images: focal_m1/focal_m2 were not uploaded");
   if (first < 0 || count < 0 || first + count > e->B) return fail(AOG_ERR_INVALID, "aog_focal_images: env range outside [0,%d)", e->B);
-  if (e->cfg.precision != AOG_PRECISION_FAST || !e->focal_m1f)
+  if (e->cfg.precision != AOG_PRECISION_FAST || !e->focal_m1s)
     return fail(AOG_ERR_UNSUPPORTED, "aog_focal_images: fast-precision handles only (use aog_focal_image on a float64 validation handle)");
   if (int rcp = refuse_pre_evolved(e, "aog_focal_images")) return rcp;
   if (count == 0) return AOG_OK;
   HIP_TRY(hipSetDevice(e->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int N = e->cfg.n_pupil, nf = e->n_focal;
-  const size_t N2 = (size_t)N * N;
   int rc;
-  if (!e->focal_phase) {
-    // work buffers on first use: phases of the whole batch (the contraction runs on whole env tiles), E and T for a chunk of envs
-    e->focal_chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)e->B, ((size_t)256 << 20) / (N2 * 8)));
-    if ((rc = dev_alloc(e, &e->focal_phase, (size_t)e->n_etiles * e->n_ptiles * 1024, false)) != AOG_OK) return rc;
-    if ((rc = dev_alloc(e, &e->focal_Eb, (size_t)e->focal_chunk * N2 * 2, true)) != AOG_OK) return rc;   // zeroed ONCE: only aperture pixels are ever written
-    if ((rc = dev_alloc(e, &e->focal_Tb, (size_t)e->focal_chunk * nf * N * 2, false)) != AOG_OK) return rc;
+  const int Nxp = round_up(N, 128), Nyp = round_up(N, 16), nfp = round_up(nf, 128);
+  const size_t grid_env = (size_t)Nyp * Nxp, t16_env = (size_t)(Nxp / 32) * (nfp / 32) * 2 * 4 * 64 * 8;
+  if (!e->focal_grid) {
+    // work buffers on first use, for a chunk of whole env tiles: the phase grid (every pixel starts out as "outside the aperture": only
+    // aperture pixels are ever written) and T' (split f16, pass 2's operand order)
+    const size_t cap = std::max<size_t>(32, (((size_t)256 << 20) / std::max(grid_env * 4, t16_env * 2)) / 32 * 32);
+    e->focal_chunk = (int)std::min<size_t>((size_t)e->n_etiles * 32, cap);
+    if ((rc = dev_alloc(e, &e->focal_grid, (size_t)e->focal_chunk * grid_env, false)) != AOG_OK) return rc;
+    if ((rc = dev_alloc(e, &e->focal_T16, (size_t)e->focal_chunk * t16_env, false)) != AOG_OK) return rc;
+    if ((rc = dev_alloc(e, &e->focal_act_ll, (size_t)e->n_etiles * 32 * e->A_pad, true)) != AOG_OK) return rc;
+    std::vector<float> fill(grid_env, aog::kShOutside);
+    for (int i = 0; i < e->focal_chunk; ++i)
+      HIP_TRY(hipMemcpy(e->focal_grid + (size_t)i * grid_env, fill.data(), sizeof(float) * grid_env, hipMemcpyHostToDevice));
   }
   // psi_tile is always current for quasi_static / semi_dynamic handles; dynamic ones refresh it here when the step kernel does not use it
   if ((rc = ensure_tiles(e, s)) != AOG_OK) return rc;
@@ -1865,19 +1937,18 @@ int aog_focal_images(aog_env* e, int first, int count, float* field_dev, void* s
   {
     const int n = e->B * e->A_pad;
     hipLaunchKernelGGL(aog::k_load_actuators, dim3((n + 255) / 256), dim3(256), 0, s, e->act_dm, e->act_rev, e->act16, e->B, e->A, e->A_pad, e->Bp,
-                       2.0 / e->cfg.wavelength_wfs);
+                       2.0 / e->cfg.wavelength_wfs, e->focal_act_ll);
   }
-  aog_host::launch_phase(e, s, e->act16, e->focal_phase);
-  for (int done = 0; done < count; done += e->focal_chunk) {
-    const int nb = std::min(e->focal_chunk, count - done);
-    hipLaunchKernelGGL(aog::k_focal_E_batched, dim3((e->n_ap + 255) / 256, nb), dim3(256), 0, s, e->focal_phase, e->ap_index,
-                       reinterpret_cast<float2*>(e->focal_Eb), first + done, e->n_ap, e->n_ptiles, (int)N2);
-    // T[b] = m1 (nf x N) . E[b] (N x N);   F[b] = T[b] (nf x N) . m2 (N x nf)
-    hipLaunchKernelGGL(aog::k_cgemm_mfma, dim3((N + 63) / 64, (nf + 63) / 64, nb), dim3(256), 0, s, reinterpret_cast<const float2*>(e->focal_m1f),
-                       reinterpret_cast<const float2*>(e->focal_Eb), reinterpret_cast<float2*>(e->focal_Tb), nf, N, N, (size_t)0, N2, (size_t)nf * N);
-    hipLaunchKernelGGL(aog::k_cgemm_mfma, dim3((nf + 63) / 64, (nf + 63) / 64, nb), dim3(256), 0, s, reinterpret_cast<const float2*>(e->focal_Tb),
-                       reinterpret_cast<const float2*>(e->focal_m2f), reinterpret_cast<float2*>(field_dev) + (size_t)done * nf * nf, nf, nf, N,
-                       (size_t)nf * N, (size_t)0, (size_t)nf * nf);
+  for (int env0 = first / 32 * 32; env0 < first + count; env0 += e->focal_chunk) {
+    const int env1 = std::min(first + count, env0 + e->focal_chunk);          // envs [lo, env1) of this chunk are asked for
+    const int lo = std::max(first, env0), n_et = (env1 - env0 + 31) / 32;
+    aog_host::launch_phase_grid(e, s, e->act16, e->focal_grid, grid_env, Nxp, env0 / 32, n_et);
+    const size_t skip = (size_t)(lo - env0);
+    hipLaunchKernelGGL(aog::k_focal_pass1, dim3(Nxp / 128, nfp / 128, env1 - lo), dim3(256), 0, s, e->focal_grid + skip * grid_env,
+                       reinterpret_cast<const aog::f16x8*>(e->focal_m1s), reinterpret_cast<aog::f16x8*>(e->focal_T16), Nxp, Nyp, nfp);
+    hipLaunchKernelGGL(aog::k_focal_pass2, dim3(nfp / 128, nfp / 128, env1 - lo), dim3(256), 0, s, reinterpret_cast<const aog::f16x8*>(e->focal_T16),
+                       reinterpret_cast<const aog::f16x8*>(e->focal_m2s), reinterpret_cast<float2*>(field_dev) + (size_t)(lo - first) * nf * nf, Nxp, nfp,
+                       nf, e->focal_unscale);
     HIP_TRY(hipGetLastError());
   }
   return AOG_OK;

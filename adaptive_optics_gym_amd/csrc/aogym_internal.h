@@ -90,11 +90,13 @@ struct aog_env {
   double* focal_m2 = nullptr;    // [N][n_focal] complex
   double* focal_E = nullptr;     // [N][N] complex scratch
   double* focal_T = nullptr;     // [n_focal][N] complex scratch
-  float* focal_m1f = nullptr;    // complex64 copies for the batched matrix-core path (aog_focal_images)
-  float* focal_m2f = nullptr;
-  float* focal_phase = nullptr;  // [n_etiles][n_ptiles][1024] phases (revolutions) of the whole batch, psi_tile layout
-  float* focal_Eb = nullptr;     // [focal_chunk][N][N] complex64
-  float* focal_Tb = nullptr;     // [focal_chunk][n_focal][N] complex64
+  _Float16* focal_m1s = nullptr; // split-f16 operand tiles of the batched matrix-core path (aog_focal_images): m1 2^e1, [v block][k-step][4][64][8]
+  _Float16* focal_m2s = nullptr; // m2 2^e2, [u block][x tile][2][4][64][8] (x in the order pass 1's accumulators hold it)
+  float focal_unscale = 1.f;     // 2^-(e1 + e2)
+  int32_t* focal_ap_yx = nullptr;  // [n_ap] iy << 16 | ix of aperture pixel p
+  float* focal_grid = nullptr;   // [focal_chunk][Nyp][Nxp] reduced phases (revolutions), kShOutside outside the aperture
+  _Float16* focal_act_ll = nullptr;  // [n_etiles][A_pad / 16][64][8] third f16 term of the actuators (K4 phases)
+  _Float16* focal_T16 = nullptr; // [focal_chunk][Nxp / 32][nfp / 32][2][4][64][8]: T' = m1' E, split, pass 2's operand order
   int focal_chunk = 0;
   // state
   float* psi_rev = nullptr;      // [n_quads][Bp][4]  (handles that run the VALU kernel only)
@@ -189,5 +191,6 @@ int launch_fused_apad64(aog_env* e, hipStream_t s);
 int launch_fused_apad128(aog_env* e, hipStream_t s);
 // phase-only contraction u = psi + Mt a for every (pixel, env) with the actuator operands `act16`, written in the psi_tile layout
 void launch_phase(aog_env* e, hipStream_t s, const _Float16* act16, float* out_tile);
+void launch_phase_grid(aog_env* e, hipStream_t s, const _Float16* act16, float* grid, size_t env_stride, int row_stride, int etile0, int n_et);
 void launch_phase_field(aog_env* e, hipStream_t s, const _Float16* act16, float* field, size_t env_stride, int row_stride, bool grid);   // complex64 field, or (grid) one float of reduced phase per pixel
 }  // namespace aog_host

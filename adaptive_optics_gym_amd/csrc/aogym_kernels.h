@@ -302,14 +302,24 @@ __global__ __launch_bounds__(64 * kProEnvs) void k_prologue(const float* __restr
 
 // actuators (metres, float64) -> the two fp32 operand layouts (used by reset / set_actuators)
 #ifdef AOG_MAIN_TU
+// act16_ll (nullable, K4): what the two f16 halves of act16 leave of the float64 actuator, as a third f16 term in the same operand order
+// without the hi | lo dimension: [env tile][A_pad / 16][lane][8]
 __global__ void k_load_actuators(const double* __restrict__ act_dm, float* __restrict__ act_rev,
-                                 _Float16* __restrict__ act16, int B, int A, int A_pad, int Bp, double two_over_lambda) {
+                                 _Float16* __restrict__ act16, int B, int A, int A_pad, int Bp, double two_over_lambda,
+                                 _Float16* __restrict__ act16_ll = nullptr) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= B * A_pad) return;
   const int env = idx / A_pad, i = idx % A_pad;
-  const float ar = (i < A) ? (float)(act_dm[(size_t)env * A + i] * two_over_lambda) : 0.f;
+  const double a64 = (i < A) ? act_dm[(size_t)env * A + i] * two_over_lambda : 0.0;
+  const float ar = (float)a64;
   act_rev[(size_t)i * Bp + env] = ar;
   store_act16(act16, env, i, A_pad, ar);
+  if (act16_ll && !(A_pad & 15)) {
+    const float sc = ar * 256.0f;   // (as store_act16)
+    const _Float16 hi = (_Float16)sc, lo = (_Float16)(sc - (float)hi);
+    const int s = i >> 4, h = (i >> 3) & 1, el = i & 7, nstep = A_pad >> 4;
+    act16_ll[((((size_t)(env >> 5) * nstep + s)) * 64 + (h * 32 + (env & 31))) * 8 + el] = (_Float16)(float)(a64 * 256.0 - (double)(float)hi - (double)(float)lo);
+  }
 }
 #endif  // AOG_MAIN_TU
 
@@ -923,6 +933,7 @@ struct PhaseFieldArgs {
   const int32_t* ap_yx;      // [n_ap] iy << 16 | ix
   const float2* mla32;       // [N*N] micro-lens phase factor, complex64
   const float* mla_rev;      // [n_ap] its argument in revolutions per packed aperture pixel (GRID form)
+  const f16x8* act_ll;       // nullable (K4): third f16 term of the actuators, [env tile][A_pad / 16][64][8] (see k_load_actuators)
   float2* field;
   size_t env_stride;
   int row_stride, n_ap, B, N;
@@ -940,8 +951,10 @@ __global__ __launch_bounds__(256) void k_phase_mfma(const f16x8* __restrict__ mo
   const int lane = threadIdx.x & 63;
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int etile = blockIdx.y;
-  __shared__ float2 field_lds[FIELD ? 4 * 32 * 33 : 1];
-  float2* field_tile = field_lds + (FIELD ? (threadIdx.x >> 6) * 32 * 33 : 0);
+  __shared__ float2 field_lds[(FIELD && !GRID) ? 4 * 32 * 33 : 1];
+  __shared__ float grid_lds[GRID ? 4 * 32 * 33 : 1];   // (GRID: one float per pixel — half the LDS, twice the workgroups per CU)
+  [[maybe_unused]] float2* field_tile = field_lds + ((FIELD && !GRID) ? (threadIdx.x >> 6) * 32 * 33 : 0);
+  [[maybe_unused]] float* grid_tile = grid_lds + (GRID ? (threadIdx.x >> 6) * 32 * 33 : 0);
   if (t >= n_ptiles || etile >= n_etiles) return;
   const f16x8* asrc = act16 + ((size_t)etile * NSTEP * 2) * 64 + lane;
   const f16x8* ms = modes16 + ((size_t)t * NSTEP * 2) * 64 + lane;
@@ -952,6 +965,12 @@ __global__ __launch_bounds__(256) void k_phase_mfma(const f16x8* __restrict__ mo
     d = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh, bh, d, 0, 0, 0);
     d = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh, bl, d, 0, 0, 0);
     d = __builtin_amdgcn_mfma_f32_32x32x16_f16(ml, bh, d, 0, 0, 0);
+    if constexpr (GRID) {
+      // K4: the actuators to 33 bits.  A rounding error of an ACTUATOR is a smooth phase error over the whole pupil — it does not average
+      // down over the pixels like the per-pixel rounding of a mode value does — and at 2^-23 of an actuator of half a revolution it was
+      // most of the error of the focal fields (7e-8 of the peak amplitude, the whole tolerance of a pixel 30 dB down)
+      if (fa.act_ll) d = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh, fa.act_ll[((size_t)etile * NSTEP + s) * 64 + lane], d, 0, 0, 0);
+    }
   }
   const size_t base = (((size_t)etile * n_ptiles + t) * 4) * 64 + lane;
   [[maybe_unused]] const int h = lane >> 5;
@@ -973,8 +992,12 @@ __global__ __launch_bounds__(256) void k_phase_mfma(const f16x8* __restrict__ mo
         const int pix = min(t * 32 + q, fa.n_ap - 1);
         [[maybe_unused]] const int yx = GRID ? 0 : fa.ap_yx[pix], iy = yx >> 16, ix = yx & 0xffff;
         if constexpr (GRID) {
-          const float w = (o[r] - rintf(o[r])) + fa.mla_rev[pix];   // + the micro-lens phase of this pixel, in revolutions
-          field_tile[(lane & 31) * 33 + q] = make_float2(w - rintf(w), 0.f);
+          // screen and mirror phase are reduced to a revolution EACH before they are added: their sum then rounds at 2^-25 .. 2^-24 of a
+          // revolution instead of at the ulp of a phase of several revolutions (which was most of the error of the K4 focal fields: 0.93
+          // -> 0.5 of the test tolerance at N = 64, where the image is a speckle field and every pixel's phase error counts)
+          const float dm = d[4 * g + r] * kPhaseUnscale, ps = p[r];
+          const float w = ((ps - rintf(ps)) + (dm - rintf(dm))) + (fa.mla_rev ? fa.mla_rev[pix] : 0.f);   // + the micro-lens phase of this pixel (K4: none)
+          grid_tile[(lane & 31) * 33 + q] = w - rintf(w);
         } else {
           float sn, cs;
           sincospif(2.0f * (o[r] - rintf(o[r])), &sn, &cs);
@@ -995,7 +1018,7 @@ __global__ __launch_bounds__(256) void k_phase_mfma(const f16x8* __restrict__ mo
       for (int j = 0; j < 16; ++j) {
         const int el = 2 * j + (lane >> 5), env_j = etile * 32 + el;
         if (env_j < fa.B) {
-          if constexpr (GRID) reinterpret_cast<float*>(fa.field)[(size_t)env_j * fa.env_stride + at] = field_tile[el * 33 + q].x;
+          if constexpr (GRID) reinterpret_cast<float*>(fa.field)[(size_t)env_j * fa.env_stride + at] = grid_tile[el * 33 + q];
           else fa.field[(size_t)env_j * fa.env_stride + at] = field_tile[el * 33 + q];
         }
       }
@@ -2167,77 +2190,197 @@ __global__ void k_focal_field(const float* __restrict__ psi_tile, const double* 
   E[ap_index[p]] = make_double2(cs, sn);
 }
 
-// K4, batched: E of a chunk of envs from the phase tiles k_phase_mfma wrote (u = psi + Mt a in revolutions, psi_tile layout), dense
-// [env in chunk][N*N] complex64, zero outside the aperture (the caller clears the buffer first)
-__global__ void k_focal_E_batched(const float* __restrict__ phase_tile, const int32_t* __restrict__ ap_index, float2* __restrict__ E, int first,
-                                  int n_ap, int n_ptiles, int N2) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n_ap) return;
-  const float u = phase_tile[psi_tile_index(first + blockIdx.y, p, n_ptiles)];
-  E[(size_t)blockIdx.y * N2 + ap_index[p]] = make_float2(__builtin_amdgcn_cosf(u), __builtin_amdgcn_sinf(u));   // (the instructions take revolutions)
+// K4, batched (aog_focal_images): both products on the f16 matrix cores with every operand split hi + lo (the step kernel's
+// contraction: 3 x v_mfma_f32_32x32x16_f16 per real product, 22 significant bits per factor, exact products, fp32 sums).  The fp32
+// matrix instruction this path used in round 2 runs at 1/16 of the f16 rate and does not co-execute with vector work.
+//   pass 1  (k_focal_pass1):  T'^T[x][v] = sum_y E[y][x] m1'[v][y],  E = e^{2 pi i w} formed from the dense phase grid k_phase_mfma<GRID>
+//           writes (one float per pixel, kShOutside outside the aperture -> E = 0) while it is loaded: E never exists in memory
+//   pass 2  (k_focal_pass2):  F[v][u] = sum_x T'[v][x] m2'[x][u] / scale
+// m1' = m1 2^e1, m2' = m2 2^e2 (largest component in [1/2, 1): the f16 halves stay normal), scale = 2^(e1 + e2).
+// Operand tiles are stored MFMA-ready: one tile = [part: re hi, re lo, im hi, im lo][lane 64][8 f16] = 4 KiB; lane l carries row / column
+// l & 31 and the 8 k-slots of k-group l >> 5.  Pass 1 leaves T' already split, in tiles [x tile of 32][v block][s][part][lane]: the 16
+// accumulator registers of a lane (column v = l & 31, rows x = (r & 3) + 8 (r >> 2) + 4 (l >> 5)) are two k-groups of 8 (s = r >> 3) for
+// pass 2, whose m2' table is laid out in the same order of x — the matrix instruction sums over k whatever order the slots are in, so no
+// transposition happens anywhere.  Workgroup = 4 waves = 4 x 32 columns (v blocks / u blocks) of ONE 128-row span; per k-step the four
+// waves produce the span's four A tiles into LDS (pass 1: one x tile each — 8 loads, 16 transcendentals, mask split; pass 2: one copied
+// T' tile each), every wave then runs 4 tiles x 12 matrix instructions against its own B tile from the L2-resident table.
+constexpr int kFocalTile = 4 * 64;   // f16x8 per operand tile
+// hi = x rounded to nearest f16, lo = x - hi rounded to nearest: an unbiased 22-bit operand.  (The step kernel's cheaper split by mask
+// truncates both halves; here the truncation error — a fixed non-linear function of cos / sin of the phase — showed up as ghost terms of
+// 1e-7 of the peak amplitude, the whole error budget of a pixel 30 dB down; this path has the vector slots to round properly.)
+__device__ __forceinline__ void split8(const float (&x)[8], f16x8& hi, f16x8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const _Float16 h = (_Float16)x[j];
+    hi[j] = h;
+    lo[j] = (_Float16)(x[j] - (float)h);
+  }
 }
-
-// Batched complex GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact fp32 products; fp32 accumulation inside a 16-deep
-// K slice, float64 accumulation across slices — the partial sums of a 256-term coherent sum would otherwise round at 6e-8 of the PEAK,
-// which is 1e-5 of a pixel 30 dB below it):
-//   C[b] (M x Nc) = A[b or shared] (M x K) . B[b or shared] (K x Nc), complex64 interleaved, row-major; strideA / strideB = 0 for a
-// matrix shared by the whole batch.  Workgroup = 64 x 64 output tile (4 waves, 32 x 32 each), K in slices of 16 through LDS;
-// a complex product is four real MFMAs per 2 k (Cr += Ar Br - Ai Bi, Ci += Ar Bi + Ai Br).  Any M, Nc, K (edges are zero-filled).
-__global__ __launch_bounds__(256) void k_cgemm_mfma(const float2* __restrict__ A, const float2* __restrict__ B, float2* __restrict__ C, int M, int Nc,
-                                                    int K, size_t strideA, size_t strideB, size_t strideC) {
-  constexpr int KC = 16, LDA = KC + 1, LDB = 64 + 1;
-  __shared__ float2 As[64 * LDA];
-  __shared__ float2 Bs[KC * LDB];
-  const int b = blockIdx.z;
-  const float2* Ab = A + (size_t)b * strideA;
-  const float2* Bb = B + (size_t)b * strideB;
-  const int row0 = blockIdx.y * 64, col0 = blockIdx.x * 64;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
-  const int li = lane & 31, lk = lane >> 5;
-  typedef float f32x16v __attribute__((ext_vector_type(16)));
-  const f32x16v zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  double dr[16], di[16];
+__device__ __forceinline__ f16x8 neg8(f16x8 v) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  return __builtin_bit_cast(f16x8, __builtin_bit_cast(u32x4, v) ^ 0x80008000u);
+}
+// one A tile (LDS, [part][lane]) against a wave's B tile (registers; nbh, nbl = -Bi): Cr += Ar Br - Ai Bi, Ci += Ar Bi + Ai Br
+__device__ __forceinline__ void focal_mma_tile(const f16x8* __restrict__ a_tile, int lane, const f16x8 (&b)[4], f16x8 nbh, f16x8 nbl, f32x16& cr, f32x16& ci) {
+  const f16x8 arh = a_tile[0 * 64 + lane], arl = a_tile[1 * 64 + lane], aih = a_tile[2 * 64 + lane], ail = a_tile[3 * 64 + lane];
+  // (the two accumulation chains alternate; small terms first)
+  cr = __builtin_amdgcn_mfma_f32_32x32x16_f16(arl, b[0], cr, 0, 0, 0);
+  ci = __builtin_amdgcn_mfma_f32_32x32x16_f16(arl, b[2], ci, 0, 0, 0);
+  cr = __builtin_amdgcn_mfma_f32_32x32x16_f16(arh, b[1], cr, 0, 0, 0);
+  ci = __builtin_amdgcn_mfma_f32_32x32x16_f16(arh, b[3], ci, 0, 0, 0);
+  cr = __builtin_amdgcn_mfma_f32_32x32x16_f16(ail, nbh, cr, 0, 0, 0);
+  ci = __builtin_amdgcn_mfma_f32_32x32x16_f16(ail, b[0], ci, 0, 0, 0);
+  cr = __builtin_amdgcn_mfma_f32_32x32x16_f16(aih, nbl, cr, 0, 0, 0);
+  ci = __builtin_amdgcn_mfma_f32_32x32x16_f16(aih, b[1], ci, 0, 0, 0);
+  cr = __builtin_amdgcn_mfma_f32_32x32x16_f16(arh, b[0], cr, 0, 0, 0);
+  ci = __builtin_amdgcn_mfma_f32_32x32x16_f16(arh, b[2], ci, 0, 0, 0);
+  cr = __builtin_amdgcn_mfma_f32_32x32x16_f16(aih, nbh, cr, 0, 0, 0);
+  ci = __builtin_amdgcn_mfma_f32_32x32x16_f16(aih, b[0], ci, 0, 0, 0);
+}
+// one k-step of a wave: its four A tiles (LDS, [tile][part][lane]) against its B tile
+__device__ __forceinline__ void focal_mma(const f16x8* __restrict__ a_lds, int lane, const f16x8 (&b)[4], f32x16 (&cr)[4], f32x16 (&ci)[4]) {
+  const f16x8 nbh = neg8(b[2]), nbl = neg8(b[3]);
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { dr[r] = 0.0; di[r] = 0.0; }
-  for (int k0 = 0; k0 < K; k0 += KC) {
-    f32x16v cr = zero, ci = zero;
-    // A slice: 64 rows x 16 k (4 threads per row, 4 consecutive k each); B slice: 16 k x 64 columns (16 threads per k row, 4 columns each)
-    {
-      const int r = threadIdx.x >> 2, kk = (threadIdx.x & 3) * 4;
+  for (int t = 0; t < 4; ++t) focal_mma_tile(a_lds + t * kFocalTile, lane, b, nbh, nbl, cr[t], ci[t]);
+}
+// pass 1.  grid (Nxp / 128, nfp / 128, envs); phase [env][Nyp][Nxp]; m1s [nfp / 32][Nyp / 16] tiles; T16 [env][Nxp / 32][nfp / 32][2] tiles
+__global__ __launch_bounds__(256, 2) void k_focal_pass1(const float* __restrict__ phase, const f16x8* __restrict__ m1s, f16x8* __restrict__ T16, int Nxp,
+                                                        int Nyp, int nfp) {
+  __shared__ f16x8 a_lds[2][4 * kFocalTile];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int env = blockIdx.z, x0 = blockIdx.x * 128, vb = blockIdx.y * 4 + wave;
+  const int nk = Nyp / 16;
+  const float* __restrict__ src = phase + ((size_t)env * Nyp + 8 * (lane >> 5)) * Nxp + x0 + 32 * wave + (lane & 31);
+  const f16x8* __restrict__ bsrc = m1s + (size_t)vb * nk * kFocalTile + lane;
+  f32x16 cr[4], ci[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int gr = row0 + r, gk = k0 + kk + u;
-        As[r * LDA + kk + u] = (gr < M && gk < K) ? Ab[(size_t)gr * K + gk] : make_float2(0.f, 0.f);
-      }
-      const int kr = threadIdx.x >> 4, cc = (threadIdx.x & 15) * 4;
+  for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int gk = k0 + kr, gc = col0 + cc + u;
-        Bs[kr * LDB + cc + u] = (gk < K && gc < Nc) ? Bb[(size_t)gk * Nc + gc] : make_float2(0.f, 0.f);
-      }
+    for (int r = 0; r < 16; ++r) { cr[t][r] = 0.f; ci[t][r] = 0.f; }
+  float w[8], wn[8];   // phases of the k-step being produced / of the one after it (HBM: requested two k-steps ahead)
+  f16x8 b[4], bn[4];
+  auto load_w = [&](int ks, float (&dst)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dst[j] = src[(size_t)(ks * 16 + j) * Nxp];
+  };
+  auto load_b = [&](int ks, f16x8 (&dst)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dst[q] = bsrc[(size_t)ks * kFocalTile + q * 64];
+  };
+  auto produce = [&](int buf) {   // this wave's x tile of the k-step whose phases are in w -> LDS
+    float c[8], s[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool in = w[j] < 1.5f;
+      c[j] = in ? __builtin_amdgcn_cosf(w[j]) : 0.f;   // (the instructions take revolutions; sincospif changed nothing measurable)
+      s[j] = in ? __builtin_amdgcn_sinf(w[j]) : 0.f;
     }
-    __syncthreads();
+    f16x8 ch, cl, sh, sl;
+    split8(c, ch, cl);
+    split8(s, sh, sl);
+    f16x8* dst = a_lds[buf] + wave * kFocalTile + lane;
+    dst[0] = ch; dst[64] = cl; dst[128] = sh; dst[192] = sl;
+  };
+  load_w(0, w);
+  load_b(0, b);
+  produce(0);
+  load_w(min(1, nk - 1), w);
+  __syncthreads();
+  for (int ks = 0; ks < nk; ++ks) {
+    const int nxt = min(ks + 1, nk - 1);
+    // the loads of the coming k-steps go out BEFORE this k-step's matrix instructions (left alone the compiler sinks them to their first
+    // use, after the matrix instructions, and every k-step then waits a full memory round trip between two bursts of matrix work)
+    load_w(min(ks + 2, nk - 1), wn);
+    load_b(nxt, bn);
+    __builtin_amdgcn_sched_barrier(0);
+    focal_mma(a_lds[ks & 1], lane, b, cr, ci);
+    __builtin_amdgcn_sched_barrier(0);
+    produce((ks + 1) & 1);   // (unconditional: under `if (ks + 1 < nk)` the loads above are sunk into the branch, behind the matrix instructions; the last
+                             // k-step re-produces its own tile into the buffer nobody reads any more)
 #pragma unroll
-    for (int ks = 0; ks < KC; ks += 2) {
-      const float2 a = As[(wm + li) * LDA + ks + lk];
-      const float2 bb = Bs[(ks + lk) * LDB + wn + li];
-      cr = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bb.x, cr, 0, 0, 0);
-      cr = __builtin_amdgcn_mfma_f32_32x32x2f32(-a.y, bb.y, cr, 0, 0, 0);
-      ci = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bb.y, ci, 0, 0, 0);
-      ci = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bb.x, ci, 0, 0, 0);
-    }
+    for (int q = 0; q < 4; ++q) b[q] = bn[q];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { dr[r] += (double)cr[r]; di[r] += (double)ci[r]; }
+    for (int jj = 0; jj < 8; ++jj) w[jj] = wn[jj];
     __syncthreads();
   }
-  // accumulator map: lane holds column li, rows (r & 3) + 8 (r >> 2) + 4 lk
-  float2* Cb = C + (size_t)b * strideC;
-  const int gc = col0 + wn + li;
+  // T' leaves split and in pass 2's operand order: registers 8 s .. 8 s + 7 of a lane = the 8 k-slots of k-step s of this x tile
+  const int nvb = nfp / 32;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int gr = row0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lk;
-    if (gr < M && gc < Nc) Cb[(size_t)gr * Nc + gc] = make_float2((float)dr[r], (float)di[r]);
+  for (int t = 0; t < 4; ++t) {
+    const int xt = (x0 >> 5) + t;
+    f16x8* dst = T16 + ((((size_t)env * (Nxp / 32) + xt) * nvb + vb) * 2) * kFocalTile + lane;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      float vr[8], vi[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { vr[j] = cr[t][8 * s2 + j]; vi[j] = ci[t][8 * s2 + j]; }
+      f16x8 rh, rl, ih, il;
+      split8(vr, rh, rl);
+      split8(vi, ih, il);
+      f16x8* d = dst + (size_t)s2 * kFocalTile;
+      d[0] = rh; d[64] = rl; d[128] = ih; d[192] = il;
+    }
+  }
+}
+// pass 2.  grid (nfp / 128 [u], nfp / 128 [v], envs); m2s [nfp / 32][Nxp / 32][2] tiles; F [env][nf][nf] complex64
+__global__ __launch_bounds__(256, 2) void k_focal_pass2(const f16x8* __restrict__ T16, const f16x8* __restrict__ m2s, float2* __restrict__ F, int Nxp, int nfp,
+                                                        int nf, float unscale) {
+  __shared__ f16x8 a_lds[2][4 * kFocalTile];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int env = blockIdx.z, ub = blockIdx.x * 4 + wave, vb0 = blockIdx.y * 4;
+  const int nvb = nfp / 32, nk = (Nxp / 32) * 2;
+  // k-step ks = (x tile ks >> 1, s = ks & 1); this wave copies the tile of v block vb0 + wave
+  const f16x8* __restrict__ asrc = T16 + ((size_t)env * (Nxp / 32) * nvb + vb0 + wave) * 2 * kFocalTile + lane;
+  const f16x8* __restrict__ bsrc = m2s + (size_t)ub * nk * kFocalTile + lane;
+  f32x16 cr[4], ci[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { cr[t][r] = 0.f; ci[t][r] = 0.f; }
+  // (fp32 sums over the whole of x.  Folding them into float64 every one or two k-steps was built and measured: worst error 0.84 -> 0.45 of
+  // the test tolerance at N = 256, but 384 accumulator registers mean one wave per SIMD and the kernel went from 100 to 250 us.)
+  f16x8 a[4], b[4], bn[4];
+  auto load_a = [&](int ks) {
+    const f16x8* p = asrc + ((size_t)(ks >> 1) * nvb * 2 + (ks & 1)) * kFocalTile;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a[q] = p[q * 64];
+  };
+  auto load_b = [&](int ks, f16x8 (&dst)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dst[q] = bsrc[(size_t)ks * kFocalTile + q * 64];
+  };
+  auto produce = [&](int buf) {
+    f16x8* dst = a_lds[buf] + wave * kFocalTile + lane;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dst[q * 64] = a[q];
+  };
+  load_a(0);
+  load_b(0, b);
+  produce(0);
+  __syncthreads();
+  for (int ks = 0; ks < nk; ++ks) {
+    const int nxt = min(ks + 1, nk - 1);
+    load_a(nxt);   // (ahead of the matrix instructions: see pass 1)
+    load_b(nxt, bn);
+    __builtin_amdgcn_sched_barrier(0);
+    focal_mma(a_lds[ks & 1], lane, b, cr, ci);
+    __builtin_amdgcn_sched_barrier(0);
+    produce((ks + 1) & 1);   // (unconditional: under `if (ks + 1 < nk)` the loads above are sunk into the branch, behind the matrix instructions; the last
+                             // k-step re-produces its own tile into the buffer nobody reads any more)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) b[q] = bn[q];
+    __syncthreads();
+  }
+  const int u = ub * 32 + (lane & 31);
+  if (u < nf) {
+    float2* Fe = F + (size_t)env * nf * nf;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int v = (vb0 + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (v < nf) Fe[(size_t)v * nf + u] = make_float2(cr[t][r] * unscale, ci[t][r] * unscale);
+      }
   }
 }
 

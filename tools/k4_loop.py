@@ -15,4 +15,4 @@ for _ in range(n): F = env.focal_images()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / n
 flops = B * 8 * (128 * N * N + 128 * N * 128)
-print(f"aog_focal_images B={B} N={N}: {dt*1e3:.2f} ms per call ({dt/B*1e6:.2f} us per env), {flops/dt/1e12:.1f} TFLOP/s fp32 of 157.3")
+print(f"aog_focal_images B={B} N={N}: {dt*1e3:.2f} ms per call ({dt/B*1e6:.2f} us per env), {flops/dt/1e12:.1f} TFLOP/s of nominal complex-GEMM flops (3 split-f16 matrix instructions per real product)")
