@@ -14,11 +14,19 @@ from .params import OpticalParams
 
 
 def _fresnel_transfer(n: int, pitch: float, wavelength: float, distance: float, q: int = 2) -> np.ndarray:
-    """hcipy FresnelPropagator, transfer-function branch, on the UNSHIFTED (q n)^2 FFT grid."""
-    if pitch < wavelength * distance / (n * pitch):
-        raise NotImplementedError("Fresnel sampling outside hcipy's transfer-function branch (impulse-response method needed)")
+    """hcipy FresnelPropagator's transfer function on the UNSHIFTED (q n)^2 FFT grid.  hcipy chooses by a sampling test: the analytic
+    paraxial transfer function while pitch >= lambda z / L (every configured geometry: the reference's f-number 50 reaches the other
+    branch only above ~800 pupil pixels), otherwise the impulse-response method — the Fourier transform, over the padded grid with a
+    sample at r = 0, of h(r) = e^{ikz} e^{ik r^2 / 2z} / (i lambda z).  h factorises, so its transform is the outer product of two
+    1-D transforms: both branches give a table the separable Shack-Hartmann passes accept."""
     k = 2 * np.pi / wavelength
-    kk = 2 * np.pi * np.fft.fftfreq(n * q, pitch)
+    m = n * q
+    kk = 2 * np.pi * np.fft.fftfreq(m, pitch)
+    if pitch < wavelength * distance / (n * pitch):
+        x = (np.arange(m) - m / 2 + (m % 2) * 0.5) * pitch                 # make_fft_grid of the Fourier grid
+        chirp = np.exp(1j * k * x ** 2 / (2 * distance))
+        line = pitch * (np.exp(-1j * np.outer(kk, x)) @ chirp)              # sum_x e^{ik x^2 / 2z} e^{-i kx x} dx, true coordinates
+        return np.exp(1j * k * distance) / (1j * wavelength * distance) * np.outer(line, line)
     k2 = kk[None, :] ** 2 + kk[:, None] ** 2
     return np.exp(-0.5j * distance * k2 / k) * np.exp(1j * k * distance)
 

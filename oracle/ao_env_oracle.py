@@ -22,7 +22,7 @@ class AOEnvOracle:
     def __init__(self, atm_type="quasi_static", atm_vel=0, atm_fried=0.15, act_type="num_actuators",
                  act_dim=64, obs_dim=2, rew_type="strehl_ratio", rew_threshold=None,
                  timesteps_per_episode=20, flat_mirror_start_per_episode=True, SH_operation=False,
-                 num_pupil_pixels=240, rng=np.random, screen=None, verbose=True):
+                 num_pupil_pixels=240, rng=np.random, screen=None, verbose=True, f_number=None):
         # AO_env.py:33-39
         self.atm_type = atm_type
         self.rew_type = rew_type
@@ -33,6 +33,8 @@ class AOEnvOracle:
         self.rng = rng
         self._verbose = verbose
         self._parameters_init(act_dim, atm_vel, obs_dim, timesteps_per_episode, atm_fried, num_pupil_pixels)
+        if f_number is not None:   # test knob (the reference fixes 50, AO_env.py:243): long lenslet focal lengths reach hcipy's impulse-response Fresnel branch at small pupils
+            self.f_number = f_number
 
         # AO_env.py:293-303 pupil_simulation
         self.pupil_grid = H.make_pupil_grid(self.num_pupil_pixels, self.telescope_diameter)

@@ -682,9 +682,17 @@ class MicroLensArray:
 
 
 class FresnelPropagator:
-    """hcipy FresnelPropagator(grid, distance, num_oversampling=2): FFT with 2x zero padding, multiply by the paraxial
-    transfer function exp(-i z |k|^2 / (2 k)) exp(i k z), inverse FFT, crop.  (The sampling test of hcipy selects this
-    transfer-function branch for the reference's geometry: delta = 20.8 um >= lambda z / L = 6.25 um.)"""
+    """hcipy FresnelPropagator(grid, distance, num_oversampling=2) = FourierFilter(grid, transfer_function, q): FFT with 2x zero
+    padding, multiply by the transfer function, inverse FFT, crop.  hcipy picks the transfer function by a sampling test
+    (propagation/fresnel.py, get_instance_data):
+
+    * ``delta >= lambda z / L_max`` (the reference's geometry: 20.8 um >= 6.25 um): the analytic paraxial transfer function
+      exp(-i z |k|^2 / (2 k)) exp(i k z) on the Fourier grid;
+    * otherwise (pupils of more than ~800 pixels at the reference's f-number, or longer lenslet focal lengths) the IMPULSE-RESPONSE
+      method: h(r) = exp(i k z) exp(i k r^2 / (2 z)) / (i lambda z) sampled on the enlarged spatial grid that is dual to the Fourier
+      grid (make_fft_grid(fourier_grid): the q-times padded grid, pitch delta, a sample exactly at r = 0) and carried to the
+      Fourier grid by FastFourierTransform.forward, i.e. sum_r h(r) exp(-i k.r) delta^2 with the grid's true coordinates.
+    """
 
     def __init__(self, input_grid, distance, num_oversampling=2):
         self.grid = input_grid
@@ -692,19 +700,39 @@ class FresnelPropagator:
         self.q = int(num_oversampling)
         self._tf = {}
 
+    def uses_impulse_response(self, wavelength):
+        g = self.grid
+        return bool(np.any(g.delta < wavelength * self.distance / np.max(g.dims * g.delta)))
+
+    def transfer_function(self, wavelength):
+        """On the UNSHIFTED (q ny, q nx) FFT grid (numpy.fft frequency order)."""
+        g = self.grid
+        ny, nx = g.shape
+        my, mx = ny * self.q, nx * self.q
+        k = 2 * np.pi / wavelength
+        if self.uses_impulse_response(wavelength):
+            # enlarged grid: x_i = (i - m/2) delta for even m (hcipy make_fft_grid: zero = delta (-dims/2 + (dims mod 2)/2))
+            xs = (np.arange(mx) - mx / 2 + (mx % 2) * 0.5) * g.delta[0]
+            ys = (np.arange(my) - my / 2 + (my % 2) * 0.5) * g.delta[1]
+            r2 = xs[None, :] ** 2 + ys[:, None] ** 2
+            h = np.exp(1j * k * self.distance) * np.exp(1j * k * r2 / (2 * self.distance)) / (1j * self.distance * wavelength)
+            kx = 2 * np.pi * np.fft.fftfreq(mx, g.delta[0])
+            ky = 2 * np.pi * np.fft.fftfreq(my, g.delta[1])
+            # sum_r h(r) exp(-i k.r) delta^2 with r the true coordinates: an FFT of h plus the phase ramp of the grid origin
+            ramp = np.exp(-1j * (kx[None, :] * xs[0] + ky[:, None] * ys[0]))
+            return np.fft.fft2(h) * ramp * (g.delta[0] * g.delta[1])
+        kx = 2 * np.pi * np.fft.fftfreq(mx, g.delta[0])
+        ky = 2 * np.pi * np.fft.fftfreq(my, g.delta[1])
+        k2 = kx[None, :] ** 2 + ky[:, None] ** 2
+        return np.exp(-0.5j * self.distance * k2 / k) * np.exp(1j * k * self.distance)
+
     def forward(self, wf):
         g = wf.grid
         ny, nx = g.shape
         my, mx = ny * self.q, nx * self.q
         lam = wf.wavelength
-        if np.any(g.delta < lam * self.distance / np.max(g.dims * g.delta)):
-            raise NotImplementedError("impulse-response branch of hcipy's FresnelPropagator is not restated")
         if lam not in self._tf:
-            k = 2 * np.pi / lam
-            kx = 2 * np.pi * np.fft.fftfreq(mx, g.delta[0])
-            ky = 2 * np.pi * np.fft.fftfreq(my, g.delta[1])
-            k2 = kx[None, :] ** 2 + ky[:, None] ** 2
-            self._tf[lam] = np.exp(-0.5j * self.distance * k2 / k) * np.exp(1j * k * self.distance)
+            self._tf[lam] = self.transfer_function(lam)
         pad = np.zeros((my, mx), dtype=complex)
         y0, x0 = my // 2 - ny // 2, mx // 2 - nx // 2
         pad[y0:y0 + ny, x0:x0 + nx] = wf.electric_field.reshape(ny, nx)

@@ -934,6 +934,37 @@ def test_device_screens_have_the_literal_covariance(method, N):
     assert abs(np.mean(tilt)) < 4 * tilt.std() / np.sqrt(B)
 
 
+def test_shack_hartmann_chain_on_the_impulse_response_fresnel_branch():
+    """hcipy's FresnelPropagator switches to its impulse-response transfer function when the pupil pitch falls below lambda z / L — the
+    reference's geometry (AO_env.py:407, f-number 50) does above ~800 pupil pixels.  A lenslet f-number of 600 puts a 96-pixel pupil on that
+    branch: the device chain (the table is uploaded, it factorises like the analytic one) against the oracle's — noise-free sensor image,
+    estimator + reconstructor + integrator on the oracle's noisy image, and the env step that consumes the actuators."""
+    torch = _torch()
+    from adaptive_optics_gym_amd import BatchedAOEnv
+    from adaptive_optics_gym_amd.params import OpticalParams
+    from oracle.ao_env_oracle import AOEnvOracle
+
+    N, A, F = 96, 8, 600.0
+    scr = smooth_screens(1, N, 3)[0] * 0.5
+    kw = dict(act_type="zernike", act_dim=A, obs_dim=2, timesteps_per_episode=50, SH_operation=True, verbose=False)
+    env = BatchedAOEnv(1, "cuda:0", screens=scr[None], sh_fft_precision="double", params=OpticalParams(num_pupil_pixels=N, f_number=F), **kw)
+    ref = AOEnvOracle(screen=scr.ravel(), rng=np.random.RandomState(42), num_pupil_pixels=N, f_number=F, **kw)
+    assert ref.shwfs.propagator.uses_impulse_response(ref.wavelength_wfs)
+    env.reset(); ref.reset()
+    for t in range(3):
+        clean = env.sh_image()[0].cpu().numpy()
+        ra, _ = ref.SH_step()
+        np.testing.assert_allclose(clean, ref.last_sh_image_noiseless, rtol=1e-5, atol=1e-7 * ref.last_sh_image_noiseless.max())
+        noisy = np.round(ref.last_sh_image_noiseless + (ref.last_sh_noisy - ref.last_sh_image_noiseless))
+        a = env.sh_update(noisy[None])[0].cpu().numpy()
+        np.testing.assert_allclose(a, ra, rtol=1e-6, atol=1e-6 * np.abs(ra).max())
+        _, _, _, _, info = env.step(torch.from_numpy(a[None]).cuda())
+        ref.step(ra)
+        _assert_obs_close(info["obs_raw"].cpu().numpy()[0], ref.last_obs_raw)
+        np.testing.assert_allclose(float(info["strehl"][0]), ref.last_strehl, rtol=1e-5)
+    env.close()
+
+
 @pytest.mark.parametrize("N", [96, 240])
 def test_shack_hartmann_chain_matches_oracle(N):
     """SH_step (AO_env.py:254-290) on the device vs the oracle (N = 240 is the reference's pupil size), stage by stage: the noise-free sensor image; then the

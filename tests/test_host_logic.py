@@ -172,16 +172,22 @@ def test_layer_tables_match_oracle_layer():
 
 
 
-def test_shack_hartmann_host_tables_match_oracle():
-    """Product-side SH construction (sh_host.ShackHartmannHost) == the oracle's shack_hartmann_init (AO_env.py:396-465)."""
+@pytest.mark.parametrize("f_number", [50.0, 600.0])
+def test_shack_hartmann_host_tables_match_oracle(f_number):
+    """Product-side SH construction (sh_host.ShackHartmannHost) == the oracle's shack_hartmann_init (AO_env.py:396-465).  f-number 50
+    is the reference's (hcipy's analytic Fresnel transfer function); 600 puts the same 96-pixel pupil past hcipy's sampling test, on the
+    impulse-response branch the reference reaches above ~800 pupil pixels (AO_env.py:407)."""
     from adaptive_optics_gym_amd.sh_host import ShackHartmannHost
 
     N, A = 96, 8
-    params = OpticalParams(num_pupil_pixels=N)
+    params = OpticalParams(num_pupil_pixels=N, f_number=f_number)
     T = optics_host.build_tables(params, "zernike", A, 2)
     sh = ShackHartmannHost(params, T)
     ref = AOEnvOracle(act_type="zernike", act_dim=A, obs_dim=2, num_pupil_pixels=N, screen=np.zeros(N * N), SH_operation=True,
-                      verbose=False)
+                      verbose=False, f_number=f_number)
+    assert ref.shwfs.propagator.uses_impulse_response(params.wavelength_wfs) == (f_number > 50)
+    tf_ref = ref.shwfs.propagator.transfer_function(params.wavelength_wfs)
+    np.testing.assert_allclose(sh.transfer, tf_ref, rtol=0, atol=1e-9 * np.abs(tf_ref).max())
     assert np.array_equal(sh.mla_index, ref.shwfs.micro_lens_array.mla_index)
     assert np.array_equal(sh.subapertures, ref.shwfse.estimation_subapertures)
     np.testing.assert_allclose(sh.slopes_ref, ref.slopes_ref.ravel(), rtol=1e-9, atol=1e-16)
@@ -190,6 +196,33 @@ def test_shack_hartmann_host_tables_match_oracle():
     np.testing.assert_allclose(sh.reconstruction, ref.reconstruction_matrix, rtol=1e-5,
                                atol=1e-5 * np.abs(ref.reconstruction_matrix).max())
     np.testing.assert_allclose(sh.amp_wfs ** 2 * sh.n_ap * sh.pix_area_pupil, ref.wf_wfs.total_power, rtol=1e-12)
+
+
+def test_impulse_response_transfer_function_tends_to_the_analytic_one():
+    """Known answer for hcipy's impulse-response Fresnel branch: the chirp h(r) = e^{ikz} e^{ik r^2 / 2z} / (i lambda z) has the analytic
+    transform e^{ikz} e^{-i z |k|^2 / 2k}; sampled on a grid that resolves it (local frequency k x / z below Nyquist at the grid edge) and
+    wide enough to hold it, the discrete transform must reproduce the analytic values in the band the chirp covers, |k| < k L / (2 z).
+    Both the product table and the oracle's are checked, on a geometry chosen inside the impulse-response regime."""
+    from adaptive_optics_gym_amd.sh_host import _fresnel_transfer
+    from oracle import hcipy_restatement as H
+
+    n, lam = 256, 1.5e-6
+    pitch = 20e-6
+    L = n * pitch
+    z = 1.5 * pitch * L / lam            # pitch < lambda z / L: impulse-response branch; edge frequency = 2/1.5 of ... still sampled by q = 2
+    tf = _fresnel_transfer(n, pitch, lam, z)
+    grid = H.make_pupil_grid(n, L)
+    prop = H.FresnelPropagator(grid, z)
+    assert prop.uses_impulse_response(lam)
+    np.testing.assert_allclose(tf, prop.transfer_function(lam), rtol=0, atol=1e-9)
+    k = 2 * np.pi / lam
+    kk = 2 * np.pi * np.fft.fftfreq(2 * n, pitch)
+    k2 = kk[None, :] ** 2 + kk[:, None] ** 2
+    analytic = np.exp(1j * k * z) * np.exp(-0.5j * z * k2 / k)
+    band = np.sqrt(k2) < 0.5 * k * L / (2 * z)        # well inside the chirp's band: the stationary point lies inside the padded grid
+    assert band.sum() > 1000
+    assert np.abs(tf[band] - analytic[band]).max() < 0.08 and np.abs(np.abs(tf[band]) - 1).max() < 0.08   # Fresnel ripple of the truncated chirp
+    assert np.abs(np.angle(tf[band] / analytic[band])).mean() < 0.05
 
 
 def test_gym_registration_through_the_gymnasium_stand_in(repo_root):
