@@ -377,7 +377,7 @@ int evolve_layer(aog_env* e, hipStream_t s, long long step_index) {
     for (int g0 = 0; g0 < groups8; g0 += groups_per_launch) {
       const int ng = std::min(groups_per_launch, groups8 - g0);
       hipLaunchKernelGGL(kern, dim3(ng * aog::kExtParts), dim3(256 * aog::kExtKs), lds, s, p, e->B, e->ext_perm, bar, e->dev_status,
-                         e->host_flag_dev, g0, e->ext_spin_limit, e->ext_absent_part, bar_next);
+                         e->host_flag_dev, g0, e->ext_spin_limit, e->ext_absent_part, bar_next, getenv("AOG_EXTRUDE_AGENT_SCOPE") ? 1 : 0);
     }
     HIP_TRY(hipGetLastError());
   } else if (!getenv("AOG_EXTRUDE_SIMPLE") && ext16_lds(e) <= kLdsBytes) {

@@ -1648,7 +1648,7 @@ __global__ __launch_bounds__(512) void k_extrude16(ExtrudeArgs p, int B) {
 // writes it in place; before the next round reads those rows they meet at a group barrier: plain stores -> every wave
 // s_waitcnt vmcnt(0) -> __syncthreads -> lane 0: agent-scope release fence, ticket add on the group's counter, relaxed poll
 // (bounded) until all four tickets of this round are in, agent-scope acquire fence -> __syncthreads (cdna_hip_programming.md
-// Guideline 16, counter form).  Two sets of counters alternate between launches; a launch zeroes the set of the next one.  Workgroup L sits on XCD L % 8; the map
+// Guideline 16, counter form; from the second round on the same-XCD short form when the group has measured that it may: see the barrier).  Two sets of counters alternate between launches; a launch zeroes the set of the next one.  Workgroup L sits on XCD L % 8; the map
 // below keeps a group's four workgroups on one XCD (speed only).  A timed-out spin sets *status and *host_flag (pinned host memory the
 // library polls without synchronising) and the kernel still terminates; aog_step / aog_reset then fail with AOG_ERR_STATE.
 constexpr int kExtParts = 4;
@@ -1658,7 +1658,8 @@ constexpr int kExtKs = 2;   // slices of the contraction per row block (template
 template <int KS>
 __global__ __launch_bounds__(256 * KS) void k_extrude16_split(ExtrudeArgs p, int B, const int* __restrict__ perm, unsigned* __restrict__ bar, int* __restrict__ status,
                                                               int* __restrict__ host_flag, int group0, unsigned spin_limit, int absent_part,
-                                                              unsigned* __restrict__ bar_next) {
+                                                              unsigned* __restrict__ bar_next, int force_agent_scope) {
+  // force_agent_scope: never take the same-XCD form of the group barrier (AOG_EXTRUDE_AGENT_SCOPE: tests, measurements).
   // group0: first group of this launch (a batch whose groups x 4 workgroups exceed what the chip holds at once is extruded in several
   // launches: barrier partners must be co-resident).  spin_limit / absent_part: see aog_selftest_barrier_timeout (product launches pass
   // 1 << 24 and -1).
@@ -1675,6 +1676,7 @@ __global__ __launch_bounds__(256 * KS) void k_extrude16_split(ExtrudeArgs p, int
   int32_t* st_v = reinterpret_cast<int32_t*>(pb + (size_t)(KS - 1) * 4 * 256);   // stencil codes (sy << 16 | sx), staged once
   int32_t* st_h = st_v + p.nz_v;
   __shared__ int s_ox[G], s_oy[G], s_dx[G], s_dy[G], s_env[G];
+  __shared__ int s_same_xcd;
   const int L = blockIdx.x;
   const int part = (L >> 3) & (kExtParts - 1);
   // groups are sorted by wind (aog_set_wind): an XCD takes a contiguous run of them, so its workgroups want the same class of
@@ -1759,6 +1761,7 @@ __global__ __launch_bounds__(256 * KS) void k_extrude16_split(ExtrudeArgs p, int
       }
     }
   };
+  bool same_xcd = false;   // the group's four workgroups share an XCD (measured in round 0: see the barrier)
   int pf = 0;   // bit j: the far samples of this wave's j-th env are already in zb (fetched in the previous round's tail)
   for (int r = 0; r < rounds; ++r) {
     long long t0 = dbg ? wall_clock64() : 0;
@@ -1977,24 +1980,43 @@ __global__ __launch_bounds__(256 * KS) void k_extrude16_split(ExtrudeArgs p, int
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores
     __syncthreads();
     if (dbg) { long long t = wall_clock64(); tm[2] += t - t0; t0 = t; }
+    // Visibility between the partners.  Placement-independent form: agent-scope release (on this chip: write the XCD's L2 back) before the
+    // ticket, agent-scope acquire (drop L1 and the L2 lines of other XCDs) after the wait.  The eight XCDs have an L2 each, and partners that
+    // sit on ONE XCD need less: a store is in that L2 once vmcnt has counted it (the vector L1 writes through), so the writer only drains
+    // its stores and the reader only invalidates its own L1 (`buffer_inv sc0`, the work-group-scope acquire of the gfx942 memory model's
+    // threadgroup-split mode).  Which it is, the group MEASURES: every workgroup ORs the bit of the XCD it really runs on (HW_REG_XCC_ID)
+    // into the high half of the group's ticket word ahead of its first ticket — under the full protocol — and whoever sees the four tickets
+    // of round 0 sees the four bits; one bit set = one XCD, and the later rounds take the short form.  (The dispatcher deals workgroups b
+    // and b + 8 to the same XCD, but nothing promises it: a different placement costs speed, never correctness.)  The full form cost
+    // 30-45 us per step at B = 1024: the L2 write-back, and every round's weights re-fetched after the wider invalidate.
     if (threadIdx.x == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      if (!same_xcd) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (r == 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        __hip_atomic_fetch_or(&bar[group], 1u << (16 + (xcc & 7u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       __hip_atomic_fetch_add(&bar[group], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const unsigned target = (unsigned)kExtParts * (unsigned)(r + 1);
-      unsigned spins = 0;
-      while (__hip_atomic_load(&bar[group], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      unsigned spins = 0, word;
+      bool timed_out = false;
+      while (((word = __hip_atomic_load(&bar[group], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xffffu) < target) {
         __builtin_amdgcn_s_sleep(2);
         if (++spins > spin_limit) {   // ~seconds: a partner never arrived (not co-resident).  The launch still terminates, but its
           atomicExch(status, 1);      // screens are invalid: flag it on the device and in host-visible memory — the host refuses
           __hip_atomic_store(host_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // every later call on the handle
+          timed_out = true;
           break;
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      if (r == 0) s_same_xcd = (!timed_out && !force_agent_scope && __builtin_popcount((word >> 16) & 0xffu) == 1) ? 1 : 0;
+      if (r == 0 ? !s_same_xcd : !same_xcd) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      else asm volatile("buffer_inv sc0" ::: "memory");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
+    if (r == 0) same_xcd = s_same_xcd != 0;
     if (dbg) { long long t = wall_clock64(); tm[3] += t - t0; t0 = t; }
     if (threadIdx.x < G) {
       const int g = threadIdx.x;
