@@ -2279,11 +2279,11 @@ __global__ __launch_bounds__(256, 2) void k_focal_pass1(const float* __restrict_
   for (int t = 0; t < 4; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { cr[t][r] = 0.f; ci[t][r] = 0.f; }
-  float w[8], wn[8];   // phases of the k-step being produced / of the one after it (HBM: requested two k-steps ahead)
+  float w[8];   // phases of the k-step being produced next (requested one k-step ahead, before the matrix instructions; two ahead: no gain)
   f16x8 b[4], bn[4];
-  auto load_w = [&](int ks, float (&dst)[8]) {
+  auto load_w = [&](int ks) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) dst[j] = src[(size_t)(ks * 16 + j) * Nxp];
+    for (int j = 0; j < 8; ++j) w[j] = src[(size_t)(ks * 16 + j) * Nxp];
   };
   auto load_b = [&](int ks, f16x8 (&dst)[4]) {
 #pragma unroll
@@ -2303,16 +2303,15 @@ __global__ __launch_bounds__(256, 2) void k_focal_pass1(const float* __restrict_
     f16x8* dst = a_lds[buf] + wave * kFocalTile + lane;
     dst[0] = ch; dst[64] = cl; dst[128] = sh; dst[192] = sl;
   };
-  load_w(0, w);
+  load_w(0);
   load_b(0, b);
   produce(0);
-  load_w(min(1, nk - 1), w);
   __syncthreads();
   for (int ks = 0; ks < nk; ++ks) {
     const int nxt = min(ks + 1, nk - 1);
     // the loads of the coming k-steps go out BEFORE this k-step's matrix instructions (left alone the compiler sinks them to their first
     // use, after the matrix instructions, and every k-step then waits a full memory round trip between two bursts of matrix work)
-    load_w(min(ks + 2, nk - 1), wn);
+    load_w(nxt);
     load_b(nxt, bn);
     __builtin_amdgcn_sched_barrier(0);
     focal_mma(a_lds[ks & 1], lane, b, cr, ci);
@@ -2321,8 +2320,6 @@ __global__ __launch_bounds__(256, 2) void k_focal_pass1(const float* __restrict_
                              // k-step re-produces its own tile into the buffer nobody reads any more)
 #pragma unroll
     for (int q = 0; q < 4; ++q) b[q] = bn[q];
-#pragma unroll
-    for (int jj = 0; jj < 8; ++jj) w[jj] = wn[jj];
     __syncthreads();
   }
   // T' leaves split and in pass 2's operand order: registers 8 s .. 8 s + 7 of a lane = the 8 k-slots of k-step s of this x tile
