@@ -273,7 +273,8 @@ int aog_focal_image(aog_env* env, int env_index, float* field_dev /* [n_focal][n
 
 /* The same field for envs [first, first + count) in one call: field_dev [count][n_focal][n_focal][2] float32.  Fast-precision handles
  * only.  E = exp(i phi) on the pupil grid from the split-f16 phase contraction of the step kernels, then the two matrices of the
- * Fraunhofer matrix Fourier transform as batched complex GEMMs on the fp32 matrix cores (v_mfma_f32_32x32x2_f32). */
+ * Fraunhofer matrix Fourier transform as two batched complex products on the f16 matrix cores (v_mfma_f32_32x32x16_f16, every operand split
+ * hi + lo: 22 significant bits per factor, exact products), the pupil field formed inside the first product from a dense phase grid. */
 int aog_focal_images(aog_env* env, int first, int count, float* field_dev, void* stream);
 
 /* ---- policy query of the rollout (Actor.forward + Actor.get_action, network.py:17-69; caller algorithm.py:216-296) ----
