@@ -451,10 +451,10 @@ def main():
     # clocks).  With a caller-chosen warm-up shorter than that, the difference is run here, ahead of the W warm-up steps, so that the K
     # timed steps measure the steady state a long-running job sees.  Config 2 only (the other configs' steps are 5-100x longer).
     spinup = max(0, SPINUP_STEPS - args.warmup) if (args.config == 2 and not args.no_spinup) else 0
-    if spinup and args.steps < T:
-        # a timed window shorter than an episode would otherwise sit between two episode ends (300 = 10 episodes of 30): shift the spin-up so
-        # that the window straddles one — the workload is "episodes with reset + all-gather of returns", and a short window should pay for one
-        spinup += (T - args.steps // 2 - (spinup + args.warmup)) % T
+    # A timed window shorter than an episode (the driver's --steps 20) holds no episode end: 300 = 10 episodes of 30 come before it.  Forcing
+    # one into it was tried (the window then straddled a reset): it charges one reset — a full pass of the fused kernel for the observation
+    # reset() returns — per 20 steps instead of per 30, and read 9 % BELOW the steady state of the same box (14.7 M against 16.1 M over 1500
+    # steps with their 50 resets); without it the short window still reads below the long run (pipeline fill + closing synchronisation).
     start_episode()
     if spinup:
         run(spinup)
