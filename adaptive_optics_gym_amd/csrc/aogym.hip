@@ -1923,6 +1923,7 @@ int aog_focal_images(aog_env* e, int first, int count, float* field_dev, void* s
     // aperture pixels are ever written) and T' (split f16, pass 2's operand order)
     const size_t cap = std::max<size_t>(32, (((size_t)256 << 20) / std::max(grid_env * 4, t16_env * 2)) / 32 * 32);
     e->focal_chunk = (int)std::min<size_t>((size_t)e->n_etiles * 32, cap);
+    if (const char* v = getenv("AOG_FOCAL_CHUNK")) e->focal_chunk = std::max(32, std::min(e->focal_chunk, atoi(v) / 32 * 32));   // (tests: several chunks at small sizes)
     if ((rc = dev_alloc(e, &e->focal_grid, (size_t)e->focal_chunk * grid_env, false)) != AOG_OK) return rc;
     if ((rc = dev_alloc(e, &e->focal_T16, (size_t)e->focal_chunk * t16_env, false)) != AOG_OK) return rc;
     if ((rc = dev_alloc(e, &e->focal_act_ll, (size_t)e->n_etiles * 32 * e->A_pad, true)) != AOG_OK) return rc;

@@ -679,6 +679,37 @@ def test_batched_focal_images_match_oracle_propagator(N, B, A, act_type):
     env.close()
 
 
+def test_batched_focal_images_in_several_chunks(monkeypatch):
+    """aog_focal_images works through the batch in chunks of whole env tiles (work buffers of <= 256 MB: 1024 envs at N = 256, 256 at
+    N = 512).  Forced down to chunks of 32 envs here: the fields of a 100-env batch, of sub-ranges that start and end inside tiles and chunks,
+    and of single envs equal the one-chunk result bit for bit."""
+    torch = _torch()
+    from adaptive_optics_gym_amd import BatchedAOEnv
+
+    N, B, A = 64, 100, 16
+    scr = smooth_screens(B, N, 17)
+    a = torch.from_numpy(actions_for(B, A, 3)).cuda()
+    kw = dict(act_dim=A, obs_dim=2, num_pupil_pixels=N, timesteps_per_episode=5, verbose=False)
+
+    def fields(chunk):
+        if chunk:
+            monkeypatch.setenv("AOG_FOCAL_CHUNK", str(chunk))
+        else:
+            monkeypatch.delenv("AOG_FOCAL_CHUNK", raising=False)
+        env = BatchedAOEnv(B, "cuda:0", screens=scr, **kw)
+        env.reset()
+        env.step(a)
+        out = env.focal_images().clone(), env.focal_images(31, 40).clone(), env.focal_images(64, 36).clone(), env.focal_image(97).clone()
+        env.close()
+        return out
+
+    whole, chunked = fields(0), fields(32)
+    for w, c in zip(whole, chunked):
+        assert torch.equal(w, c)
+    assert torch.equal(chunked[1], chunked[0][31:71]) and torch.equal(chunked[2], chunked[0][64:100]) and torch.equal(chunked[3], chunked[0][97])
+    assert float(chunked[0].abs().max()) > 0
+
+
 @pytest.mark.parametrize("N,vel", [(32, 35.0), (128, 20.0)])
 def test_dynamic_extrusion_kernel_variants_agree(monkeypatch, N, vel):
     """The extrusion kernels — float64 matrix-core form with a group's rows split over four workgroups and a group barrier (default; at N = 128
