@@ -350,7 +350,8 @@ int evolve_layer(aog_env* e, hipStream_t s, long long step_index) {
   p.ring = e->ring_direct ? e->psi_ring : nullptr;
   p.ring_ref = e->psi_offset;
   p.ring_inv = 1.0 / (2.0 * M_PI * e->cfg.wavelength_wfs);
-  TimedRegion tr_ext(e, s, AOG_PROF_EXTRUDE);
+  // (sampled like the fused kernel's launches — blocks of 8 steps, one block in profile_every: two event records cost ~6 us of a 250 us step)
+  TimedRegion tr_ext(e, s, AOG_PROF_EXTRUDE, ((e->profile_phase >> 3) % (unsigned)e->profile_every) == 0);
   if (e->ext_bar && !getenv("AOG_EXTRUDE_SIMPLE") && !getenv("AOG_EXTRUDE_NOSPLIT") && ext_split_lds(e) <= kLdsBytes) {
     // float64 matrix-core form with each 16-env group's rows split over four workgroups + group barrier
     const size_t lds = ext_split_lds(e);

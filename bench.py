@@ -269,11 +269,13 @@ def roofline_dominant(env, w, kernels, steps_range):
             sh = integer_shifts(env.velocity_vectors, t * env.delta_t, (t + 1) * env.delta_t, env.params.pupil_pixel)
             shifts += int(np.abs(sh).sum())
         nz = int(max(env._layer["stencil_vertical"].size, env._layer["stencil_horizontal"].size))
-        flop = 2.0 * N * (nz + N) * shifts
-        out["extrude"] = {"kernel": "k_extrude16_split", "bound": "mfma_f64", "ms": ms, "launches": n, "achieved": flop / (ms * 1e-3 * n) / 1e12,
-                          "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flop / (ms * 1e-3 * n) / 1e12 / F64_MFMA_PEAK_TFLOPS,
-                          "shifts_per_env_step": shifts / max(1, B * (steps_range[1] - steps_range[0])),
-                          "note": "2 N (nz + N) flop per one-pixel shift of one env, shifts recomputed on the host for the timed steps"}
+        n_steps = max(1, steps_range[1] - steps_range[0])
+        flop = 2.0 * N * (nz + N) * shifts / n_steps          # per step (= per launch), mean over the timed region
+        out["extrude"] = {"kernel": "k_extrude16_split", "bound": "mfma_f64", "ms": ms, "launches": n, "achieved": flop / (ms * 1e-3) / 1e12,
+                          "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flop / (ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS,
+                          "shifts_per_env_step": shifts / max(1, B * n_steps),
+                          "note": "2 N (nz + N) flop per one-pixel shift of one env, shifts recomputed on the host for the timed steps (mean per "
+                                  "step); ms = mean duration of the sampled launches (HIP events around one block of 8 steps in 8)"}
     if all(k in kernels for k in ("sh_rows_fwd", "sh_cols")):
         three = "sh_rows_inv" in kernels                      # (transfer functions that do not factorise keep the three-pass form)
         names = ("sh_rows_fwd", "sh_cols", "sh_rows_inv") if three else ("sh_rows_fwd", "sh_cols")
