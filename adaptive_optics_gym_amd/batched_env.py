@@ -585,9 +585,10 @@ class BatchedAOEnv:
         _lib.check(self.lib.aog_device_status(self._handle, C.byref(v)))
         return int(v.value)
 
-    def profile(self, enable=True, every=1):
-        """HIP-event timing of the fused kernel; ``every`` = n times one block of 8 consecutive launches in n (the records hold the
+    def profile(self, enable=True, every=1, block=8):
+        """HIP-event timing of the fused kernel; ``every`` = n times one block of ``block`` consecutive launches in n (the records hold the
         stream ~6 us per timed launch)."""
+        _lib.check(self.lib.aog_profile_block(self._handle, int(block)))
         _lib.check(self.lib.aog_profile_enable(self._handle, max(1, int(every)) if enable else 0))
 
     def profile_read(self):

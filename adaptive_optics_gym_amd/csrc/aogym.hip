@@ -218,7 +218,7 @@ int launch_fused(aog_env* e, hipStream_t s) {
   // event timing of one launch block in profile_every: the two records cost ~3 us each on the stream, so a throughput measurement that
   // also wants the kernel's duration samples instead of timing every launch
   // (blocks of 8 consecutive launches, one block in profile_every: a timed launch mostly sees the same neighbours as with every launch timed)
-  const bool timed = e->profile && ((e->profile_phase++ >> 3) % (unsigned)e->profile_every) == 0;
+  const bool timed = e->profile && ((e->profile_phase++ / (unsigned)e->profile_block) % (unsigned)e->profile_every) == 0;
   TimedRegion tr(e, s, AOG_PROF_FUSED, timed);
   if (e->cfg.precision == AOG_PRECISION_FP64) {
     hipLaunchKernelGGL(aog::k_fused_ref, dim3(e->B), dim3(256), 0, s, e->modes64, e->tabs64, e->psi64, e->act_dm,
@@ -351,7 +351,7 @@ int evolve_layer(aog_env* e, hipStream_t s, long long step_index) {
   p.ring_ref = e->psi_offset;
   p.ring_inv = 1.0 / (2.0 * M_PI * e->cfg.wavelength_wfs);
   // (sampled like the fused kernel's launches — blocks of 8 steps, one block in profile_every: two event records cost ~6 us of a 250 us step)
-  TimedRegion tr_ext(e, s, AOG_PROF_EXTRUDE, ((e->profile_phase >> 3) % (unsigned)e->profile_every) == 0);
+  TimedRegion tr_ext(e, s, AOG_PROF_EXTRUDE, ((e->profile_phase / (unsigned)e->profile_block) % (unsigned)e->profile_every) == 0);
   if (e->ext_bar && !getenv("AOG_EXTRUDE_SIMPLE") && !getenv("AOG_EXTRUDE_NOSPLIT") && ext_split_lds(e) <= kLdsBytes) {
     // float64 matrix-core form with each 16-env group's rows split over four workgroups + group barrier
     const size_t lds = ext_split_lds(e);
@@ -2034,6 +2034,13 @@ int aog_selftest_sincos(const float* u_dev, float* sin_dev, float* cos_dev, int 
   hipLaunchKernelGGL(aog::k_selftest_sincos, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), u_dev, sin_dev,
                      cos_dev, n, flavour);
   HIP_TRY(hipGetLastError());
+  return AOG_OK;
+}
+
+int aog_profile_block(aog_env* e, int launches) {
+  if (!e) return fail(AOG_ERR_INVALID, "aog_profile_block: null handle");
+  if (launches < 1 || launches > 64) return fail(AOG_ERR_INVALID, "aog_profile_block: %d launches per block (1 .. 64)", launches);
+  e->profile_block = launches;
   return AOG_OK;
 }
 

@@ -448,7 +448,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    env.profile(True, every=PROFILE_EVERY)   # switched on ahead of the warm-up: the first timed launches of a process pay ~1 ms of runtime set-up
+    # a window of a few dozen steps (the driver's 20) times ONE block of 2 launches: 8 timed launches of 20 held the stream for 48 us = 3.8 %
+    prof_block, prof_every = (8, PROFILE_EVERY) if args.steps >= 256 else (2, max(1, (args.steps + 1) // 2))
+    env.profile(True, every=prof_every, block=prof_block)   # switched on ahead of the warm-up: the first timed launches of a process pay ~1 ms of runtime set-up
     # Device spin-up (reported as config.spinup_steps): a process's first few hundred steps run ~5 % slower than steady state (device
     # clocks).  With a caller-chosen warm-up shorter than that, the difference is run here, ahead of the W warm-up steps, so that the K
     # timed steps measure the steady state a long-running job sees.  Config 2 only (the other configs' steps are 5-100x longer).
@@ -518,14 +520,14 @@ def main():
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_fused_tab" if env.info.kernel == 2 else "k_fused_valu",
                          "kernel_ms": kernel_ms, "launches_timed": launches, "bytes_per_env_step": bytes_step,
                          "layout_bytes_per_env_step": layout_step, "achieved_layout": lay_gbs, "frac_layout": lay_gbs / HBM_PEAK_GBS,
-                         "timed_every": PROFILE_EVERY,
+                         "timed_every": prof_every, "timed_block": prof_block,
                          "f16_mfma": {"achieved": mfma_flops / k_s / 1e12, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                       "frac": mfma_flops / k_s / 1e12 / F16_MFMA_PEAK_TFLOPS,
                                       "note": "matrix flops as issued (split-f16: 3 products per operand pair, padded tiles)"},
                          "valu_issue": None,   # filled below when the PMC citation is there
                          "note": "achieved = algorithmic bytes (SURVEY.md 8d: 4 N^2 + ... per env-step) x envs per launch / mean HIP-event "
-                                 "duration of the fused kernel over the timed region (one block of 8 launches in 8 carries the two event "
-                                 "records); achieved_layout = the same with the bytes the aperture-packed layout must move (4 n_ap per "
+                                 "duration of the fused kernel over the timed region (one block of timed_block launches in timed_every carries the two "
+                                 "event records); achieved_layout = the same with the bytes the aperture-packed layout must move (4 n_ap per "
                                  "screen); traffic = PMC (2*FETCH_SIZE + WRITE_SIZE) per launch from profiles/traffic_latest.json; "
                                  "6.29 TB/s is the measured copy ceiling"},
         }

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define AOG_ABI_VERSION 15
+#define AOG_ABI_VERSION 16
 
 typedef struct aog_env aog_env;
 
@@ -323,6 +323,9 @@ int aog_selftest_barrier_timeout(aog_env* env, void* stream);
  * of a timed launch hold the stream for ~6 us, which a throughput measurement running at the same time should not pay on
  * every step. */
 int aog_profile_enable(aog_env* env, int enable);
+/* Launches per timed block (default 8; 1 .. 64): a window of a few dozen steps takes a short block so that the records stay ~1 % of it
+ * (ABI 16).  Takes effect at the next aog_profile_enable / aog_profile_read. */
+int aog_profile_block(aog_env* env, int launches);
 int aog_profile_read(aog_env* env, double* mean_ms, int* launches);
 /* While profiling is enabled the kernels that dominate the other workloads are timed the same way (HIP events on the launch stream,
  * every launch: they run once per reset or take >= 100 us): which = one of AOG_PROF_*; returns the mean duration and the number of launches
