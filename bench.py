@@ -449,7 +449,7 @@ def main():
         torch.cuda.synchronize()
 
     # a window of a few dozen steps (the driver's 20) times ONE block of 2 launches: 8 timed launches of 20 held the stream for 48 us = 3.8 %
-    prof_block, prof_every = (8, PROFILE_EVERY) if args.steps >= 256 else (2, max(1, (args.steps + 1) // 2))
+    prof_block, prof_every = (8, PROFILE_EVERY) if args.steps >= 64 else (2, max(1, (args.steps + 1) // 2))
     env.profile(True, every=prof_every, block=prof_block)   # switched on ahead of the warm-up: the first timed launches of a process pay ~1 ms of runtime set-up
     # Device spin-up (reported as config.spinup_steps): a process's first few hundred steps run ~5 % slower than steady state (device
     # clocks).  With a caller-chosen warm-up shorter than that, the difference is run here, ahead of the W warm-up steps, so that the K
