@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libaogym.so")
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 AOG_REWARD = {"strehl_ratio": 0, "smf_ssim": 1}
 AOG_PRECISION = {"fast": 0, "fp64": 1}
@@ -93,6 +93,7 @@ SYMBOLS = {
     "aog_set_actuators": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "aog_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "aog_step": (C.c_int, [C.c_void_p] * 9),
+    "aog_step_pipelined": (C.c_int, [C.c_void_p] * 10),
     "aog_focal_image": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "aog_focal_images": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "aog_selftest_poisson": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_void_p]),

@@ -106,6 +106,7 @@ class BatchedAOEnv:
         self._episode_returns = None
         self._trunc = None
         self._persistent_out = False   # see persistent_outputs()
+        self._step_cache = None        # (views of the persistent block + their addresses)
         self._pack = None
 
 
@@ -437,21 +438,33 @@ class BatchedAOEnv:
         self.last_obs_raw = obs_raw
         return obs, {}
 
-    def step(self, actions, out=None):
+    _PIPELINE_END = object()
+
+    def step(self, actions, out=None, next_actions=_PIPELINE_END):
         """AOEnv.step (AO_env.py:106-153).  ``actions``: [B, A] float32 tensor on the device.
+        ``next_actions`` (optional; callers that know the next action already — open-loop sequences, replays, synthetic benchmarks):
+        a [B, A] float32 device tensor = the actions of the NEXT call, or None on the last step of such a sequence.  The step then goes
+        through ``aog_step_pipelined``: identical results, one kernel launch less per step; between two calls of a sequence the mirror
+        already holds the next action, so ``reset`` / ``get_state`` / ``focal_images`` ... raise until the sequence is ended with
+        ``next_actions=None``.
         Returns (obs float16 [B, o^2], reward float32 [B], done bool [B], trunc bool [B] (all False),
         {"power": [B] float32, "obs_raw": [B, o^2] float32, "strehl": [B] float32}).
         ``out`` (optional): (obs float16 [B, o^2], reward float32 [B], done bool/uint8 [B]) contiguous device tensors to write
         into — a rollout hands in slices of its transition buffers, so nothing is copied afterwards."""
         torch = self._torch
-        a = torch.as_tensor(actions, device=self.device)
-        if a.dtype != torch.float32:
-            a = a.to(torch.float32)
-        a = a.reshape(self.num_envs, self.num_modes).contiguous()
+        a = self._as_actions(actions)
         if self.atm_type == "dynamic" and self._host_rng:
             self._host_extrusion_noise()
         n = self.obs_dim ** 2
         B = self.num_envs
+        if self._persistent_out and out is None and self._step_cache is not None:
+            # persistent outputs: the views of the block and their addresses are made once (a step's host cost drops from ~22 to ~10 us, which
+            # matters right after a synchronisation, when the first launches of a burst cost the host twice their steady-state time)
+            ret, ptrs = self._step_cache
+            self._launch_step(a, next_actions, ptrs)
+            self.timestep += 1
+            self.last_obs_raw = ret[4]["obs_raw"]
+            return ret
         # ONE allocation per step: fp32 block (obs_raw | reward | power | strehl), fp16 obs, uint8 done — or none at all when the
         # caller asked for a persistent block (``persistent_outputs``: the single-env wrapper copies it to the host in one transfer)
         nb32, nb16 = 4 * B * (n + 3), 2 * B * n
@@ -477,14 +490,40 @@ class BatchedAOEnv:
             if not ok:
                 raise ValueError("step(out=...): expected contiguous (float16 [B, o^2], float32 [B], bool/uint8 [B]) device tensors")
         base = f32.data_ptr()
-        _lib.check(self.lib.aog_step(self._handle, C.c_void_p(a.data_ptr()), C.c_void_p(base), C.c_void_p(obs.data_ptr()),
-                                     C.c_void_p(reward.data_ptr()), C.c_void_p(done.data_ptr()),
-                                     C.c_void_p(base + 4 * B * (n + 1)), C.c_void_p(base + 4 * B * (n + 2)), self._stream()))
+        ptrs = (base, obs.data_ptr(), reward.data_ptr(), done.data_ptr(), base + 4 * B * (n + 1), base + 4 * B * (n + 2))
+        self._launch_step(a, next_actions, ptrs)
         self.timestep += 1
         self.last_obs_raw = obs_raw
         if self._trunc is None:
             self._trunc = torch.zeros((B,), dtype=torch.bool, device=self.device)
-        return obs, reward, done if done.dtype == torch.bool else done.view(torch.bool), self._trunc, {"power": power, "obs_raw": obs_raw, "strehl": strehl}
+        ret = (obs, reward, done if done.dtype == torch.bool else done.view(torch.bool), self._trunc, {"power": power, "obs_raw": obs_raw, "strehl": strehl})
+        if self._persistent_out and out is None:
+            self._step_cache = (ret, ptrs)
+        return ret
+
+    def _as_actions(self, actions):
+        """[B, A] float32 contiguous device tensor (as is when it already is one)."""
+        torch = self._torch
+        if (isinstance(actions, torch.Tensor) and actions.dtype == torch.float32 and actions.device == self.device and actions.is_contiguous()
+                and actions.dim() == 2 and actions.shape[0] == self.num_envs and actions.shape[1] == self.num_modes):
+            return actions
+        a = torch.as_tensor(actions, device=self.device)
+        if a.dtype != torch.float32:
+            a = a.to(torch.float32)
+        return a.reshape(self.num_envs, self.num_modes).contiguous()
+
+    def _launch_step(self, a, next_actions, ptrs):
+        p = C.c_void_p
+        if next_actions is BatchedAOEnv._PIPELINE_END:
+            _lib.check(self.lib.aog_step(self._handle, p(a.data_ptr()), p(ptrs[0]), p(ptrs[1]), p(ptrs[2]), p(ptrs[3]), p(ptrs[4]), p(ptrs[5]),
+                                         self._stream()))
+        else:
+            nxt = None
+            if next_actions is not None:
+                nxt = self._as_actions(next_actions)
+                self._next_actions_keepalive = nxt   # (read by the launch enqueued here)
+            _lib.check(self.lib.aog_step_pipelined(self._handle, p(a.data_ptr()), p(nxt.data_ptr() if nxt is not None else None), p(ptrs[0]),
+                                                   p(ptrs[1]), p(ptrs[2]), p(ptrs[3]), p(ptrs[4]), p(ptrs[5]), self._stream()))
 
     def persistent_outputs(self, enable=True):
         """Write every ``step``'s outputs into ONE block that lives as long as the env instead of fresh tensors: the tensors a step
@@ -492,6 +531,7 @@ class BatchedAOEnv:
         single-env wrapper: one device-to-host copy of the block per step); returns the block layout (n = obs_dim^2):
         float32 [B n] obs_raw | [B] reward | [B] power | [B] strehl, then float16 [B n] obs, then uint8 [B] done."""
         self._persistent_out = bool(enable)
+        self._step_cache = None
         if not enable:
             self._pack = None
         n, B = self.obs_dim ** 2, self.num_envs

@@ -218,7 +218,8 @@ int launch_fused(aog_env* e, hipStream_t s) {
   // event timing of one launch block in profile_every: the two records cost ~3 us each on the stream, so a throughput measurement that
   // also wants the kernel's duration samples instead of timing every launch
   // (blocks of 8 consecutive launches, one block in profile_every: a timed launch mostly sees the same neighbours as with every launch timed)
-  const bool timed = e->profile && ((e->profile_phase++ / (unsigned)e->profile_block) % (unsigned)e->profile_every) == 0;
+  // (the MIDDLE block of each period of profile_every blocks: a short window's first launches come right after a synchronisation and are its slowest)
+  const bool timed = e->profile && ((e->profile_phase++ / (unsigned)e->profile_block) % (unsigned)e->profile_every) == (unsigned)e->profile_every / 2;
   TimedRegion tr(e, s, AOG_PROF_FUSED, timed);
   if (e->cfg.precision == AOG_PRECISION_FP64) {
     hipLaunchKernelGGL(aog::k_fused_ref, dim3(e->B), dim3(256), 0, s, e->modes64, e->tabs64, e->psi64, e->act_dm,
@@ -231,8 +232,9 @@ int launch_fused(aog_env* e, hipStream_t s) {
   return AOG_OK;
 }
 
+// action_next (aog_step_pipelined): the prologue of the NEXT step rides in the same launch (k_epilogue_prologue)
 int launch_epilogue(aog_env* e, bool is_step, float* obs_raw, uint16_t* obs, float* reward, uint8_t* done, float* power,
-                    float* strehl, hipStream_t s) {
+                    float* strehl, hipStream_t s, const float* action_next = nullptr) {
   aog::EpilogueArgs p{};
   p.partials = e->partials;
   p.wfs_coef = e->wfs_coef;
@@ -274,8 +276,25 @@ int launch_epilogue(aog_env* e, bool is_step, float* obs_raw, uint16_t* obs, flo
   p.ssim_alpha = e->cfg.ssim_alpha;
   const int NS = 2 * (p.MRW + p.MRS);
   const size_t lds = aog::epilogue_lds_bytes(NS, p.n_obs, p.n_fiber, p.MRW_used, p.MRS_used);
-  if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_epilogue), lds, e->device)) return rc;
-  hipLaunchKernelGGL(aog::k_epilogue, dim3((e->Bp + aog::kEpiEnvs - 1) / aog::kEpiEnvs), dim3(1024), lds, s, p);
+  const int n_epi = (e->Bp + aog::kEpiEnvs - 1) / aog::kEpiEnvs;
+  if (action_next) {
+    aog::PrologueArgs q{};
+    const bool mfma_fast = e->kernel == AOG_KERNEL_MFMA && e->cfg.precision == AOG_PRECISION_FAST && !e->sh_ready;
+    q.action = action_next;
+    q.gram = e->gram;
+    q.act_dm = e->act_dm;
+    q.act_rev = mfma_fast ? nullptr : e->act_rev;
+    q.act16 = e->act16;
+    q.B = e->B; q.A = e->A; q.A_pad = e->A_pad; q.Bp = e->Bp;
+    q.sh_operation = e->cfg.sh_operation;
+    q.target = e->cfg.surface_rms_target;
+    q.two_over_lambda = 2.0 / e->cfg.wavelength_wfs;
+    if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_epilogue_prologue), lds, e->device)) return rc;
+    hipLaunchKernelGGL(aog::k_epilogue_prologue, dim3(n_epi + (e->B + aog::kEpiProEnvs - 1) / aog::kEpiProEnvs), dim3(1024), lds, s, p, q, n_epi);
+  } else {
+    if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_epilogue), lds, e->device)) return rc;
+    hipLaunchKernelGGL(aog::k_epilogue, dim3(n_epi), dim3(1024), lds, s, p);
+  }
   HIP_TRY(hipGetLastError());
   return AOG_OK;
 }
@@ -351,7 +370,7 @@ int evolve_layer(aog_env* e, hipStream_t s, long long step_index) {
   p.ring_ref = e->psi_offset;
   p.ring_inv = 1.0 / (2.0 * M_PI * e->cfg.wavelength_wfs);
   // (sampled like the fused kernel's launches — blocks of 8 steps, one block in profile_every: two event records cost ~6 us of a 250 us step)
-  TimedRegion tr_ext(e, s, AOG_PROF_EXTRUDE, ((e->profile_phase / (unsigned)e->profile_block) % (unsigned)e->profile_every) == 0);
+  TimedRegion tr_ext(e, s, AOG_PROF_EXTRUDE, ((e->profile_phase / (unsigned)e->profile_block) % (unsigned)e->profile_every) == (unsigned)e->profile_every / 2);
   if (e->ext_bar && !getenv("AOG_EXTRUDE_SIMPLE") && !getenv("AOG_EXTRUDE_NOSPLIT") && ext_split_lds(e) <= kLdsBytes) {
     // float64 matrix-core form with each 16-env group's rows split over four workgroups + group barrier
     const size_t lds = ext_split_lds(e);
@@ -440,6 +459,9 @@ int check_poisoned(const aog_env* e, const char* who) {
 // With lookahead on, between aog_step(t) and aog_step(t + 1) the screens already stand at step t + 1: anything that reads or replaces
 // them then would see (or break) a state the env is not in.  Episode boundaries are safe: the last step of an episode does not look ahead.
 int refuse_pre_evolved(const aog_env* e, const char* who) {
+  if (e->pro_pending)
+    return fail(AOG_ERR_STATE, "%s: a pipelined step has already loaded the NEXT action into the mirror (aog_step_pipelined with action_next): finish "
+                "the sequence with action_next = NULL (or reset the whole batch) first", who);
   if (e->pre_evolved)
     return fail(AOG_ERR_STATE, "%s: the atmosphere of this handle has been advanced to the next step already (aog_set_lookahead): call it at an "
                 "episode boundary (after a step that returned done), or switch lookahead off and take one more step first", who);
@@ -1618,6 +1640,7 @@ int aog_sh_image(aog_env* e, double* image_dev, void* stream) {
 int aog_sh_update(aog_env* e, const double* noisy_image_dev, double* action_dev, void* stream) {
   if (!e || !action_dev) return fail(AOG_ERR_INVALID, "aog_sh_update: null argument");
   if (!e->sh_ready) return fail(AOG_ERR_STATE, "aog_sh_update before aog_upload_sh");
+  if (int rc = refuse_pre_evolved(e, "aog_sh_update")) return rc;
   HIP_TRY(hipSetDevice(e->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int N = e->cfg.n_pupil;
@@ -1720,6 +1743,7 @@ int aog_get_state(aog_env* e, void* blob_dev, int64_t* timestep_out, void* strea
 int aog_set_state(aog_env* e, const void* blob_dev, int64_t timestep, void* stream) {
   if (!e || !blob_dev) return fail(AOG_ERR_INVALID, "aog_set_state: null argument");
   if (!e->tables_ready) return fail(AOG_ERR_STATE, "aog_set_state before aog_upload_tables");
+  e->pro_pending = false;   // (a restored state replaces the mirror: a pending pipelined action is forgotten)
   HIP_TRY(hipSetDevice(e->device));
   if (e->pre_evolved) {   // a restored state replaces everything the pending extrusion touches: let it finish, then forget it
     HIP_TRY(hipStreamSynchronize(e->ext_stream));
@@ -1796,6 +1820,7 @@ int aog_device_status(aog_env* e, int32_t* status_out) {
 
 int aog_get_actuators(aog_env* e, double* act_dev, void* stream) {
   if (!e || !act_dev) return fail(AOG_ERR_INVALID, "aog_get_actuators: null argument");
+  if (int rc = refuse_pre_evolved(e, "aog_get_actuators")) return rc;   // (pipelined stepping: the mirror already holds the next action)
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipMemcpyAsync(act_dev, e->act_dm, sizeof(double) * e->B * e->A, hipMemcpyDeviceToDevice,
                          static_cast<hipStream_t>(stream)));
@@ -1804,6 +1829,7 @@ int aog_get_actuators(aog_env* e, double* act_dev, void* stream) {
 
 int aog_set_actuators(aog_env* e, const double* act_dev, void* stream) {
   if (!e || !act_dev) return fail(AOG_ERR_INVALID, "aog_set_actuators: null argument");
+  e->pro_pending = false;   // (whatever a pipelined step had loaded is replaced)
   HIP_TRY(hipSetDevice(e->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
   HIP_TRY(hipMemcpyAsync(e->act_dm, act_dev, sizeof(double) * e->B * e->A, hipMemcpyDeviceToDevice, s));
@@ -1836,9 +1862,22 @@ int aog_reset(aog_env* e, const uint8_t* mask, float* obs_raw, uint16_t* obs, vo
   return launch_epilogue(e, false, obs_raw, obs, nullptr, nullptr, nullptr, nullptr, s);
 }
 
+static int step_impl(aog_env* e, const float* action, const float* action_next, bool pipelined, float* obs_raw, uint16_t* obs, float* reward,
+                     uint8_t* done, float* power, float* strehl, void* stream);
 int aog_step(aog_env* e, const float* action, float* obs_raw, uint16_t* obs, float* reward, uint8_t* done, float* power,
              float* strehl, void* stream) {
+  return step_impl(e, action, nullptr, false, obs_raw, obs, reward, done, power, strehl, stream);
+}
+int aog_step_pipelined(aog_env* e, const float* action, const float* action_next, float* obs_raw, uint16_t* obs, float* reward, uint8_t* done,
+                       float* power, float* strehl, void* stream) {
+  return step_impl(e, action, action_next, true, obs_raw, obs, reward, done, power, strehl, stream);
+}
+static int step_impl(aog_env* e, const float* action, const float* action_next, bool pipelined, float* obs_raw, uint16_t* obs, float* reward,
+                     uint8_t* done, float* power, float* strehl, void* stream) {
   if (!e || !action) return fail(AOG_ERR_INVALID, "aog_step: null argument");
+  if (!pipelined && e->pro_pending)
+    return fail(AOG_ERR_STATE, "aog_step: a pipelined step has already loaded the next action (continue with aog_step_pipelined)");
+  if (pipelined && e->lookahead) return fail(AOG_ERR_UNSUPPORTED, "aog_step_pipelined: not together with aog_set_lookahead");
   if (!e->tables_ready || !e->screens_ready) return fail(AOG_ERR_STATE, "aog_step before aog_upload_tables/aog_set_screens");
   if (int rc = check_poisoned(e, "aog_step")) return rc;
   if (e->cfg.reward_type == AOG_REWARD_SMF_SSIM && e->n_obs < 7)
@@ -1862,10 +1901,13 @@ int aog_step(aog_env* e, const float* action, float* obs_raw, uint16_t* obs, flo
   }
   // each fused kernel reads one operand layout: write only that one (the float64 device kernel and the VALU kernel read act_rev)
   const bool mfma_fast = e->kernel == AOG_KERNEL_MFMA && e->cfg.precision == AOG_PRECISION_FAST && !e->sh_ready;
-  hipLaunchKernelGGL(join_ext ? aog::k_prologue<false> : aog::k_prologue<true>, dim3((e->B + aog::kProEnvs - 1) / aog::kProEnvs), dim3(64 * aog::kProEnvs), 0, s, action, e->gram, e->act_dm,
-                     mfma_fast ? nullptr : e->act_rev, e->act16, e->B, e->A,
-                     e->A_pad, e->Bp, e->cfg.sh_operation, e->cfg.surface_rms_target, 2.0 / e->cfg.wavelength_wfs);
-  HIP_TRY(hipGetLastError());
+  if (!e->pro_pending) {   // (pipelined: the previous call's last launch already turned this step's action into actuators)
+    hipLaunchKernelGGL(join_ext ? aog::k_prologue<false> : aog::k_prologue<true>, dim3((e->B + aog::kProEnvs - 1) / aog::kProEnvs), dim3(64 * aog::kProEnvs), 0, s, action, e->gram, e->act_dm,
+                       mfma_fast ? nullptr : e->act_rev, e->act16, e->B, e->A,
+                       e->A_pad, e->Bp, e->cfg.sh_operation, e->cfg.surface_rms_target, 2.0 / e->cfg.wavelength_wfs);
+    HIP_TRY(hipGetLastError());
+  }
+  e->pro_pending = false;
   if (join_ext) HIP_TRY(hipStreamWaitEvent(s, e->ev_ext_done, 0));
   int rc = launch_fused(e, s);
   if (rc != AOG_OK) return rc;
@@ -1878,7 +1920,9 @@ int aog_step(aog_env* e, const float* action, float* obs_raw, uint16_t* obs, flo
     HIP_TRY(hipEventRecord(e->ev_ext_done, e->ext_stream));
     e->pre_evolved = true;
   }
-  return launch_epilogue(e, true, obs_raw, obs, reward, done, power, strehl, s);
+  const int rce = launch_epilogue(e, true, obs_raw, obs, reward, done, power, strehl, s, pipelined ? action_next : nullptr);
+  if (rce == AOG_OK && pipelined && action_next) e->pro_pending = true;
+  return rce;
 }
 
 int aog_focal_image(aog_env* e, int env_index, float* field_dev, void* stream) {

@@ -164,6 +164,7 @@ struct aog_env {
   // profiling of the fused kernel
   float* ret_acc = nullptr;      // caller-owned episode-return accumulator (aog_set_return_accumulator)
   bool profile = false;
+  bool pro_pending = false;      // aog_step_pipelined: the actuators already hold the NEXT step's action (its prologue rode with the last epilogue)
   int profile_block = 8;         // launches per timed block (aog_profile_block)
   int profile_every = 1;         // time every n-th launch of the fused kernel (aog_profile_enable(env, n))
   unsigned profile_phase = 0;

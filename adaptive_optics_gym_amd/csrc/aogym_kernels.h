@@ -231,27 +231,27 @@ constexpr int kProEnvs = 4;   // envs (= waves) per workgroup: they share one co
 // SHARED_GRAM = false: the Gram matrix is read through the caches instead of a 32 KB LDS copy — same arithmetic in the same order (bit-
 // identical), 1 us slower, but the workgroup then fits beside a resident extrusion workgroup (146 KB of a CU's 160 KB LDS): the form
 // aog_step uses while the next step's extrusion runs on the library's stream (aog_set_lookahead)
-template <bool SHARED_GRAM>
-__global__ __launch_bounds__(64 * kProEnvs) void k_prologue(const float* __restrict__ action, const double* __restrict__ gram,
-                                                            double* __restrict__ act_dm, float* __restrict__ act_rev,
-                                                            _Float16* __restrict__ act16, int B, int A, int A_pad, int Bp,
-                                                            int sh_operation, double target, double two_over_lambda) {
+template <bool SHARED_GRAM, int ENVS>
+__device__ __forceinline__ void prologue_body(const float* __restrict__ action, const double* __restrict__ gram,
+                                              double* __restrict__ act_dm, float* __restrict__ act_rev,
+                                              _Float16* __restrict__ act16, int B, int A, int A_pad, int Bp,
+                                              int sh_operation, double target, double two_over_lambda, int block) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int env = blockIdx.x * kProEnvs + wave;
+  const int env = block * ENVS + wave;
   const bool live = env < B;
   __shared__ double Gs[SHARED_GRAM ? 64 * 64 : 1];   // G[j][i] at j * 64 + i (A <= 64); lane i then reads a conflict-free row per j
-  __shared__ double aps[kProEnvs][256];
+  __shared__ double aps[ENVS][256];
   double* ap = aps[wave];
   // A <= 64 (every fast-path config of the reference): the Gram matrix crosses L2 -> LDS ONCE per workgroup, every load of it in
   // flight together with the action loads: one memory round trip in front of the arithmetic (4 K multiply-adds per env).  Round 1
   // had every env pull its own 32 KB copy through L2 (33 MB per step at B = 1024).
   const bool pre = SHARED_GRAM && !sh_operation && A <= 64;
   if (pre) {
-    constexpr int PER = 64 * 64 / (64 * kProEnvs);
+    constexpr int PER = 64 * 64 / (64 * ENVS);
     double g[PER];
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
-      const int idx = threadIdx.x + 64 * kProEnvs * u;
+      const int idx = threadIdx.x + 64 * ENVS * u;
       const int j = idx >> 6, i = idx & 63;
       g[u] = gram[(size_t)min(j, A - 1) * A + min(i, A - 1)];
     }
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(64 * kProEnvs) void k_prologue(const float* __restr
       ap[i] = a / (double)(i + 10);
     }
 #pragma unroll
-    for (int u = 0; u < PER; ++u) Gs[threadIdx.x + 64 * kProEnvs * u] = g[u];
+    for (int u = 0; u < PER; ++u) Gs[threadIdx.x + 64 * ENVS * u] = g[u];
   } else {
     for (int i = lane; i < A; i += 64) {
       const double a = live ? (double)action[(size_t)env * A + i] : 1.0;
@@ -297,6 +297,13 @@ __global__ __launch_bounds__(64 * kProEnvs) void k_prologue(const float* __restr
     if (act_rev) act_rev[(size_t)i * Bp + env] = ar;
     store_act16(act16, env, i, A_pad, ar);
   }
+}
+template <bool SHARED_GRAM>
+__global__ __launch_bounds__(64 * kProEnvs) void k_prologue(const float* __restrict__ action, const double* __restrict__ gram,
+                                                            double* __restrict__ act_dm, float* __restrict__ act_rev,
+                                                            _Float16* __restrict__ act16, int B, int A, int A_pad, int Bp,
+                                                            int sh_operation, double target, double two_over_lambda) {
+  prologue_body<SHARED_GRAM, kProEnvs>(action, gram, act_dm, act_rev, act16, B, A, A_pad, Bp, sh_operation, target, two_over_lambda, (int)blockIdx.x);
 }
 #endif  // AOG_MAIN_TU
 
@@ -1146,12 +1153,11 @@ __host__ __device__ inline size_t epilogue_lds_bytes(int NS, int n_obs, int n_fi
           (size_t)(n_obs + n_fiber) * MRW_used * 2 + (size_t)MRS_used * 2) * sizeof(double);
 }
 #ifdef AOG_MAIN_TU
-__global__ __launch_bounds__(1024) void k_epilogue(EpilogueArgs p) {
-  extern __shared__ double sm[];
+__device__ __forceinline__ void epilogue_body(const EpilogueArgs& p, int block, double* __restrict__ sm) {
   const int e = threadIdx.x & (kEpiEnvs - 1);
   const int q = (threadIdx.x / kEpiEnvs) & 15;            // sum slot
   const int cq = threadIdx.x / (kEpiEnvs * 16);           // chunk group (= wave index)
-  const int env = blockIdx.x * kEpiEnvs + e;              // < Bp: padded envs read defined (ignored) slabs
+  const int env = block * kEpiEnvs + e;              // < Bp: padded envs read defined (ignored) slabs
   const int MR = p.MRW + p.MRS;
   const int NS = 2 * MR;
   const int n_out = p.n_obs + p.n_fiber;
@@ -1201,7 +1207,7 @@ __global__ __launch_bounds__(1024) void k_epilogue(EpilogueArgs p) {
   __syncthreads();
   if (threadIdx.x < kEpiEnvs * kEpiOutSlots) {
     const int oe = threadIdx.x & (kEpiEnvs - 1), slot = threadIdx.x / kEpiEnvs;
-    const int oenv = blockIdx.x * kEpiEnvs + oe;
+    const int oenv = block * kEpiEnvs + oe;
     for (int j = slot; j <= n_out; j += kEpiOutSlots) {
       double zr = 0, zi = 0;
       if (j < n_out) {
@@ -1249,6 +1255,32 @@ __global__ __launch_bounds__(1024) void k_epilogue(EpilogueArgs p) {
   if (p.done) p.done[env] = (tr == p.max_steps) ? 1 : 0;
   if (p.power) p.power[env] = (float)power;
   if (p.strehl) p.strehl[env] = (float)strehl;
+}
+__global__ __launch_bounds__(1024) void k_epilogue(EpilogueArgs p) {
+  extern __shared__ double sm[];
+  epilogue_body(p, (int)blockIdx.x, sm);
+}
+// Pipelined stepping (aog_step_pipelined): the epilogue of step t and the prologue of step t + 1 — which share nothing — in ONE launch:
+// workgroups [0, n_epi) run the epilogue, the rest the prologue with one env per wave, 16 per workgroup (same arithmetic in the same order
+// as the standalone kernel's four: bit-identical).  One launch and one dispatch gap less per step.
+constexpr int kEpiProEnvs = 16;
+struct PrologueArgs {
+  const float* action;
+  const double* gram;
+  double* act_dm;
+  float* act_rev;
+  _Float16* act16;
+  int B, A, A_pad, Bp, sh_operation;
+  double target, two_over_lambda;
+};
+__global__ __launch_bounds__(1024) void k_epilogue_prologue(EpilogueArgs p, PrologueArgs q, int n_epi) {
+  extern __shared__ double sm[];
+  if ((int)blockIdx.x < n_epi) {
+    epilogue_body(p, (int)blockIdx.x, sm);
+    return;
+  }
+  prologue_body<true, kEpiProEnvs>(q.action, q.gram, q.act_dm, q.act_rev, q.act16, q.B, q.A, q.A_pad, q.Bp, q.sh_operation, q.target, q.two_over_lambda,
+                                   (int)blockIdx.x - n_epi);
 }
 #endif  // AOG_MAIN_TU
 

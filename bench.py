@@ -347,6 +347,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-spinup", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="plain aog_step per step instead of aog_step_pipelined (configs 2 and 3)")
     ap.add_argument("--lookahead", action="store_true", help="config 4: launch each step's wind extrusion one step ahead on the library's own stream")
     args = ap.parse_args()
     w = dict(WORKLOADS[args.config])
@@ -419,6 +420,10 @@ def main():
                "done": torch.empty((T, B), dtype=torch.bool, device=device), "mean": torch.empty((B, w["act_dim"]), device=device)}
 
     state = {"t": 0, "obs": None}
+    pipeline = not args.no_pipeline and not w["rollout"] and not w["SH_operation"]
+    if not w["rollout"]:
+        env.persistent_outputs(True)   # a step's outputs live in one block of the env (nothing here keeps them past the next step): no allocation,
+                                       # no new views per step — the host's cost per step drops from ~22 to ~10 us
 
     def start_episode():
         obs, _ = env.reset()
@@ -428,7 +433,7 @@ def main():
             buf["obs"][0].copy_(obs)
 
     def run(n_steps):
-        for _ in range(n_steps):
+        for i_run in range(n_steps):
             t = state["t"]
             if w["rollout"]:          # algorithm.py:242-270: policy query, env.step, transition stored (here: written in place)
                 a, _, _ = dev_actor(buf["obs"][t], 0.5, out=(buf["act"][t], buf["log_prob"][t], buf["mean"]))
@@ -436,6 +441,11 @@ def main():
             elif w["SH_operation"]:   # algorithm.py:253 + :262
                 a, _ = env.SH_step()
                 env.step(a)
+            elif pipeline:
+                # the actions are synthetic and known ahead: the next one is handed over with the current one (aog_step_pipelined: same
+                # results bit for bit, the prologue of step t + 1 rides in the launch of step t's epilogue); an episode's last step ends the sequence
+                # (and so does the last step of this call: every timed window is a self-contained sequence)
+                env.step(actions[t], next_actions=actions[t + 1] if (t + 1 < T and i_run + 1 < n_steps) else None)
             else:
                 env.step(actions[t])
             state["t"] = t + 1
@@ -449,7 +459,7 @@ def main():
         torch.cuda.synchronize()
 
     # a window of a few dozen steps (the driver's 20) times ONE block of 2 launches: 8 timed launches of 20 held the stream for 48 us = 3.8 %
-    prof_block, prof_every = (8, PROFILE_EVERY) if args.steps >= 64 else (2, max(1, (args.steps + 1) // 2))
+    prof_block, prof_every = (8, PROFILE_EVERY) if args.steps >= 64 else (2, max(1, args.steps // 2))   # (the library times the MIDDLE block of each period)
     env.profile(True, every=prof_every, block=prof_block)   # switched on ahead of the warm-up: the first timed launches of a process pay ~1 ms of runtime set-up
     # Device spin-up (reported as config.spinup_steps): a process's first few hundred steps run ~5 % slower than steady state (device
     # clocks).  With a caller-chosen warm-up shorter than that, the difference is run here, ahead of the W warm-up steps, so that the K
@@ -512,6 +522,8 @@ def main():
             "config": {"workload": f"{w['name']}: {w['text']}", "batch_per_gpu": B, "global_batch": total, "n_pupil": w["n_pupil"],
                        "act_dim": w["act_dim"], "obs_dim": w["obs_dim"], "atm_type": w["atm_type"],
                        "kernel": {1: "valu", 2: "mfma"}.get(env.info.kernel, "ref"), "spinup_steps": spinup,
+                       "stepping": ("aog_step_pipelined: the next (synthetic, known) action is handed over with the current one; results bit-identical "
+                                    "to aog_step, one launch less per step; --no-pipeline times plain aog_step") if pipeline else "aog_step",
                        "collective_backend": (dist.get_backend() if distributed else "none (single process)"),
                        "lookahead": bool(w["rollout"] and args.lookahead),
                        "parallelism": f"envs sharded over {world} GPU(s) by global env id, no data-path collective; one all-gather of "

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define AOG_ABI_VERSION 16
+#define AOG_ABI_VERSION 17
 
 typedef struct aog_env aog_env;
 
@@ -266,6 +266,16 @@ int aog_reset(aog_env* env, const uint8_t* mask_dev, float* obs_raw_dev, uint16_
 int aog_step(aog_env* env, const float* action_dev, float* obs_raw_dev, uint16_t* obs_dev, float* reward_dev,
              uint8_t* done_dev, float* power_dev, float* strehl_dev, void* stream);
 
+/* aog_step for callers that know the NEXT action when they hand over the current one (open-loop action sequences, replayed trajectories,
+ * throughput benchmarks on synthetic actions): identical results, one kernel launch less per step.  The last launch of the call carries
+ * the epilogue of this step AND the action -> actuator prologue of the next one (they share nothing); the next call then skips its own
+ * prologue and `action` must be the `action_next` of the call before (it is not looked at).  action_next = NULL ends the sequence (a plain
+ * epilogue).  Between a call with action_next != NULL and the next call the mirror state already belongs to the next step: aog_reset,
+ * aog_step, aog_get_state, aog_get_actuators, aog_focal_image(s), aog_sh_* ... fail with AOG_ERR_STATE until the sequence is ended
+ * (aog_set_actuators / aog_set_state replace the mirror and end it).  Not together with aog_set_lookahead.  (ABI 17) */
+int aog_step_pipelined(aog_env* env, const float* action_dev, const float* action_next_dev, float* obs_raw_dev, uint16_t* obs_dev, float* reward_dev,
+                       uint8_t* done_dev, float* power_dev, float* strehl_dev, void* stream);
+
 /* self.wf_wfs_after_foc.electric_field of one env (AO_env.py:138): the n_focal x n_focal focal-plane field of the sensing
  * arm with the current screen and mirror, as interleaved (re, im) float32, row-major (y, x), up to a global phase (the
  * library stores screens with their aperture mean removed).  Off the step() path; used for render()/fiber cross-checks. */
@@ -319,7 +329,8 @@ int aog_selftest_barrier_timeout(aog_env* env, void* stream);
 
 /* Microseconds-resolution timing of the dominant (fused) kernel of the most recent aog_step/aog_reset calls,
  * measured with HIP events on the stream the kernel was launched on.  Enable, run steps, then read the
- * mean duration (ms) and the number of launches averaged.  enable = n > 1 times one block of 8 consecutive launches in n only: the two event records
+ * mean duration (ms) and the number of launches averaged.  enable = n > 1 times one block of consecutive launches (aog_profile_block, default 8) in n
+ * only — the middle block of every n: the two event records
  * of a timed launch hold the stream for ~6 us, which a throughput measurement running at the same time should not pay on
  * every step. */
 int aog_profile_enable(aog_env* env, int enable);

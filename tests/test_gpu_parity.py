@@ -679,6 +679,49 @@ def test_batched_focal_images_match_oracle_propagator(N, B, A, act_type):
     env.close()
 
 
+@pytest.mark.parametrize("atm,o,rew,sh", [("quasi_static", 2, "strehl_ratio", False), ("semi_dynamic", 5, "smf_ssim", False),
+                                          ("dynamic", 2, "strehl_ratio", False)])
+def test_pipelined_stepping_is_bit_identical(atm, o, rew, sh):
+    """aog_step_pipelined (the epilogue of step t and the action -> actuator prologue of step t + 1 in one launch, for callers that know
+    the next action already) against plain aog_step: every output of every step and the final mirror state bit for bit, over two episodes
+    with a reset between them; between two calls of a sequence the handle refuses whatever would see the half-advanced mirror."""
+    torch = _torch()
+    from adaptive_optics_gym_amd import BatchedAOEnv
+
+    B, A, N, T = 70, 16, 64, 6
+    kw = dict(atm_type=atm, atm_vel=20.0 if atm == "dynamic" else 0, atm_fried=0.15, act_dim=A, obs_dim=o, rew_type=rew,
+              num_pupil_pixels=N, timesteps_per_episode=T, seed=9, screen_oversampling=4, verbose=False)
+    acts = torch.from_numpy(np.random.RandomState(3).randn(2 * T, B, A).astype(np.float32)).cuda()
+
+    def run(pipelined):
+        env = BatchedAOEnv(B, "cuda:0", **kw)
+        outs = []
+        for ep in range(2):
+            obs0, _ = env.reset()
+            outs.append(obs0.clone())
+            for t in range(T):
+                k = ep * T + t
+                if pipelined:
+                    r = env.step(acts[k], next_actions=acts[k + 1] if t + 1 < T else None)
+                    if t + 1 < T and t == 2:   # mid-sequence: the mirror already belongs to step t + 1
+                        for call in (env.reset, env.get_state, lambda: env.focal_images(0, 1), lambda: env.step(acts[k + 1])):
+                            with pytest.raises(RuntimeError):
+                                call()
+                else:
+                    r = env.step(acts[k])
+                outs.extend([r[0].clone(), r[1].clone(), r[2].clone(), r[4]["obs_raw"].clone(), r[4]["power"].clone(), r[4]["strehl"].clone()])
+        mirror = env.get_actuators().clone()
+        env.close()
+        return outs, mirror
+
+    plain, m0 = run(False)
+    piped, m1 = run(True)
+    assert len(plain) == len(piped)
+    for a, b in zip(plain, piped):
+        assert torch.equal(a, b)
+    assert torch.equal(m0, m1)
+
+
 def test_batched_focal_images_in_several_chunks(monkeypatch):
     """aog_focal_images works through the batch in chunks of whole env tiles (work buffers of <= 256 MB: 1024 envs at N = 256, 256 at
     N = 512).  Forced down to chunks of 32 envs here: the fields of a 100-env batch, of sub-ranges that start and end inside tiles and chunks,

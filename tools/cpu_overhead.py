@@ -21,6 +21,13 @@ def bench(name, f, n=3000):
     print(f"{name}: submit {1e6*(t1-t0)/n:.1f} us/call, incl. drain {1e6*(t2-t0)/n:.1f} us/call", flush=True)
 bench("env.step", lambda: env.step(a))
 bench("env.step(out=)", lambda: env.step(a, out=so))
+bench("env.step(next_actions=)", lambda: env.step(a, next_actions=a))
+env.step(a, next_actions=None)
+env.persistent_outputs(True)
+bench("env.step, persistent outputs", lambda: env.step(a))
+bench("env.step(next_actions=), persistent outputs", lambda: env.step(a, next_actions=a))
+env.step(a, next_actions=None)
+env.persistent_outputs(False)
 bench("DeviceActor", lambda: da(obs, 0.5, out=bufs))
 bench("torch.empty x3", lambda: (torch.empty(B, 4, device=dev), torch.empty(B, device=dev), torch.empty(B, device=dev)))
 big = torch.empty(300, B, 4, device=dev)
