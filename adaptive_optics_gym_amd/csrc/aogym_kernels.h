@@ -2014,9 +2014,8 @@ __global__ __launch_bounds__(256 * KS) void k_extrude16_split(ExtrudeArgs p, int
     if (dbg) { long long t = wall_clock64(); tm[2] += t - t0; t0 = t; }
     // Visibility between the partners.  Placement-independent form: agent-scope release (on this chip: write the XCD's L2 back) before the
     // ticket, agent-scope acquire (drop L1 and the L2 lines of other XCDs) after the wait.  The eight XCDs have an L2 each, and partners that
-    // sit on ONE XCD need less: a store is in that L2 once vmcnt has counted it (the vector L1 writes through), so the writer only drains
-    // its stores and the reader only invalidates its own L1 (`buffer_inv sc0`, the work-group-scope acquire of the gfx942 memory model's
-    // threadgroup-split mode).  Which it is, the group MEASURES: every workgroup ORs the bit of the XCD it really runs on (HW_REG_XCC_ID)
+    // sit on ONE XCD need less on the WRITING side: a store is in that shared L2 once vmcnt has counted it (the vector L1 writes through), so
+    // the writer only drains its stores — no write-back of the whole L2 per round.  Which it is, the group MEASURES: every workgroup ORs the bit of the XCD it really runs on (HW_REG_XCC_ID)
     // into the high half of the group's ticket word ahead of its first ticket — under the full protocol — and whoever sees the four tickets
     // of round 0 sees the four bits; one bit set = one XCD, and the later rounds take the short form.  (The dispatcher deals workgroups b
     // and b + 8 to the same XCD, but nothing promises it: a different placement costs speed, never correctness.)  The full form cost
@@ -2043,8 +2042,9 @@ __global__ __launch_bounds__(256 * KS) void k_extrude16_split(ExtrudeArgs p, int
         }
       }
       if (r == 0) s_same_xcd = (!timed_out && !force_agent_scope && __builtin_popcount((word >> 16) & 0xffu) == 1) ? 1 : 0;
-      if (r == 0 ? !s_same_xcd : !same_xcd) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      else asm volatile("buffer_inv sc0" ::: "memory");
+      // (the reader side keeps the agent-scope acquire in both forms: outside threadgroup-split mode a `buffer_inv sc0` does not reliably
+      // drop this CU's L1 lines — a 4096-env run differed from its 1024-env twin in a few samples, once in three full test runs)
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
