@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libaogym.so")
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 AOG_REWARD = {"strehl_ratio": 0, "smf_ssim": 1}
 AOG_PRECISION = {"fast": 0, "fp64": 1}
@@ -64,6 +64,7 @@ class AogInfo(C.Structure):
 SYMBOLS = {
     "aog_abi_version": (C.c_int, []),
     "aog_last_error": (C.c_char_p, []),
+    "aog_build_id": (C.c_char_p, []),
     "aog_struct_size": (C.c_int64, [C.c_int]),
     "aog_create": (C.c_int, [C.POINTER(AogConfig), C.c_int, C.POINTER(C.c_void_p)]),
     "aog_destroy": (None, [C.c_void_p]),
@@ -128,6 +129,14 @@ def load():
         fn.argtypes = args
     if lib.aog_abi_version() != ABI_VERSION:
         raise RuntimeError(f"libaogym.so ABI {lib.aog_abi_version()} != binding ABI {ABI_VERSION}; rebuild")
+    # the binary must come from the sources beside it (build.py::source_id; developer builds carry "+FLAG" and are accepted on their base id)
+    if os.path.isdir(os.path.join(_HERE, "csrc")) and os.environ.get("AOG_SKIP_BUILD_ID_CHECK") != "1":
+        from .build import source_id
+
+        have, want = lib.aog_build_id().decode(), source_id()
+        if have.split("+")[0] != want:
+            raise RuntimeError(f"libaogym.so was built from other sources (build id {have}, sources {want}): run "
+                               "`python -m adaptive_optics_gym_amd.build` (or __graft_entry__.build())")
     for which, cls in enumerate((AogConfig, AogTables, AogLayerTables, AogShTables, AogActor, AogInfo)):
         if lib.aog_struct_size(which) != C.sizeof(cls):
             raise RuntimeError(f"{cls.__name__}: ctypes layout is {C.sizeof(cls)} bytes, the library's struct {lib.aog_struct_size(which)}")

@@ -8,6 +8,7 @@ All arithmetic of ``reset``/``step`` runs in ``libaogym.so`` (hand-written HIP, 
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -53,7 +54,7 @@ class BatchedAOEnv:
                  timesteps_per_episode=20, flat_mirror_start_per_episode=True, SH_operation=False, *,
                  num_pupil_pixels=240, seed=None, screen_source="device", screen_oversampling=16, screens=None,
                  precision="fast", kernel="auto", pixel_chunks=0, rng=None, verbose=True, params=None,
-                 global_env_offset=0, total_envs=None, sh_fft_precision="single", screen_method="twoband"):
+                 global_env_offset=0, total_envs=None, sh_fft_precision="single", screen_method="twoband", tables=None):
         import torch
 
         self._torch = torch
@@ -114,7 +115,8 @@ class BatchedAOEnv:
         self.action_space = make_box(-1, 1, (self.num_modes,), np.float16)          # AO_env.py:46
 
         self.Cn_squared = cn_squared_from_fried_parameter(self.fried_parameter, self.params.wavelength_sci)
-        self.tables: HostTables = build_tables(self.params, act_type, self.num_modes, self.obs_dim)
+        # (tables=: the HostTables of another instance with the same params / act_type / act_dim / obs_dim, to skip the host precompute)
+        self.tables: HostTables = tables if tables is not None else build_tables(self.params, act_type, self.num_modes, self.obs_dim)
         t = self.tables
         cfg = _lib.AogConfig()
         cfg.abi_version = _lib.ABI_VERSION
@@ -514,14 +516,23 @@ class BatchedAOEnv:
 
     def _launch_step(self, a, next_actions, ptrs):
         p = C.c_void_p
+        pending = getattr(self, "_next_actions_keepalive", None)
         if next_actions is BatchedAOEnv._PIPELINE_END:
+            self._next_actions_keepalive = None
             _lib.check(self.lib.aog_step(self._handle, p(a.data_ptr()), p(ptrs[0]), p(ptrs[1]), p(ptrs[2]), p(ptrs[3]), p(ptrs[4]), p(ptrs[5]),
                                          self._stream()))
         else:
+            # continuation of a pipelined sequence: the mirror already holds what the PREVIOUS call announced as next_actions and the library
+            # ignores `actions` — a caller that passes something else (a corrected action, say) would silently get the old one's results
+            if pending is not None and a is not pending and not (a.data_ptr() == pending.data_ptr() and a.shape == pending.shape):
+                # (other storage: compared by value, which synchronises — AOG_CHECK_PIPELINE=0 skips it for callers that copy their actions around)
+                if os.environ.get("AOG_CHECK_PIPELINE") != "0" and not bool(self._torch.equal(a, pending)):
+                    raise ValueError("step(next_actions=...): `actions` differs from the next_actions announced by the previous call of this "
+                                     "pipelined sequence (the mirror already holds those); end the sequence with next_actions=None first")
             nxt = None
             if next_actions is not None:
                 nxt = self._as_actions(next_actions)
-                self._next_actions_keepalive = nxt   # (read by the launch enqueued here)
+            self._next_actions_keepalive = nxt   # (read by the launch enqueued here; checked against the next call's actions)
             _lib.check(self.lib.aog_step_pipelined(self._handle, p(a.data_ptr()), p(nxt.data_ptr() if nxt is not None else None), p(ptrs[0]),
                                                    p(ptrs[1]), p(ptrs[2]), p(ptrs[3]), p(ptrs[4]), p(ptrs[5]), self._stream()))
 

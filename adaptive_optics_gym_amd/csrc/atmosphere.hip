@@ -1,0 +1,345 @@
+// Dynamic atmosphere (AO_env.py:125): layer tables, wind, the per-step extrusion launch, master / ring maintenance.
+#include "host_common.h"
+#include "k_pack.h"
+#include "k_extrude.h"
+
+using namespace aog_host;
+
+namespace aog_host {
+// float64 ring-buffer master screens of envs [first, first+count) -> the fused kernels' fp32 layouts
+int pack_from_master(aog_env* e, int first, int count, hipStream_t s, bool per_step) {
+  const double inv = 1.0 / (2.0 * M_PI * e->cfg.wavelength_wfs);
+  const int N2 = e->cfg.n_pupil * e->cfg.n_pupil;
+  if (per_step && e->kernel == AOG_KERNEL_MFMA && e->cfg.precision == AOG_PRECISION_FAST && first == 0 && count == e->B) {
+    // fast path: offsets = means measured by the previous repack, whole-row writes
+    hipLaunchKernelGGL(aog::k_refresh_offsets, dim3((e->B + 255) / 256), dim3(256), 0, s, e->psi_offset, e->psi_sum, e->B, e->n_ap);
+    dim3 grid(((e->n_ptiles + 1) / 2 + aog::kRepackIters - 1) / aog::kRepackIters, e->n_etiles);
+    hipLaunchKernelGGL(aog::k_repack_master, grid, dim3(256), 0, s, e->psi_master, e->origin, e->ap_index, e->psi_offset, e->psi_sum,
+                       e->psi_tile, e->B, e->cfg.n_pupil, e->n_ap, e->n_ptiles, inv);
+    HIP_TRY(hipGetLastError());
+    return AOG_OK;
+  }
+  // the MFMA kernel only reads psi_tile, the VALU kernel only psi_rev: write the one that is used
+  float* rev = e->kernel == AOG_KERNEL_VALU ? e->psi_rev : nullptr;
+  float* tile = (e->kernel == AOG_KERNEL_MFMA || e->sh_ready) ? e->psi_tile : nullptr;
+  hipLaunchKernelGGL((aog::k_pack_screens<double>), dim3(count), dim3(256), 0, s, e->psi_master + (size_t)first * N2, e->ap_index,
+                     rev, tile, e->psi64, first, N2, e->n_ap, e->n_ap_pad, e->Bp, inv, (const int32_t*)e->origin,
+                     e->cfg.n_pupil, e->psi_offset, e->psi_sum);
+  HIP_TRY(hipGetLastError());
+  return AOG_OK;
+}
+
+size_t ext16_lds(const aog_env* e) {
+  return (size_t)aog::kExt16G * ((std::max(e->nz_v, e->nz_h) | 1) + (e->cfg.n_pupil | 1)) * sizeof(double);
+}
+
+size_t ext_split_lds(const aog_env* e) {
+  return ((size_t)aog::kExt16G * (aog::ext_split_stride(std::max(e->nz_v, e->nz_h)) + aog::ext_split_stride(e->cfg.n_pupil)) +
+          (size_t)(aog::kExtKs - 1) * 4 * 256) * sizeof(double) + (size_t)(e->nz_v + e->nz_h) * sizeof(int32_t);
+}
+
+// step_index: the AOEnv.timestep this extrusion brings the layer to (layer.t = step_index * delta_t)
+int evolve_layer(aog_env* e, hipStream_t s, long long step_index) {
+  if (!e->layer_ready) return fail(AOG_ERR_STATE, "dynamic atmosphere: aog_upload_layer / aog_set_wind not called");
+  aog::ExtrudeArgs p{};
+  p.master = e->psi_master;
+  p.origin = e->origin;
+  p.ext_counter = e->ext_counter;
+  p.velocity = e->velocity;
+  p.stencil_v = e->stencil_v;
+  p.stencil_h = e->stencil_h;
+  p.stencil_v_yx = e->stencil_v_yx;
+  p.stencil_h_yx = e->stencil_h_yx;
+  p.At_v = e->At_v;
+  p.Bt_v = e->Bt_v;
+  p.At_h = e->At_h;
+  p.Bt_h = e->Bt_h;
+  p.Wa_v = e->Wa_v;
+  p.Wb_v = e->Wb_v;
+  p.Wa_h = e->Wa_h;
+  p.Wb_h = e->Wb_h;
+  p.noise = e->next_noise;
+  p.max_ext = e->next_noise_max_ext;
+  p.N = e->cfg.n_pupil;
+  p.nz_v = e->nz_v;
+  p.nz_h = e->nz_h;
+  p.near_v = e->near_v;
+  p.near_h = e->near_h;
+  p.t_prev = (double)(step_index - 1) * e->delta_t;
+  p.t_new = (double)step_index * e->delta_t;
+  p.pitch = e->pitch;
+  p.sqrt_cn2 = e->sqrt_cn2;
+  p.seed = e->rng_seed;
+  p.env_base = e->cfg.env_id_base;
+  p.ring = e->ring_direct ? e->psi_ring : nullptr;
+  p.ring_ref = e->psi_offset;
+  p.ring_inv = 1.0 / (2.0 * M_PI * e->cfg.wavelength_wfs);
+  // (sampled like the fused kernel's launches — blocks of 8 steps, one block in profile_every: two event records cost ~6 us of a 250 us step)
+  TimedRegion tr_ext(e, s, AOG_PROF_EXTRUDE, ((e->profile_phase / (unsigned)e->profile_block) % (unsigned)e->profile_every) == (unsigned)e->profile_every / 2);
+  if (e->ext_bar && !getenv("AOG_EXTRUDE_SIMPLE") && !getenv("AOG_EXTRUDE_NOSPLIT") && ext_split_lds(e) <= kLdsBytes) {
+    // float64 matrix-core form with each 16-env group's rows split over four workgroups + group barrier
+    const size_t lds = ext_split_lds(e);
+    auto kern = aog::k_extrude16_split<aog::kExtKs>;
+    if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, e->device)) return rc;
+    if (!e->ext_resident) {
+      // The four workgroups of a group meet at a spin barrier: they must be resident together.  Ask once per handle how many of these
+      // workgroups a CU holds (registers + this shape's LDS), keep one CU's worth of margin (the query over-reports by one block per CU for
+      // some kernels: MI355X_MICROARCH.md, Residency), and never put more workgroups than that into one launch.
+      int per_cu = 0, cus = 0;
+      HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 256 * aog::kExtKs, lds));
+      HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
+      if (per_cu < 1 || cus < 8) return fail(AOG_ERR_HIP, "k_extrude16_split does not fit a compute unit (occupancy query: %d)", per_cu);
+      e->ext_resident = std::max(1, per_cu > 1 ? per_cu - 1 : 1) * cus;
+      if (const char* v = getenv("AOG_EXTRUDE_RESIDENT")) e->ext_resident = std::max(8 * aog::kExtParts, atoi(v));   // (tests: force several launches)
+    }
+    p.origin = e->origin;
+    const int groups8 = round_up(e->n_ext_groups, 8);
+    // two ticket sets alternate between steps: this step's launches poll `bar` and zero `bar_next` (both start zeroed at creation)
+    unsigned* bar = e->ext_bar + (size_t)(e->ext_bar_phase & 1) * groups8;
+    unsigned* bar_next = e->ext_bar + (size_t)((e->ext_bar_phase ^ 1) & 1) * groups8;
+    e->ext_bar_phase ^= 1;
+    const int groups_per_launch = std::max(8, e->ext_resident / aog::kExtParts / 8 * 8);
+    for (int g0 = 0; g0 < groups8; g0 += groups_per_launch) {
+      const int ng = std::min(groups_per_launch, groups8 - g0);
+      hipLaunchKernelGGL(kern, dim3(ng * aog::kExtParts), dim3(256 * aog::kExtKs), lds, s, p, e->B, e->ext_perm, bar, e->dev_status,
+                         e->host_flag_dev, g0, e->ext_spin_limit, e->ext_absent_part, bar_next, getenv("AOG_EXTRUDE_AGENT_SCOPE") ? 1 : 0);
+    }
+    HIP_TRY(hipGetLastError());
+  } else if (!getenv("AOG_EXTRUDE_SIMPLE") && ext16_lds(e) <= kLdsBytes) {
+    // default: float64 matrix-core form, 16 envs per workgroup (a workgroup owns whole envs: no cross-workgroup hazard)
+    const size_t lds = (size_t)aog::kExt16G * ((std::max(e->nz_v, e->nz_h) | 1) + (e->cfg.n_pupil | 1)) * sizeof(double);
+    if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_extrude16), lds, e->device)) return rc;
+    p.origin = e->origin;
+    hipLaunchKernelGGL(aog::k_extrude16, dim3((e->B + aog::kExt16G - 1) / aog::kExt16G), dim3(512), lds, s, p, e->B);
+    HIP_TRY(hipGetLastError());
+  } else {
+    const size_t lds = (size_t)aog::kExtG * (std::max(e->nz_v, e->nz_h) + 2 * e->cfg.n_pupil) * sizeof(double);
+    if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_extrude), lds, e->device)) return rc;
+    p.origin = e->origin;
+    hipLaunchKernelGGL(aog::k_extrude, dim3((e->B + aog::kExtG - 1) / aog::kExtG), dim3(aog::kExtThreads), lds, s, p, e->B);
+    HIP_TRY(hipGetLastError());
+  }
+  e->next_noise = nullptr;
+  e->next_noise_max_ext = 0;
+  if (e->ring_direct) {   // the extrusion kept the fp32 ring copy in step: nothing to repack
+    e->tiles_stale = true;
+    return AOG_OK;
+  }
+  return pack_from_master(e, 0, e->B, s, true);
+}
+
+// psi_tile of a ring-direct handle is only refreshed when something other than the step kernel needs it
+int ensure_tiles(aog_env* e, hipStream_t s) {
+  if (!e->ring_direct || !e->tiles_stale) return AOG_OK;
+  const double inv = 1.0 / (2.0 * M_PI * e->cfg.wavelength_wfs);
+  const int N2 = e->cfg.n_pupil * e->cfg.n_pupil;
+  hipLaunchKernelGGL((aog::k_pack_screens<double>), dim3(e->B), dim3(256), 0, s, e->psi_master, e->ap_index, (float*)nullptr, e->psi_tile,
+                     (double*)nullptr, 0, N2, e->n_ap, e->n_ap_pad, e->Bp, inv, (const int32_t*)e->origin, e->cfg.n_pupil, (double*)nullptr,
+                     (double*)nullptr);
+  HIP_TRY(hipGetLastError());
+  e->tiles_stale = false;
+  return AOG_OK;
+}
+
+int ring_from_master(aog_env* e, int first, int count, int keep_ref, hipStream_t s) {
+  hipLaunchKernelGGL(aog::k_ring_from_master, dim3(count), dim3(256), 0, s, e->psi_master, e->origin, e->ap_index, e->psi_offset, e->psi_ring, first,
+                     e->cfg.n_pupil, e->n_ap, 1.0 / (2.0 * M_PI * e->cfg.wavelength_wfs), keep_ref);
+  HIP_TRY(hipGetLastError());
+  e->tiles_stale = true;
+  return AOG_OK;
+}
+
+template <typename T>
+static int store_master_t(aog_env* e, const T* psi, int first, int count, hipStream_t s) {
+  const int N2 = e->cfg.n_pupil * e->cfg.n_pupil;
+  const size_t n = (size_t)count * N2;
+  hipLaunchKernelGGL((aog::k_store_master<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, psi, e->psi_master, e->origin,
+                     e->ext_counter, first, count, N2);
+  HIP_TRY(hipGetLastError());
+  return AOG_OK;
+}
+int store_master_f64(aog_env* e, const double* psi, int first, int count, hipStream_t s) { return store_master_t(e, psi, first, count, s); }
+int store_master_f32(aog_env* e, const float* psi, int first, int count, hipStream_t s) { return store_master_t(e, psi, first, count, s); }
+
+int unroll_master(aog_env* e, double* psi_dev, int first, int count, hipStream_t s) {
+  const int N = e->cfg.n_pupil;
+  const size_t n = (size_t)count * N * N;
+  hipLaunchKernelGGL(aog::k_unroll_master, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, e->psi_master, e->origin, psi_dev, first, count, N);
+  HIP_TRY(hipGetLastError());
+  return AOG_OK;
+}
+}  // namespace aog_host
+
+extern "C" {
+
+int aog_upload_layer(aog_env* e, const aog_layer_tables* t) {
+  if (!e || !t) return fail(AOG_ERR_INVALID, "aog_upload_layer: null argument");
+  if (!e->cfg.atm_dynamic) return fail(AOG_ERR_STATE, "aog_upload_layer: handle was not created with atm_dynamic = 1");
+  if (!t->stencil_vertical || !t->stencil_horizontal || !t->A_vertical || !t->B_vertical || !t->A_horizontal || !t->B_horizontal)
+    return fail(AOG_ERR_INVALID, "aog_upload_layer: null table pointer");
+  const int N = e->cfg.n_pupil;
+  if (t->nz_vertical < 1 || t->nz_horizontal < 1 || t->nz_vertical > 4 * N || t->nz_horizontal > 4 * N || !(t->pixel_pitch > 0) ||
+      !(t->delta_t > 0))
+    return fail(AOG_ERR_INVALID, "aog_upload_layer: bad sizes");
+  for (int k = 0; k < t->nz_vertical; ++k)
+    if (t->stencil_vertical[k] < 0 || t->stencil_vertical[k] >= N * N) return fail(AOG_ERR_INVALID, "aog_upload_layer: stencil index out of range");
+  for (int k = 0; k < t->nz_horizontal; ++k)
+    if (t->stencil_horizontal[k] < 0 || t->stencil_horizontal[k] >= N * N) return fail(AOG_ERR_INVALID, "aog_upload_layer: stencil index out of range");
+  // the lock-step round kernel overwrites the row / column that drops out while other workgroups still gather stencil
+  // samples: only legal if no stencil sample lies in the last logical row (vertical) / column (horizontal)
+  bool safe = true;
+  for (int k = 0; k < t->nz_vertical; ++k) safe &= t->stencil_vertical[k] / N != N - 1;
+  for (int k = 0; k < t->nz_horizontal; ++k) safe &= t->stencil_horizontal[k] % N != N - 1;
+  (void)safe;
+  HIP_TRY(hipSetDevice(e->device));
+  e->nz_v = t->nz_vertical;
+  e->nz_h = t->nz_horizontal;
+  e->sqrt_cn2 = t->sqrt_cn_squared;
+  e->pitch = t->pixel_pitch;
+  e->delta_t = t->delta_t;
+  int rc;
+  auto upload_t = [&](const double* src, int rows, int cols, double** dst) -> int {  // src [rows][cols] -> dst [cols][rows]
+    std::vector<double> tr((size_t)rows * cols);
+    for (int r = 0; r < rows; ++r)
+      for (int c = 0; c < cols; ++c) tr[(size_t)c * rows + r] = src[(size_t)r * cols + c];
+    if (!*dst && (rc = dev_alloc(e, dst, tr.size(), false)) != AOG_OK) return rc;
+    HIP_TRY(hipMemcpy(*dst, tr.data(), sizeof(double) * tr.size(), hipMemcpyHostToDevice));
+    return AOG_OK;
+  };
+  // src [rows][cols] -> [row block][k / 8][lane = (k % 4) * 16 + row % 16][(k / 4) % 2], zero padded: one 16-B load per lane
+  // feeds the A operands of two consecutive v_mfma_f64_16x16x4 k-steps
+  auto upload_blocked = [&](const double* src, int rows, int cols, double** dst) -> int {
+    const int nrb = (rows + 15) / 16, k8 = (cols + 7) / 8;
+    std::vector<double> blk((size_t)nrb * k8 * 128, 0.0);
+    for (int r = 0; r < rows; ++r)
+      for (int c = 0; c < cols; ++c) {
+        const int lane = (c & 3) * 16 + (r & 15);
+        blk[(((size_t)(r >> 4) * k8 + (c >> 3)) * 64 + lane) * 2 + ((c >> 2) & 1)] = src[(size_t)r * cols + c];
+      }
+    if (!*dst && (rc = dev_alloc(e, dst, blk.size(), false)) != AOG_OK) return rc;
+    HIP_TRY(hipMemcpy(*dst, blk.data(), sizeof(double) * blk.size(), hipMemcpyHostToDevice));
+    return AOG_OK;
+  };
+  if (e->layer_ready) return fail(AOG_ERR_STATE, "aog_upload_layer: already uploaded");
+  if (int rcp = refuse_pre_evolved(e, "aog_upload_layer")) return rcp;
+  // The device keeps the stencil samples (and the matching columns of A) with the NEAR ones first — the samples in the two newest slices
+  // (rows 0, 1 of the 'bottom' stencil, columns 0, 1 of the 'left' one), which change with every extrusion — and the FAR ones after
+  // them: k_extrude16_split fetches an env's far samples for the next round ahead of the inter-workgroup barrier.  A permutation of
+  // the terms of A z: every kernel form reads the same arrays.
+  auto near_first = [&](const int32_t* stencil, const double* A, int nz, bool vertical, std::vector<int32_t>& st, std::vector<double>& Ap) -> int {
+    std::vector<int> order;
+    for (int pass = 0; pass < 2; ++pass)
+      for (int k = 0; k < nz; ++k) {
+        const int slice = vertical ? stencil[k] / N : stencil[k] % N;
+        if ((slice < 2) == (pass == 0)) order.push_back(k);
+      }
+    int n_near = 0;
+    for (int k = 0; k < nz; ++k) n_near += (vertical ? stencil[k] / N : stencil[k] % N) < 2;
+    st.resize(nz);
+    Ap.resize((size_t)N * nz);
+    for (int k = 0; k < nz; ++k) {
+      st[k] = stencil[order[k]];
+      for (int r = 0; r < N; ++r) Ap[(size_t)r * nz + k] = A[(size_t)r * nz + order[k]];
+    }
+    return n_near;
+  };
+  std::vector<int32_t> st_v, st_h;
+  std::vector<double> Ap_v, Ap_h;
+  e->near_v = near_first(t->stencil_vertical, t->A_vertical, e->nz_v, true, st_v, Ap_v);
+  e->near_h = near_first(t->stencil_horizontal, t->A_horizontal, e->nz_h, false, st_h, Ap_h);
+  if ((rc = upload_blocked(Ap_v.data(), N, e->nz_v, &e->Wa_v)) != AOG_OK) return rc;
+  if ((rc = upload_blocked(t->B_vertical, N, N, &e->Wb_v)) != AOG_OK) return rc;
+  if ((rc = upload_blocked(Ap_h.data(), N, e->nz_h, &e->Wa_h)) != AOG_OK) return rc;
+  if ((rc = upload_blocked(t->B_horizontal, N, N, &e->Wb_h)) != AOG_OK) return rc;
+  if ((rc = upload_t(Ap_v.data(), N, e->nz_v, &e->At_v)) != AOG_OK) return rc;
+  if ((rc = upload_t(t->B_vertical, N, N, &e->Bt_v)) != AOG_OK) return rc;
+  if ((rc = upload_t(Ap_h.data(), N, e->nz_h, &e->At_h)) != AOG_OK) return rc;
+  if ((rc = upload_t(t->B_horizontal, N, N, &e->Bt_h)) != AOG_OK) return rc;
+  if ((rc = dev_alloc(e, &e->stencil_v, e->nz_v, false)) != AOG_OK) return rc;
+  if ((rc = dev_alloc(e, &e->stencil_h, e->nz_h, false)) != AOG_OK) return rc;
+  HIP_TRY(hipMemcpy(e->stencil_v, st_v.data(), sizeof(int32_t) * e->nz_v, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->stencil_h, st_h.data(), sizeof(int32_t) * e->nz_h, hipMemcpyHostToDevice));
+  {
+    std::vector<int32_t> pv(e->nz_v), ph(e->nz_h);
+    for (int k = 0; k < e->nz_v; ++k) pv[k] = (int32_t)(((uint32_t)(st_v[k] / N) << 16) | (uint32_t)(st_v[k] % N));
+    for (int k = 0; k < e->nz_h; ++k) ph[k] = (int32_t)(((uint32_t)(st_h[k] / N) << 16) | (uint32_t)(st_h[k] % N));
+    if ((rc = dev_alloc(e, &e->stencil_v_yx, e->nz_v, false)) != AOG_OK) return rc;
+    if ((rc = dev_alloc(e, &e->stencil_h_yx, e->nz_h, false)) != AOG_OK) return rc;
+    HIP_TRY(hipMemcpy(e->stencil_v_yx, pv.data(), sizeof(int32_t) * e->nz_v, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->stencil_h_yx, ph.data(), sizeof(int32_t) * e->nz_h, hipMemcpyHostToDevice));
+  }
+  e->layer_ready = true;
+  return AOG_OK;
+}
+
+int aog_set_wind(aog_env* e, const double* velocity_dev, double max_abs_component, void* stream) {
+  if (!e || !velocity_dev || !(max_abs_component >= 0)) return fail(AOG_ERR_INVALID, "aog_set_wind: bad argument");
+  e->max_wind = max_abs_component;
+  if (!e->cfg.atm_dynamic) return fail(AOG_ERR_STATE, "aog_set_wind: handle was not created with atm_dynamic = 1");
+  if (int rcp = refuse_pre_evolved(e, "aog_set_wind")) return rcp;   // (an extrusion launched ahead may still be reading the old wind)
+  HIP_TRY(hipSetDevice(e->device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  HIP_TRY(hipMemcpyAsync(e->velocity, velocity_dev, sizeof(double) * 2 * e->B, hipMemcpyDeviceToDevice, s));
+  // Group envs of similar per-step shift (|dx|, |dy|) for k_extrude16_split: a 16-env group runs max(|dx| + |dy|) rounds and a
+  // round whose envs are split between column and row extrusion costs two matrix passes.  Results do not depend on the grouping.
+  std::vector<double> v((size_t)2 * e->B);
+  HIP_TRY(hipMemcpyAsync(v.data(), velocity_dev, sizeof(double) * v.size(), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  std::vector<int32_t> perm((size_t)e->n_ext_groups * aog::kExt16G, -1);
+  std::vector<int32_t> order(e->B);
+  for (int i = 0; i < e->B; ++i) order[i] = i;
+  const double per_step = e->pitch > 0 ? e->delta_t / e->pitch : 1.0;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+    const double ax = std::fabs(v[2 * a]) * per_step, bx = std::fabs(v[2 * b]) * per_step;
+    const long qa = std::lround(ax * 2), qb = std::lround(bx * 2);   // half-pixel bins of |dx|, then by |dy|
+    if (qa != qb) return qa < qb;
+    return std::fabs(v[2 * a + 1]) < std::fabs(v[2 * b + 1]);
+  });
+  for (int i = 0; i < e->B; ++i) perm[i] = order[i];
+  HIP_TRY(hipMemcpyAsync(e->ext_perm, perm.data(), sizeof(int32_t) * perm.size(), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return AOG_OK;
+}
+
+int aog_set_extrusion_noise(aog_env* e, const double* noise_dev, int max_ext, void* stream) {
+  (void)stream;
+  if (!e || max_ext < 0) return fail(AOG_ERR_INVALID, "aog_set_extrusion_noise: bad argument");
+  if (!e->cfg.atm_dynamic) return fail(AOG_ERR_STATE, "aog_set_extrusion_noise: handle was not created with atm_dynamic = 1");
+  e->next_noise = noise_dev;
+  e->next_noise_max_ext = noise_dev ? max_ext : 0;
+  return AOG_OK;
+}
+
+int aog_set_lookahead(aog_env* e, int enable) {
+  if (!e) return fail(AOG_ERR_INVALID, "aog_set_lookahead: null handle");
+  if (!e->cfg.atm_dynamic) return fail(AOG_ERR_STATE, "aog_set_lookahead: only dynamic-atmosphere handles evolve their screens inside aog_step");
+  HIP_TRY(hipSetDevice(e->device));
+  if (enable && !e->ext_stream) {
+    HIP_TRY(hipStreamCreateWithFlags(&e->ext_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&e->ev_fused_done, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&e->ev_ext_done, hipEventDisableTiming));
+  }
+  e->lookahead = enable != 0;   // (an extrusion already launched ahead stays valid: the next aog_step joins it)
+  return AOG_OK;
+}
+
+int aog_selftest_barrier_timeout(aog_env* e, void* stream) {
+  if (!e) return fail(AOG_ERR_INVALID, "aog_selftest_barrier_timeout: null handle");
+  if (!e->cfg.atm_dynamic || !e->layer_ready || !e->screens_ready) return fail(AOG_ERR_STATE, "aog_selftest_barrier_timeout: needs a dynamic handle with layer and screens");
+  if (!e->ext_bar || getenv("AOG_EXTRUDE_SIMPLE") || getenv("AOG_EXTRUDE_NOSPLIT") || ext_split_lds(e) > kLdsBytes)
+    return fail(AOG_ERR_UNSUPPORTED, "aog_selftest_barrier_timeout: this handle does not use the split extrusion kernel");
+  if (int rcp = refuse_pre_evolved(e, "aog_selftest_barrier_timeout")) return rcp;
+  HIP_TRY(hipSetDevice(e->device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  e->ext_spin_limit = 1u << 10;
+  e->ext_absent_part = 1;
+  e->timestep += 1;
+  const int rc = evolve_layer(e, s, e->timestep);
+  e->ext_spin_limit = 1u << 24;
+  e->ext_absent_part = -1;
+  if (rc != AOG_OK) return rc;
+  HIP_TRY(hipStreamSynchronize(s));
+  return AOG_OK;
+}
+
+}  // extern "C"

@@ -1,6 +1,6 @@
 // Instantiations of the fused kernels for ONE padded mode count (AOG_INST_APAD), all table counts.
-#include "aogym_internal.h"
-#include "aogym_kernels.h"
+#include "host_common.h"
+#include "k_fused.h"
 
 #ifndef AOG_INST_APAD
 #error "compile with -DAOG_INST_APAD=16|32|64|128"
@@ -101,4 +101,31 @@ namespace aog_host {
 #define AOG_CAT2(a, b) a##b
 #define AOG_CAT(a, b) AOG_CAT2(a, b)
 int AOG_CAT(launch_fused_apad, AOG_INST_APAD)(aog_env* e, hipStream_t s) { return launch_fast1<AOG_INST_APAD>(e, s); }
+
+// ---- phase-only contraction u = psi + Mt a (k_phase_mfma) for this padded mode count ----------------------------------------------
+int AOG_CAT(launch_phase_apad, AOG_INST_APAD)(aog_env* e, hipStream_t s, const _Float16* act16, float* out_tile) {
+  constexpr int A_PAD = AOG_INST_APAD;
+  hipLaunchKernelGGL((aog::k_phase_mfma<A_PAD>), dim3((e->n_ptiles + 3) / 4, e->n_etiles), dim3(256), 0, s,
+                     reinterpret_cast<const aog::f16x8*>(e->modes16), reinterpret_cast<const aog::f32x4*>(e->psi_tile),
+                     reinterpret_cast<const aog::f16x8*>(act16), reinterpret_cast<aog::f32x4*>(out_tile), e->n_ptiles, e->n_etiles);
+  return 0;
+}
+// field (or, grid = true, one float of reduced phase per pixel) of every env on its own pupil grid: see k_phase_mfma<.., FIELD, GRID>
+int AOG_CAT(launch_phase_field_apad, AOG_INST_APAD)(aog_env* e, hipStream_t s, const _Float16* act16, const aog::PhaseFieldArgs& fa, bool grid) {
+  constexpr int A_PAD = AOG_INST_APAD;
+  auto kern = grid ? aog::k_phase_mfma<A_PAD, true, true> : aog::k_phase_mfma<A_PAD, true, false>;
+  hipLaunchKernelGGL(kern, dim3((e->n_ptiles + 3) / 4, e->n_etiles), dim3(256), 0, s,
+                     reinterpret_cast<const aog::f16x8*>(e->modes16), reinterpret_cast<const aog::f32x4*>(e->psi_tile),
+                     reinterpret_cast<const aog::f16x8*>(act16), static_cast<aog::f32x4*>(nullptr), e->n_ptiles, e->n_etiles, fa);
+  return 0;
+}
+// K4: reduced phases of env tiles [etile0, etile0 + n_et) as one float per pixel on a dense [env][rows][row_stride] grid (no micro-lens term)
+int AOG_CAT(launch_phase_grid_apad, AOG_INST_APAD)(aog_env* e, hipStream_t s, const _Float16* act16, const aog::PhaseFieldArgs& fa, int etile0, int n_et) {
+  constexpr int A_PAD = AOG_INST_APAD;
+  hipLaunchKernelGGL((aog::k_phase_mfma<A_PAD, true, true>), dim3((e->n_ptiles + 3) / 4, n_et), dim3(256), 0, s,
+                     reinterpret_cast<const aog::f16x8*>(e->modes16), reinterpret_cast<const aog::f32x4*>(e->psi_tile) + (size_t)etile0 * e->n_ptiles * 4 * 64,
+                     reinterpret_cast<const aog::f16x8*>(act16) + (size_t)etile0 * (A_PAD / 16) * 2 * 64, static_cast<aog::f32x4*>(nullptr), e->n_ptiles,
+                     n_et, fa);
+  return 0;
+}
 }  // namespace aog_host

@@ -63,6 +63,26 @@ class EpisodeReturnGatherer:
             self._keep = None if len(keep) == self.world * self.padded else torch.tensor(keep, dtype=torch.long, device=device)
 
         self._attached = None
+        self._timing = None      # time_collective(): [(start event, end event)] or host seconds
+
+    def time_collective(self, enable=True):
+        """Bracket every ``finish_episode`` exchange with device events (host clock for staged gloo rehearsals) so that a scaling run can
+        report what the collective cost: ``collective_ms()`` -> (total milliseconds, exchanges) since the last call."""
+        self._timing = [] if enable else None
+
+    def collective_ms(self):
+        if not self._timing:
+            return 0.0, 0
+        tot = 0.0
+        for a, b in self._timing:
+            if b is None:
+                tot += a * 1e3
+            else:
+                b.synchronize()
+                tot += a.elapsed_time(b)
+        n = len(self._timing)
+        self._timing = []
+        return tot, n
 
     def attach(self, env):
         """Let ``env`` (a ``BatchedAOEnv``) add each step's rewards into ``self.returns`` inside its own last kernel; ``add`` then
@@ -85,14 +105,27 @@ class EpisodeReturnGatherer:
     def finish_episode(self):
         """Returns the [world * local_envs] tensor of episode returns ordered by global env id."""
         if self.distributed:
+            timed = self._timing is not None
             if self._send is not self.returns:
                 self._send[: self.local_envs].copy_(self.returns)
             if self._stage:     # gloo does not all-gather device tensors: single-GPU rehearsals stage through the host
+                import time
+
+                t0 = time.perf_counter()
                 out = self._torch.empty(self._out.shape, dtype=self._out.dtype)
                 self._dist.all_gather_into_tensor(out, self._send.cpu(), group=self.group)
                 self._out.copy_(out)
+                if timed:
+                    self._timing.append((time.perf_counter() - t0, None))
             else:
+                ev = None
+                if timed and self._torch.device(self.device).type == "cuda":
+                    ev = (self._torch.cuda.Event(enable_timing=True), self._torch.cuda.Event(enable_timing=True))
+                    ev[0].record()
                 self._dist.all_gather_into_tensor(self._out, self._send, group=self.group)
+                if ev:
+                    ev[1].record()
+                    self._timing.append(ev)
             self.last_global_returns = self._out if self._keep is None else self._out.index_select(0, self._keep)
         else:
             self.last_global_returns = self.returns.clone()

@@ -205,14 +205,18 @@ def cpu_baseline(w, budget_s=8.0):
 
 def parity_check(env, w, actions, torch):
     """Strehl / obs error of the device path vs the CPU oracle on 2 envs at full size (same screens, same action).  Quasi-static
-    handles only (the screens are read back from the handle)."""
+    handles only (the screens are read back from the handle).  ``obs_rel_err`` is the tests' measure (relative, with the absolute floor
+    of 1e-3 x the vector's peak below which an element is held to an absolute bound: tests/test_gpu_parity.py::_assert_obs_close);
+    ``obs_rel_err_pure`` is the worst |device - oracle| / |oracle| with no floor at all, ``obs_floor_fraction`` the share of elements
+    that sit below the floor (where the two measures differ)."""
     import numpy as np
 
     from oracle.ao_env_oracle import AOEnvOracle
 
     env.reset()
     _, _, _, _, info = env.step(actions)
-    out = {"strehl_abs_err": 0.0, "obs_rel_err": 0.0, "envs": 2}
+    out = {"strehl_abs_err": 0.0, "obs_rel_err": 0.0, "obs_rel_err_pure": 0.0, "obs_floor_fraction": 0.0, "envs": 2}
+    below, count = 0, 0
     for b in (0, env.num_envs - 1):
         screen = env.get_screens(b, 1)[0].cpu().numpy().ravel()      # the stored screen, hcipy's unit (phase * lambda)
         ref = AOEnvOracle(atm_type="quasi_static", atm_fried=w["atm_fried"], act_type=w["act_type"], act_dim=w["act_dim"], obs_dim=w["obs_dim"],
@@ -224,6 +228,10 @@ def parity_check(env, w, actions, torch):
             out["strehl_abs_err"] = max(out["strehl_abs_err"], abs(float(info["strehl"][b]) - ref.last_strehl))
         o, r = info["obs_raw"][b].double().cpu().numpy(), ref.last_obs_raw
         out["obs_rel_err"] = max(out["obs_rel_err"], float(np.max(np.abs(o - r) / np.maximum(np.abs(r), 1e-3 * r.max()))))
+        out["obs_rel_err_pure"] = max(out["obs_rel_err_pure"], float(np.max(np.abs(o - r) / np.abs(r))))
+        below += int(np.sum(np.abs(r) < 1e-3 * r.max()))
+        count += int(r.size)
+    out["obs_floor_fraction"] = below / max(1, count)
     return out
 
 
@@ -300,6 +308,44 @@ def roofline_dominant(env, w, kernels, steps_range):
     return out
 
 
+def fused_at_b4096(env, w, device, torch, steps=120):
+    """The fused kernel at config 2's shape on a working set the Infinity Cache cannot hold (B = 4096: screens + tables 0.9 GB = 3.5 x 256 MiB;
+    every launch re-reads all of it from HBM): its roofline fraction there, next to the headline's B = 1024 figure (whose 0.29 GB working set
+    is partly served on-die).  A second handle with the first one's host tables; 120 causal steps, every fused launch timed."""
+    from adaptive_optics_gym_amd import BatchedAOEnv
+
+    B4 = 4096
+    T = w["timesteps_per_episode"]
+    e4 = BatchedAOEnv(B4, device, atm_type=w["atm_type"], atm_vel=w["atm_vel"], atm_fried=w["atm_fried"], act_type=w["act_type"],
+                      act_dim=w["act_dim"], obs_dim=w["obs_dim"], rew_type=w["rew_type"], timesteps_per_episode=T, num_pupil_pixels=w["n_pupil"],
+                      seed=1234, screen_source="device", screen_oversampling=16, verbose=False, tables=env.tables)
+    e4.persistent_outputs(True)
+    a4 = torch.randn((T, B4, w["act_dim"]), device=device, generator=torch.Generator(device).manual_seed(11)) * (0.5 ** 0.5)
+    e4.reset()
+    for t in range(T):
+        e4.step(a4[t])
+    e4.reset()
+    torch.cuda.synchronize()
+    e4.profile(True, every=1, block=8)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        e4.step(a4[i % T])
+        if (i + 1) % T == 0:
+            e4.reset()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms, n = e4.profile_read()
+    e4.profile(False)
+    by, _, lay = algorithmic_per_step(w["n_pupil"], w["act_dim"], w["obs_dim"], B4, e4.tables.n_ap)
+    out = {"batch": B4, "kernel_ms": ms, "launches_timed": n, "achieved": by * B4 / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": by * B4 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "frac_layout": lay * B4 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "env_steps_per_sec": B4 * steps / dt, "bytes_per_env_step": by,
+           "note": "same kernel, 0.9 GB working set (3.5 x the Infinity Cache): every timed launch streams it from HBM"}
+    e4.close()
+    del e4
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------------------------------------
 def spawn_ranks(args, argv):
     """--gpus N without a launcher: start the N ranks as children (this process has not touched the GPU and never will)."""
@@ -347,7 +393,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-spinup", action="store_true")
-    ap.add_argument("--no-pipeline", action="store_true", help="plain aog_step per step instead of aog_step_pipelined (configs 2 and 3)")
+    ap.add_argument("--no-pipeline", action="store_true", help="skip the second timed region (aog_step_pipelined: `value_pipelined`) of configs 2 and 3")
+    ap.add_argument("--no-b4096", action="store_true", help="config 2: skip the HBM-resident (B = 4096) measurement of the fused kernel")
     ap.add_argument("--lookahead", action="store_true", help="config 4: launch each step's wind extrusion one step ahead on the library's own stream")
     args = ap.parse_args()
     w = dict(WORKLOADS[args.config])
@@ -419,8 +466,11 @@ def main():
                "log_prob": torch.empty((T, B), device=device), "rew": torch.empty((T, B), device=device),
                "done": torch.empty((T, B), dtype=torch.bool, device=device), "mean": torch.empty((B, w["act_dim"]), device=device)}
 
-    state = {"t": 0, "obs": None}
-    pipeline = not args.no_pipeline and not w["rollout"] and not w["SH_operation"]
+    state = {"t": 0, "obs": None, "resets": 0}
+    # `value` is measured with plain, causal aog_step (the loop every caller of the reference runs: algorithm.py:256-262).
+    # aog_step_pipelined (the NEXT action handed over with the current one; bit-identical, one launch less per step, usable only by
+    # open-loop callers) is timed in a second region of the same length and reported as `value_pipelined`.
+    plain_capable = not w["rollout"] and not w["SH_operation"]
     if not w["rollout"]:
         env.persistent_outputs(True)   # a step's outputs live in one block of the env (nothing here keeps them past the next step): no allocation,
                                        # no new views per step — the host's cost per step drops from ~22 to ~10 us
@@ -429,10 +479,11 @@ def main():
         obs, _ = env.reset()
         gather.start_episode()
         state["t"] = 0
+        state["resets"] += 1
         if w["rollout"]:
             buf["obs"][0].copy_(obs)
 
-    def run(n_steps):
+    def run(n_steps, pipeline=False):
         for i_run in range(n_steps):
             t = state["t"]
             if w["rollout"]:          # algorithm.py:242-270: policy query, env.step, transition stored (here: written in place)
@@ -477,20 +528,41 @@ def main():
     run(args.warmup)
     fence()
     env.profile_read()                       # discard the warm-up's samples; timing stays on
+    gather.time_collective(True)
     t_first = env.timestep                   # (python-side step counter: the extrusion's shift count of the timed region is recomputed from it)
+    resets0 = state["resets"]
     t0 = time.perf_counter()
     run(args.steps)
     fence()
     dt = time.perf_counter() - t0
+    dt_local = dt
+    resets_timed = state["resets"] - resets0
     steps_range = (t_first, env.timestep)
     kernel_ms, launches = env.profile_read()
     other_kernels = env.profile_kernels()    # {name: (mean ms, launches)}: reset / extrusion / Shack-Hartmann kernels timed in the same region
-    env.profile(False)
+    coll_ms, coll_n = gather.collective_ms()
     status = env.device_status()
+    # second region, same length: the pipelined call (open-loop callers only)
+    dt_pipe, kernel_ms_pipe = None, None
+    if plain_capable and not args.no_pipeline:
+        fence()
+        t0 = time.perf_counter()
+        run(args.steps, pipeline=True)
+        fence()
+        dt_pipe = time.perf_counter() - t0
+        kernel_ms_pipe, _ = env.profile_read()
+        gather.collective_ms()
+    env.profile(False)
+    status |= env.device_status()
+    rank_wall = [dt_local]
     if distributed:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        tmax = torch.tensor([dt, dt_pipe if dt_pipe is not None else 0.0], dtype=torch.float64, device="cpu" if share else device)
+        every = [torch.zeros_like(tmax) for _ in range(world)]
+        dist.all_gather(every, tmax)         # per-rank wall times: a bad scaling number can be read from one run
+        rank_wall = [float(x[0]) for x in every]
+        dt = max(rank_wall)
+        if dt_pipe is not None:
+            dt_pipe = max(float(x[1]) for x in every)
     if status != 0:
         raise SystemExit(f"bench.py: device status {status} (an inter-workgroup wait timed out): results invalid")
 
@@ -518,12 +590,12 @@ def main():
         result = {
             "metric": "env_steps_per_sec", "value": world * B * args.steps / dt, "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "warmup_effective": args.warmup + spinup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32 storage, split-f16 MFMA, f32/f64 accumulate", "data": "synthetic",
             "config": {"workload": f"{w['name']}: {w['text']}", "batch_per_gpu": B, "global_batch": total, "n_pupil": w["n_pupil"],
                        "act_dim": w["act_dim"], "obs_dim": w["obs_dim"], "atm_type": w["atm_type"],
                        "kernel": {1: "valu", 2: "mfma"}.get(env.info.kernel, "ref"), "spinup_steps": spinup,
-                       "stepping": ("aog_step_pipelined: the next (synthetic, known) action is handed over with the current one; results bit-identical "
-                                    "to aog_step, one launch less per step; --no-pipeline times plain aog_step") if pipeline else "aog_step",
+                       "stepping": "aog_step" + ("" if plain_capable else " inside the policy / Shack-Hartmann loop"),
+                       "timed_window_resets": resets_timed,   # episode ends (reset + all-gather of returns) inside the K timed steps
                        "collective_backend": (dist.get_backend() if distributed else "none (single process)"),
                        "lookahead": bool(w["rollout"] and args.lookahead),
                        "parallelism": f"envs sharded over {world} GPU(s) by global env id, no data-path collective; one all-gather of "
@@ -543,6 +615,17 @@ def main():
                                  "screen); traffic = PMC (2*FETCH_SIZE + WRITE_SIZE) per launch from profiles/traffic_latest.json; "
                                  "6.29 TB/s is the measured copy ceiling"},
         }
+        result["timing"] = {"rank_wall_s": rank_wall, "collective_ms_total": coll_ms, "collectives": coll_n,
+                            "note": "rank_wall_s: every rank's own wall time of the K timed steps (value uses the maximum); collective_ms_total: "
+                                    "device time of this rank's all-gathers of episode returns inside them"}
+        if dt_pipe is not None:
+            result["value_pipelined"] = world * B * args.steps / dt_pipe
+            result["ms_per_step_pipelined"] = dt_pipe / args.steps * 1e3
+            result["pipelined_note"] = ("aog_step_pipelined over a second region of the same K steps: the next (synthetic, known) action is handed over "
+                                        "with the current one, bit-identical results, one launch less per step; NOT usable by a policy in the loop, "
+                                        "hence not `value`")
+            if kernel_ms_pipe:
+                result["roofline"]["kernel_ms_pipelined_region"] = kernel_ms_pipe
         if pmc.get("valu_insts_per_launch") and pmc.get("trans_insts_per_launch") is not None:
             tr_, mf_ = pmc["trans_insts_per_launch"], pmc.get("mfma_insts_per_launch", 0.0)
             cyc = 8 * tr_ + 8 * mf_ + 4 * (pmc["valu_insts_per_launch"] - tr_ - mf_)
@@ -551,6 +634,8 @@ def main():
                 "note": "issue cycles per launch = 8 x transcendental + 8 x matrix + 4 x other vector instructions (SQ_INSTS_VALU, "
                         "SQ_INSTS_VALU_TRANS_F32, SQ_INSTS_MFMA per launch: PMC citation from profiles/traffic_latest.json, not measured in "
                         "this run) / this run's kernel time, against 1024 SIMDs x 2.4 GHz; the binding resource of this kernel"}
+        if args.config == 2 and not args.batch and world == 1 and not args.no_b4096:
+            result["roofline"]["hbm_resident_b4096"] = fused_at_b4096(env, w, device, torch)
         dom = roofline_dominant(env, w, other_kernels, steps_range)
         if dom:
             result["roofline_dominant"] = dom

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define AOG_ABI_VERSION 17
+#define AOG_ABI_VERSION 18
 
 typedef struct aog_env aog_env;
 
@@ -107,6 +107,10 @@ typedef struct {
 } aog_info;
 
 int aog_abi_version(void);
+/* Identity of the sources this binary was compiled from: the first 32 hex digits of the SHA-256 over every csrc/ header and .hip file and this header
+ * (adaptive_optics_gym_amd/build.py::source_id), "+FLAG" appended for developer builds.  The ctypes binding refuses a library whose id
+ * differs from the sources it finds beside it. */
+const char* aog_build_id(void);
 const char* aog_last_error(void);
 /* sizeof() of the structs of this header as the library was compiled, so that a binding in another language can verify its own
  * declarations at load time: which = 0 aog_config, 1 aog_tables, 2 aog_layer_tables, 3 aog_sh_tables, 4 aog_actor, 5 aog_info;
