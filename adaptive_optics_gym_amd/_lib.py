@@ -10,12 +10,13 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libaogym.so")
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 AOG_REWARD = {"strehl_ratio": 0, "smf_ssim": 1}
 AOG_PRECISION = {"fast": 0, "fp64": 1}
 AOG_KERNEL = {"auto": 0, "valu": 1, "mfma": 2}
 AOG_SCREENS = {"twoband": 0, "hcipy16": 1}
+AOG_EXTRUDE = {"auto": 0, "f64": 1}
 AOG_PROF = {"fused": 0, "screen_rows": 1, "screen_cols": 2, "pack": 3, "extrude": 4, "sh_field": 5, "sh_rows_fwd": 6, "sh_cols": 7, "sh_rows_inv": 8}
 
 
@@ -38,6 +39,11 @@ class AogLayerTables(C.Structure):
                 ("A_vertical", C.POINTER(C.c_double)), ("B_vertical", C.POINTER(C.c_double)),
                 ("A_horizontal", C.POINTER(C.c_double)), ("B_horizontal", C.POINTER(C.c_double)),
                 ("sqrt_cn_squared", C.c_double), ("pixel_pitch", C.c_double), ("delta_t", C.c_double)]
+
+
+class AogLayerComposite(C.Structure):
+    _fields_ = [("axis", C.c_int32), ("k_max", C.c_int32), ("n_old", C.c_int32), ("reserved0", C.c_int32),
+                ("old_yx", C.POINTER(C.c_int32)), ("A", C.POINTER(C.c_double)), ("B", C.POINTER(C.c_double))]
 
 
 class AogShTables(C.Structure):
@@ -73,6 +79,8 @@ SYMBOLS = {
     "aog_set_screens_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "aog_set_screens_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "aog_upload_layer": (C.c_int, [C.c_void_p, C.POINTER(AogLayerTables)]),
+    "aog_upload_layer_composite": (C.c_int, [C.c_void_p, C.POINTER(AogLayerComposite)]),
+    "aog_set_extrusion_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "aog_set_wind": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]),
     "aog_set_lookahead": (C.c_int, [C.c_void_p, C.c_int]),
     "aog_set_extrusion_noise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
@@ -137,7 +145,7 @@ def load():
         if have.split("+")[0] != want:
             raise RuntimeError(f"libaogym.so was built from other sources (build id {have}, sources {want}): run "
                                "`python -m adaptive_optics_gym_amd.build` (or __graft_entry__.build())")
-    for which, cls in enumerate((AogConfig, AogTables, AogLayerTables, AogShTables, AogActor, AogInfo)):
+    for which, cls in enumerate((AogConfig, AogTables, AogLayerTables, AogShTables, AogActor, AogInfo, AogLayerComposite)):
         if lib.aog_struct_size(which) != C.sizeof(cls):
             raise RuntimeError(f"{cls.__name__}: ctypes layout is {C.sizeof(cls)} bytes, the library's struct {lib.aog_struct_size(which)}")
     _lib = lib

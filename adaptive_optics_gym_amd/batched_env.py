@@ -46,6 +46,8 @@ class BatchedAOEnv:
                         below the photon noise added before the image is read) | 'double' (complex128, for comparing the noise-free
                         sensor image with a float64 oracle)
     precision           'fast' (fp32 data, float64 accumulators) | 'fp64' (validation kernel)
+    extrusion           'auto' (dynamic atmosphere: the int8 matrix-core composite form, new samples good to ~1e-9 rad) | 'f64' (float64 round
+                        kernels only: the validation form, bit-comparable with the oracle's recursion to 1e-12)
     kernel              'auto' | 'mfma' | 'valu'
     """
 
@@ -54,7 +56,7 @@ class BatchedAOEnv:
                  timesteps_per_episode=20, flat_mirror_start_per_episode=True, SH_operation=False, *,
                  num_pupil_pixels=240, seed=None, screen_source="device", screen_oversampling=16, screens=None,
                  precision="fast", kernel="auto", pixel_chunks=0, rng=None, verbose=True, params=None,
-                 global_env_offset=0, total_envs=None, sh_fft_precision="single", screen_method="twoband", tables=None):
+                 global_env_offset=0, total_envs=None, sh_fft_precision="single", screen_method="twoband", tables=None, extrusion="auto"):
         import torch
 
         self._torch = torch
@@ -103,6 +105,9 @@ class BatchedAOEnv:
         if screen_method not in _lib.AOG_SCREENS:
             raise ValueError("screen_method must be 'twoband' or 'hcipy16'")
         self.screen_method = screen_method
+        if extrusion not in _lib.AOG_EXTRUDE:
+            raise ValueError("extrusion must be 'auto' or 'f64'")
+        self._extrusion = extrusion
         self._rng = rng
         self._episode_returns = None
         self._trunc = None
@@ -273,6 +278,33 @@ class BatchedAOEnv:
         _lib.check(self.lib.aog_set_wind(self._handle, C.c_void_p(v.data_ptr()), float(np.abs(self.velocity_vectors).max()), self._stream()))
         _lib.check(self.lib.aog_set_rng_seed(self._handle, C.c_uint64(1234 if self.seed is None else int(self.seed))))
         torch.cuda.current_stream(self.device).synchronize()
+        self._upload_composite(layer)
+
+    def _upload_composite(self, layer):
+        """The step's shifts along each axis as ONE operator (``extrusion_host.compose_extrusions``) for the int8 matrix-core extrusion
+        (``aog_upload_layer_composite``).  k_max = the largest whole-pixel shift any env makes per step; winds that would need more than 8
+        shifts per axis and step (or ``extrusion='f64'``) keep the float64 round kernels."""
+        from .extrusion_host import compose_extrusions
+
+        self.extrusion_kmax = 0
+        vmax = float(np.abs(self.velocity_vectors).max()) if self.velocity_vectors.size else 0.0
+        k_need = int(np.floor(vmax * self.params.delta_t / self.params.pupil_pixel)) + 1
+        if self._extrusion == "f64" or k_need > 8 or os.environ.get("AOG_EXTRUDE_F64"):
+            return
+        N = self.num_pupil_pixels
+        keep = []
+        for axis, (st, A, B) in enumerate(((layer["stencil_vertical"], layer["A_vertical"], layer["B_vertical"]),
+                                            (layer["stencil_horizontal"], layer["A_horizontal"], layer["B_horizontal"]))):
+            yx, Ak, Bk = compose_extrusions(st, A, B, N, k_need, vertical=axis == 0)
+            yx, Ak, Bk = np.ascontiguousarray(yx, dtype=np.int32), np.ascontiguousarray(Ak), np.ascontiguousarray(Bk)
+            keep.append((yx, Ak, Bk))
+            op = _lib.AogLayerComposite(axis, k_need, int(yx.size), 0, _dptr(yx, C.c_int32), _dptr(Ak, C.c_double), _dptr(Bk, C.c_double))
+            _lib.check(self.lib.aog_upload_layer_composite(self._handle, C.byref(op)))
+        self.extrusion_kmax = k_need
+
+    def set_extrusion_mode(self, mode):
+        """'auto' (default: the int8 composite form when its operators were uploaded) | 'f64' (the float64 round kernels: validation form)."""
+        _lib.check(self.lib.aog_set_extrusion_mode(self._handle, _lib.AOG_EXTRUDE[mode]))
 
     def _upload_shack_hartmann(self):
         """shack_hartmann_init (AO_env.py:396-465): host calibration, then the tables of the device chain."""

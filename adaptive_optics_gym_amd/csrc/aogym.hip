@@ -365,6 +365,7 @@ int64_t aog_struct_size(int which) {
     case 3: return (int64_t)sizeof(aog_sh_tables);
     case 4: return (int64_t)sizeof(aog_actor);
     case 5: return (int64_t)sizeof(aog_info);
+    case 6: return (int64_t)sizeof(aog_layer_composite);
     default: return -1;
   }
 }

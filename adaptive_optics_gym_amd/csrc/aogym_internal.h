@@ -153,6 +153,18 @@ struct aog_env {
   double* Wa_h = nullptr;
   double* Wb_h = nullptr;
   int nz_v = 0, nz_h = 0;
+  // int8 composite extrusion (aog_upload_layer_composite; kernels in k_extrude_i8.h).  x8_host: host copies of the operator tables (opaque here)
+  void* x8_host = nullptr;
+  void* x8_tables_dev = nullptr;   // aog::X8Table [2][kX8MaxK + 1]
+  int x8_kmax[2] = {0, 0};         // k_max uploaded per axis (0 = none)
+  int ext_mode = 0;                // AOG_EXTRUDE_*
+  int32_t* x8_dxy = nullptr;
+  int32_t* x8_slot = nullptr;
+  int32_t* x8_list = nullptr;
+  int32_t* x8_tile_k = nullptr;
+  int8_t* x8_Z8 = nullptr;
+  double* x8_rec = nullptr;
+  int x8_tiles64_max = 0, x8_slots_max = 0, x8_KsTot_max = 0, x8_rt_max = 0;
   int near_v = 0, near_h = 0;    // stencil samples in the two newest slices come first in the uploaded order (aog_upload_layer)
   double sqrt_cn2 = 0, pitch = 0, delta_t = 0;
   const double* next_noise = nullptr;

@@ -2,8 +2,100 @@
 #include "host_common.h"
 #include "k_pack.h"
 #include "k_extrude.h"
+#include "k_extrude_i8.h"
 
 using namespace aog_host;
+
+// ---- int8 composite extrusion: host side -----------------------------------------------------------------------------------------------
+namespace {
+struct X8Host {
+  aog::X8Table tab[2][aog::kX8MaxK + 1] = {};
+};
+
+void x8_digits_host(long long x, int nd, int8_t* d) {   // balanced base-128 digits, most significant first (as the device's x8_digits)
+  for (int t = nd - 1; t > 0; --t) {
+    const int dg = (int)((x + 64) & 127) - 64;
+    d[t] = (int8_t)dg;
+    x = (x - dg) >> 7;
+  }
+  d[0] = (int8_t)x;
+}
+
+// The step's whole-pixel shifts never exceed floor(max wind component x delta_t / pitch) + 1 per axis (difference of two roundings)
+int x8_needed_k(const aog_env* e) { return (int)std::floor(e->max_wind * e->delta_t / e->pitch) + 1; }
+
+bool x8_usable(const aog_env* e) {
+  if (e->ext_mode == AOG_EXTRUDE_F64 || getenv("AOG_EXTRUDE_F64") || !e->x8_host) return false;
+  const int kcap = std::min(e->x8_kmax[0], e->x8_kmax[1]);
+  return kcap >= 1 && x8_needed_k(e) <= kcap;
+}
+
+int x8_ensure_buffers(aog_env* e) {
+  if (e->x8_Z8) return AOG_OK;
+  const X8Host* h = static_cast<const X8Host*>(e->x8_host);
+  const int kcap = std::min(e->x8_kmax[0], e->x8_kmax[1]);
+  int ks_max = 0, rt_max = 0;
+  for (int a = 0; a < 2; ++a)
+    for (int k = 1; k <= kcap; ++k) {
+      ks_max = std::max(ks_max, h->tab[a][k].KsA + h->tab[a][k].KsB);
+      rt_max = std::max(rt_max, h->tab[a][k].RT);
+    }
+  e->x8_tiles64_max = (e->B + 63) / 64 + kcap;   // every shift class may end in a partly filled tile
+  e->x8_slots_max = e->x8_tiles64_max * 64;
+  e->x8_KsTot_max = ks_max;
+  e->x8_rt_max = rt_max;
+  int rc;
+  if ((rc = dev_alloc(e, &e->x8_dxy, (size_t)2 * e->B)) != AOG_OK) return rc;
+  if ((rc = dev_alloc(e, &e->x8_slot, (size_t)2 * e->B)) != AOG_OK) return rc;
+  if ((rc = dev_alloc(e, &e->x8_list, (size_t)2 * e->x8_slots_max)) != AOG_OK) return rc;
+  if ((rc = dev_alloc(e, &e->x8_tile_k, (size_t)2 * e->x8_tiles64_max)) != AOG_OK) return rc;
+  if ((rc = dev_alloc(e, &e->x8_rec, (size_t)4 * e->x8_slots_max)) != AOG_OK) return rc;
+  if ((rc = dev_alloc(e, &e->x8_Z8, (size_t)2 * e->x8_tiles64_max * ks_max * 5 * 1024)) != AOG_OK) return rc;   // (zeroed: unused columns hold zeros, not junk)
+  return AOG_OK;
+}
+
+// one step of every env's wind shifts as plan -> (prepare, product) x 2
+int x8_evolve(aog_env* e, hipStream_t s, long long step_index) {
+  if (int rc = x8_ensure_buffers(e)) return rc;
+  aog::X8Args p{};
+  p.tables = static_cast<const aog::X8Table*>(e->x8_tables_dev);
+  p.master = e->psi_master;
+  p.ring = e->ring_direct ? e->psi_ring : nullptr;
+  p.ring_ref = e->psi_offset;
+  p.ring_inv = 1.0 / (2.0 * M_PI * e->cfg.wavelength_wfs);
+  p.origin = e->origin;
+  p.ext_counter = e->ext_counter;
+  p.velocity = e->velocity;
+  p.noise = e->next_noise;
+  p.max_ext = e->next_noise_max_ext;
+  p.N = e->cfg.n_pupil;
+  p.B = e->B;
+  p.kcap = std::min(e->x8_kmax[0], e->x8_kmax[1]);
+  p.t_prev = (double)(step_index - 1) * e->delta_t;
+  p.t_new = (double)step_index * e->delta_t;
+  p.pitch = e->pitch;
+  p.seed = e->rng_seed;
+  p.env_base = e->cfg.env_id_base;
+  p.dxy = e->x8_dxy;
+  p.slot = e->x8_slot;
+  p.list = e->x8_list;
+  p.tile_k = e->x8_tile_k;
+  p.tiles64_max = e->x8_tiles64_max;
+  p.slots_max = e->x8_slots_max;
+  p.Z8 = e->x8_Z8;
+  p.KsTot_max = e->x8_KsTot_max;
+  p.rec = e->x8_rec;
+  p.status = e->dev_status;
+  hipLaunchKernelGGL(aog::k_x8_plan, dim3(1), dim3(64), 0, s, p);
+  const dim3 gprep((e->B + aog::kX8PrepWaves - 1) / aog::kX8PrepWaves), gprod(e->x8_tiles64_max, (e->x8_rt_max + 1) / 2);
+  for (int phase = 0; phase < 2; ++phase) {
+    hipLaunchKernelGGL(aog::k_x8_prepare, gprep, dim3(64 * aog::kX8PrepWaves), 0, s, p, phase);
+    hipLaunchKernelGGL(aog::k_x8_product, gprod, dim3(256), 0, s, p, phase);
+  }
+  HIP_TRY(hipGetLastError());
+  return AOG_OK;
+}
+}  // namespace
 
 namespace aog_host {
 // float64 ring-buffer master screens of envs [first, first+count) -> the fused kernels' fp32 layouts
@@ -76,7 +168,10 @@ int evolve_layer(aog_env* e, hipStream_t s, long long step_index) {
   p.ring_inv = 1.0 / (2.0 * M_PI * e->cfg.wavelength_wfs);
   // (sampled like the fused kernel's launches — blocks of 8 steps, one block in profile_every: two event records cost ~6 us of a 250 us step)
   TimedRegion tr_ext(e, s, AOG_PROF_EXTRUDE, ((e->profile_phase / (unsigned)e->profile_block) % (unsigned)e->profile_every) == (unsigned)e->profile_every / 2);
-  if (e->ext_bar && !getenv("AOG_EXTRUDE_SIMPLE") && !getenv("AOG_EXTRUDE_NOSPLIT") && ext_split_lds(e) <= kLdsBytes) {
+  if (x8_usable(e)) {
+    // int8 matrix-core form: the step's x shifts, then its y shifts, each as one exact fixed-point product (k_extrude_i8.h)
+    if (int rc = x8_evolve(e, s, step_index)) return rc;
+  } else if (e->ext_bar && !getenv("AOG_EXTRUDE_SIMPLE") && !getenv("AOG_EXTRUDE_NOSPLIT") && ext_split_lds(e) <= kLdsBytes) {
     // float64 matrix-core form with each 16-env group's rows split over four workgroups + group barrier
     const size_t lds = ext_split_lds(e);
     auto kern = aog::k_extrude16_split<aog::kExtKs>;
@@ -269,6 +364,125 @@ int aog_upload_layer(aog_env* e, const aog_layer_tables* t) {
     HIP_TRY(hipMemcpy(e->stencil_h_yx, ph.data(), sizeof(int32_t) * e->nz_h, hipMemcpyHostToDevice));
   }
   e->layer_ready = true;
+  return AOG_OK;
+}
+
+int aog_upload_layer_composite(aog_env* e, const aog_layer_composite* t) {
+  if (!e || !t) return fail(AOG_ERR_INVALID, "aog_upload_layer_composite: null argument");
+  if (!e->cfg.atm_dynamic || !e->layer_ready) return fail(AOG_ERR_STATE, "aog_upload_layer_composite: needs a dynamic handle after aog_upload_layer");
+  if (t->axis < 0 || t->axis > 1 || t->k_max < 1 || t->k_max > aog::kX8MaxK || t->n_old < 1 || !t->old_yx || !t->A || !t->B)
+    return fail(AOG_ERR_INVALID, "aog_upload_layer_composite: bad argument (axis %d, k_max %d of at most %d, n_old %d)", t->axis, t->k_max, aog::kX8MaxK, t->n_old);
+  if (e->x8_kmax[t->axis]) return fail(AOG_ERR_STATE, "aog_upload_layer_composite: axis %d already uploaded", t->axis);
+  if (int rcp = refuse_pre_evolved(e, "aog_upload_layer_composite")) return rcp;
+  const int N = e->cfg.n_pupil, K = t->k_max, U = t->n_old, Np = round_up(N, 64);
+  if (U > 64 * aog::kX8MaxChunks * 16) return fail(AOG_ERR_UNSUPPORTED, "aog_upload_layer_composite: union stencil of %d samples (at most %d built)", U, 64 * aog::kX8MaxChunks * 16);
+  for (int c = 0; c < U; ++c)
+    if ((t->old_yx[c] >> 16) < 0 || (t->old_yx[c] >> 16) >= N || (t->old_yx[c] & 0xffff) >= N) return fail(AOG_ERR_INVALID, "aog_upload_layer_composite: old_yx[%d] outside the screen", c);
+  HIP_TRY(hipSetDevice(e->device));
+  if (!e->x8_host) e->x8_host = new X8Host();
+  X8Host* h = static_cast<X8Host*>(e->x8_host);
+  const bool vertical = t->axis == 0;
+  const double mid = 0.5 * (double)(N - 1);
+  // the first shift whose rows touch each union column (exact zeros elsewhere: compose_extrusions never writes them)
+  std::vector<int> first_use((size_t)U, K + 1);
+  for (int j = 1; j <= K; ++j)
+    for (int i = 0; i < N; ++i) {
+      const double* row = t->A + (size_t)((j - 1) * N + i) * U;
+      for (int c = 0; c < U; ++c)
+        if (row[c] != 0.0 && first_use[c] > j) first_use[c] = j;
+    }
+  int rc;
+  auto up = [&](auto** dst, const auto* src, size_t count) -> int {
+    if ((rc = dev_alloc(e, dst, count, false)) != AOG_OK) return rc;
+    HIP_TRY(hipMemcpy(*dst, src, sizeof(**dst) * count, hipMemcpyHostToDevice));
+    return AOG_OK;
+  };
+  for (int k = 1; k <= K; ++k) {
+    std::vector<int> cols;
+    for (int c = 0; c < U; ++c)
+      if (first_use[c] <= k) cols.push_back(c);
+    const int Uk = (int)cols.size(), KsA = (Uk + 31) / 32, KsB = k * Np / 32, RT = k * Np / 32;
+    if (Uk < 2) return fail(AOG_ERR_INVALID, "aog_upload_layer_composite: operator for k = %d has %d columns", k, Uk);
+    double amax = 0.0, bmax = 0.0;
+    for (int r = 0; r < k * N; ++r) {
+      for (int c : cols) amax = std::max(amax, std::fabs(t->A[(size_t)r * U + c]));
+      for (int c = 0; c < k * N; ++c) bmax = std::max(bmax, std::fabs(t->B[(size_t)r * K * N + c]) * e->sqrt_cn2);
+    }
+    if (!(amax > 0.0) || !(bmax > 0.0) || !std::isfinite(amax) || !std::isfinite(bmax)) return fail(AOG_ERR_INVALID, "aog_upload_layer_composite: empty or non-finite operator");
+    const int log2_qa = std::ilogb(amax) + 1 - 34, log2_qb = std::ilogb(bmax) + 1 - 27;   // |A| / qa < 2^34 (5 digits), |B| / qb < 2^27 (4 digits)
+    std::vector<int32_t> yx((size_t)KsA * 32);
+    std::vector<int8_t> A8((size_t)RT * KsA * 5 * 1024, 0), B8((size_t)RT * KsB * 4 * 1024, 0);
+    std::vector<double> r1((size_t)RT * 32, 0.0), r2((size_t)RT * 32, 0.0);
+    double sx = 0.0, sxx = 0.0;
+    std::vector<double> xa((size_t)Uk);
+    for (int cc = 0; cc < Uk; ++cc) {
+      const int32_t q = t->old_yx[cols[cc]];
+      xa[cc] = (double)(vertical ? (q & 0xffff) : (q >> 16)) - mid;
+      sx += xa[cc];
+      sxx += xa[cc] * xa[cc];
+    }
+    for (int cc = 0; cc < KsA * 32; ++cc) yx[cc] = t->old_yx[cols[cc < Uk ? cc : 0]];
+    for (int j = 1; j <= k; ++j)
+      for (int i = 0; i < N; ++i) {
+        const int row = (j - 1) * Np + i, rt = row >> 5;
+        const double* arow = t->A + (size_t)((j - 1) * N + i) * U;
+        long double s1 = 0.0L, s2 = 0.0L;
+        for (int cc = 0; cc < Uk; ++cc) {
+          const double a = arow[cols[cc]];
+          s1 += a;
+          s2 += (long double)a * xa[cc];
+          int8_t d[5];
+          x8_digits_host(std::llrint(std::ldexp(a, -log2_qa)), 5, d);
+          const size_t base = (((size_t)rt * KsA + (cc >> 5)) * 5) * 1024 + (size_t)((row & 31) + 32 * ((cc & 31) >> 4)) * 16 + (cc & 15);
+          for (int dg = 0; dg < 5; ++dg) A8[base + (size_t)dg * 1024] = d[dg];
+        }
+        r1[row] = (double)s1;
+        r2[row] = (double)s2;
+        const double* brow = t->B + (size_t)((j - 1) * N + i) * K * N;
+        for (int jj = 1; jj <= j; ++jj)
+          for (int ii = 0; ii < N; ++ii) {
+            const double b = brow[(size_t)(jj - 1) * N + ii] * e->sqrt_cn2;
+            if (b == 0.0) continue;
+            const int cc = (jj - 1) * Np + ii;
+            int8_t d[4];
+            x8_digits_host(std::llrint(std::ldexp(b, -log2_qb)), 4, d);
+            const size_t base = (((size_t)rt * KsB + (cc >> 5)) * 4) * 1024 + (size_t)((row & 31) + 32 * ((cc & 31) >> 4)) * 16 + (cc & 15);
+            for (int dg = 0; dg < 4; ++dg) B8[base + (size_t)dg * 1024] = d[dg];
+          }
+      }
+    aog::X8Table& tb = h->tab[t->axis][k];
+    tb = aog::X8Table{};
+    int32_t* d_yx = nullptr;
+    int8_t *d_A8 = nullptr, *d_B8 = nullptr;
+    double *d_r1 = nullptr, *d_r2 = nullptr;
+    if ((rc = up(&d_yx, yx.data(), yx.size())) != AOG_OK) return rc;
+    if ((rc = up(&d_A8, A8.data(), A8.size())) != AOG_OK) return rc;
+    if ((rc = up(&d_B8, B8.data(), B8.size())) != AOG_OK) return rc;
+    if ((rc = up(&d_r1, r1.data(), r1.size())) != AOG_OK) return rc;
+    if ((rc = up(&d_r2, r2.data(), r2.size())) != AOG_OK) return rc;
+    tb.yx = d_yx; tb.A8 = d_A8; tb.B8 = d_B8; tb.r1 = d_r1; tb.r2 = d_r2;
+    tb.k = k; tb.U = Uk; tb.KsA = KsA; tb.KsB = KsB; tb.RT = RT; tb.Np = Np;
+    tb.log2_qa = log2_qa;
+    tb.log2_cn = log2_qa + 7 - log2_qb;
+    tb.ez_floor = 3 - tb.log2_cn;
+    tb.sx = sx;
+    tb.sxx = sxx;
+  }
+  e->x8_kmax[t->axis] = K;
+  if (!e->x8_tables_dev) {
+    void* dp = nullptr;
+    if ((rc = dev_alloc_bytes(e, &dp, sizeof h->tab, true)) != AOG_OK) return rc;
+    e->x8_tables_dev = dp;
+  }
+  HIP_TRY(hipMemcpy(e->x8_tables_dev, h->tab, sizeof h->tab, hipMemcpyHostToDevice));
+  return AOG_OK;
+}
+
+int aog_set_extrusion_mode(aog_env* e, int mode) {
+  if (!e) return fail(AOG_ERR_INVALID, "aog_set_extrusion_mode: null handle");
+  if (mode != AOG_EXTRUDE_AUTO && mode != AOG_EXTRUDE_F64) return fail(AOG_ERR_INVALID, "aog_set_extrusion_mode: unknown mode %d", mode);
+  if (int rcp = refuse_pre_evolved(e, "aog_set_extrusion_mode")) return rcp;
+  e->ext_mode = mode;
   return AOG_OK;
 }
 

@@ -64,6 +64,42 @@ def sample_action(mean, cov_var: float = 0.5, generator=None):
     return action, log_prob
 
 
+def actor_layers(actor):
+    """The four ``nn.Linear`` of a policy module in forward order, or None.  Two structures are recognised by ATTRIBUTE NAME: the reference's own
+    ``Actor`` (``network.py:17-39``: ``layer1a``, ``layer2a``, ``layer3a``, ``outputa``) — so ``rollout(env, reference_actor)`` takes the fused
+    kernel like any other — and ``make_actor``'s (``hidden`` = three layers, ``out``)."""
+    names = ("layer1a", "layer2a", "layer3a", "outputa")
+    if all(hasattr(actor, n) for n in names):
+        return [getattr(actor, n) for n in names]
+    if hasattr(actor, "hidden") and hasattr(actor, "out") and len(list(actor.hidden)) == 3:
+        return list(actor.hidden) + [actor.out]
+    return None
+
+
+class OrnsteinUhlenbeckNoise:
+    """DDPG's exploration noise (``network.py:259-274``; added to the action at ``algorithm.py:258-259``) for a batch of envs on the device:
+    ``state += theta (mu - state) + sigma N(0, I)``; ``sample`` returns the state itself.  One independent process per env
+    (the reference has one env, hence one process); ``reset`` puts every state back to ``mu``.  Like the reference's it is NOT reset between
+    episodes unless the caller does so."""
+
+    def __init__(self, num_envs: int, action_dim: int, mu: float, theta: float, sigma: float, device=None, generator=None):
+        import torch
+
+        self.mu, self.theta, self.sigma = float(mu), float(theta), float(sigma)
+        self.generator = generator
+        self.state = torch.full((int(num_envs), int(action_dim)), self.mu, dtype=torch.float32, device=device)
+
+    def reset(self):
+        self.state.fill_(self.mu)
+
+    def sample(self):
+        import torch
+
+        eps = torch.randn(self.state.shape, dtype=self.state.dtype, device=self.state.device, generator=self.generator)
+        self.state += self.theta * (self.mu - self.state) + self.sigma * eps
+        return self.state
+
+
 # rollout()'s DeviceActor per actor module.  Kept here, NOT on the module: a DeviceActor holds the ctypes library handle, which can be
 # neither deep-copied (target networks) nor pickled (torch.save of the module).  Weak keys, and DeviceActor only holds a weak
 # reference back to its module, so neither keeps the other alive.
@@ -72,7 +108,7 @@ _DEVICE_ACTORS = weakref.WeakKeyDictionary()
 
 class DeviceActor:
     """The policy query (``Actor.forward`` + ``get_action``, network.py:48-69) as ONE library launch (``aog_actor_act``): the
-    weights of a torch module built by ``make_actor`` (or any module exposing ``hidden`` = three ``nn.Linear`` and ``out``)
+    weights of a torch module built by ``make_actor`` or of the reference's own ``Actor`` (``actor_layers``: recognised by attribute name)
     are read in place on every call, so a learner may keep updating them.  Dropout masks / Gaussian noise come from the
     library's Philox streams keyed by (seed, call counter, GLOBAL env id, layer, unit), not from torch's generator.  Keep ONE
     instance alive for the whole training run: its call counter is what makes every query draw fresh masks and noise
@@ -85,6 +121,9 @@ class DeviceActor:
         from . import _lib
 
         self._C, self._lib_mod = C, _lib
+        if actor_layers(actor) is None:
+            raise ValueError("DeviceActor: the module exposes neither layer1a / layer2a / layer3a / outputa (the reference's Actor, network.py:17-39) "
+                             "nor hidden (3 x nn.Linear) + out")
         self.lib = _lib.load()
         self._actor_ref = weakref.ref(actor)
         self.seed = int(seed)
@@ -104,7 +143,7 @@ class DeviceActor:
         import torch
 
         C, _lib = self._C, self._lib_mod
-        layers = list(self.actor.hidden) + [self.actor.out]
+        layers = actor_layers(self.actor)
         for layer in layers:
             if layer.weight.dtype != torch.float32 or not layer.weight.is_contiguous() or not layer.weight.is_cuda:
                 raise ValueError("DeviceActor needs contiguous float32 CUDA weights")
@@ -130,7 +169,7 @@ class DeviceActor:
 
 
 def rollout(env, actor, episodes: int = 1, cov_var: float = 0.5, gatherer=None, generator=None, actor_impl: str = "auto", seed: int = 0,
-            dev_actor=None, lookahead: bool = False):
+            dev_actor=None, lookahead: bool = False, policy: str = "actor", ou_noise=None):
     """Collect ``episodes`` lock-step episodes from ``env`` (a ``BatchedAOEnv``).
 
     ``actor_impl``: "hip" = the fused policy-query kernel (``DeviceActor``), "torch" = the module's own forward +
@@ -139,7 +178,14 @@ def rollout(env, actor, episodes: int = 1, cov_var: float = 0.5, gatherer=None, 
     module-level weak dictionary keyed by the actor: the caller's module stays deep-copyable and picklable) — a training loop that calls ``rollout`` once per iteration (algorithm.py:156) then explores with fresh
     dropout masks and noise in every iteration, like the reference's torch generator does.  Returns a dict of device tensors
     shaped ``[T*E, B, ...]`` (obs, act, log_prob, rew, next_obs, done), ``ep_returns`` ``[E, B_global]`` (gathered over ranks
-    when ``gatherer`` is distributed) and ``avg_ep_rew`` (the reference's logged scalar)."""
+    when ``gatherer`` is distributed), ``avg_ep_rew`` (the reference's logged scalar) and ``batch_lens`` (``algorithm.py:226,283``: a numpy
+    array of T*E zeros whose first E entries hold the length of each episode — always T here: ``done`` depends on the step counter only).
+
+    ``policy="shack"`` (``algorithm.py:252-253``, the 'SHACK' algorithm): the action of every step comes from ``env.SH_step()`` (the
+    Shack-Hartmann integrator on the device; needs an env built with ``SH_operation=True``), ``actor`` may be None and ``log_prob`` holds the
+    reference's constant 1.  ``ou_noise`` (``algorithm.py:258-259``, DDPG): an ``OrnsteinUhlenbeckNoise`` whose sample is added to every
+    action before the env sees it (and before it is stored, like the reference's in-place ``action +=``)."""
+    import numpy as np
     import torch
 
     from .sharding import EpisodeReturnGatherer
@@ -148,9 +194,15 @@ def rollout(env, actor, episodes: int = 1, cov_var: float = 0.5, gatherer=None, 
     B = env.num_envs
     if gatherer is None:
         gatherer = EpisodeReturnGatherer(B, env.device, False)
-    if actor_impl == "auto":
-        structured = hasattr(actor, "hidden") and hasattr(actor, "out") and len(list(actor.hidden)) == 3
-        actor_impl = "hip" if structured and next(actor.parameters()).is_cuda else "torch"
+    if policy not in ("actor", "shack"):
+        raise ValueError("policy must be 'actor' or 'shack'")
+    shack = policy == "shack"
+    if shack:
+        if not getattr(env, "SH_operation", False):
+            raise ValueError("policy='shack' needs an env created with SH_operation=True (AO_env.py:115-116, 254)")
+        actor_impl = "none"
+    elif actor_impl == "auto":
+        actor_impl = "hip" if actor_layers(actor) is not None and next(actor.parameters()).is_cuda else "torch"
     if actor_impl != "hip":
         dev_actor = None
     elif dev_actor is None:
@@ -179,18 +231,26 @@ def rollout(env, actor, episodes: int = 1, cov_var: float = 0.5, gatherer=None, 
             for _t in range(T):
                 if out is None:   # buffers are laid out once the shapes are known: [T*E, B, ...], written in place
                     S = obs.shape[1]
-                    A = int(list(actor.parameters())[-1].shape[0])   # width of the output layer's bias
+                    A = int(env.num_modes) if shack else int(list(actor.parameters())[-1].shape[0])   # width of the output layer's bias
                     dev = obs.device
                     out = {"obs": torch.empty((n, B, S), dtype=obs.dtype, device=dev), "act": torch.empty((n, B, A), dtype=torch.float32, device=dev),
                            "log_prob": torch.empty((n, B), dtype=torch.float32, device=dev), "rew": torch.empty((n, B), dtype=torch.float32, device=dev),
                            "next_obs": torch.empty((n, B, S), dtype=obs.dtype, device=dev), "done": torch.empty((n, B), dtype=torch.bool, device=dev)}
                     mean_buf = torch.empty((B, A), dtype=torch.float32, device=dev)
-                if dev_actor is not None:
+                if shack:
+                    sh_act, _ = env.SH_step()                       # (actuators [B, A] float64, the reference's constant log-probability 1)
+                    out["act"][i].copy_(sh_act)
+                    out["log_prob"][i].fill_(1.0)
+                    action = out["act"][i]
+                elif dev_actor is not None:
                     action, _, _ = dev_actor(obs, cov_var, out=(out["act"][i], out["log_prob"][i], mean_buf))
                 else:
                     action, log_prob = sample_action(actor(obs), cov_var, generator)
                     out["act"][i].copy_(action)
                     out["log_prob"][i].copy_(log_prob)
+                if ou_noise is not None:
+                    out["act"][i].add_(ou_noise.sample())           # algorithm.py:258-259
+                    action = out["act"][i]
                 if step_takes_out:   # the env writes the transition straight into this step's slices
                     next_obs = env.step(action, out=(out["next_obs"][i], out["rew"][i], out["done"][i]))[0]
                 else:
@@ -211,6 +271,9 @@ def rollout(env, actor, episodes: int = 1, cov_var: float = 0.5, gatherer=None, 
         env.lookahead(False)
     out["ep_returns"] = torch.stack(ep_returns)
     out["avg_ep_rew"] = float(out["ep_returns"].mean().item()) / T
+    lens = np.zeros(n)
+    lens[:episodes] = T
+    out["batch_lens"] = lens
     return out
 
 

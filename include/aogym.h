@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define AOG_ABI_VERSION 18
+#define AOG_ABI_VERSION 19
 
 typedef struct aog_env aog_env;
 
@@ -113,7 +113,7 @@ int aog_abi_version(void);
 const char* aog_build_id(void);
 const char* aog_last_error(void);
 /* sizeof() of the structs of this header as the library was compiled, so that a binding in another language can verify its own
- * declarations at load time: which = 0 aog_config, 1 aog_tables, 2 aog_layer_tables, 3 aog_sh_tables, 4 aog_actor, 5 aog_info;
+ * declarations at load time: which = 0 aog_config, 1 aog_tables, 2 aog_layer_tables, 3 aog_sh_tables, 4 aog_actor, 5 aog_info, 6 aog_layer_composite;
  * -1 for any other value. */
 int64_t aog_struct_size(int which);
 
@@ -148,6 +148,28 @@ typedef struct {
   double delta_t;                       /* 1e-3 s (AO_env.py:226)                                            */
 } aog_layer_tables;
 int aog_upload_layer(aog_env* env, const aog_layer_tables* layer);
+
+/* k_max successive one-pixel extrusions along one axis composed into ONE linear operator (exact: the same samples given the same normals;
+ * adaptive_optics_gym_amd/extrusion_host.py::compose_extrusions builds it from the tables above):
+ *     [R_1; ...; R_k] = A z_old + sqrt(Cn^2) B [n_1; ...; n_k],   R_j = the slice shift j of a step creates,
+ * z_old = the screen BEFORE the first shift at the union of every sample the k stencils reach.  With both axes uploaded (after
+ * aog_upload_layer, same k_max) aog_step advances a dynamic atmosphere with two matrix products per step on the int8 matrix cores
+ * (csrc/k_extrude_i8.h: operands in base-128 digits, exact int32 accumulation; new samples good to ~1e-9 rad) instead of the chain of
+ * one-pixel float64 rounds; operators for k < k_max are cut out of the uploaded one.  k_max must cover the largest whole-pixel shift any
+ * env makes per step (floor(max wind component * delta_t / pixel_pitch) + 1) and be <= 8; steps the operators do not cover, float64
+ * validation handles and AOG_EXTRUDE_F64 keep the float64 kernels.  HOST pointers. */
+typedef struct {
+  int32_t axis;             /* 0: vertical ('bottom' / 'top': new rows), 1: horizontal ('left' / 'right': new columns)             */
+  int32_t k_max;            /* shifts composed                                                                                    */
+  int32_t n_old;            /* U: size of the union stencil                                                                       */
+  int32_t reserved0;
+  const int32_t* old_yx;    /* [U] (sy << 16 | sx): logical position on the screen hcipy's _extrude sees, before the first shift   */
+  const double* A;          /* [k_max N][U]: row (j - 1) N + i = sample i of the slice shift j creates                            */
+  const double* B;          /* [k_max N][k_max N]: column (j' - 1) N + i' = normal i' of shift j' (without the sqrt(Cn^2) factor)  */
+} aog_layer_composite;
+int aog_upload_layer_composite(aog_env* env, const aog_layer_composite* op);
+enum { AOG_EXTRUDE_AUTO = 0, AOG_EXTRUDE_F64 = 1 };   /* AUTO: the int8 composite form whenever its operators cover the step        */
+int aog_set_extrusion_mode(aog_env* env, int mode);
 
 /* layer.velocity of every env: [B][2] float64 (vx, vy) in m/s (hcipy draws the direction at construction).
  * max_abs_component >= max over envs of max(|vx|, |vy|): bounds the whole-pixel shifts per step.

@@ -127,3 +127,92 @@ def test_device_actor_cache_leaves_the_module_copyable_and_picklable():
         raise AssertionError("expected RuntimeError")
     except RuntimeError:
         pass
+
+
+class ReferenceNamedActor(torch.nn.Module):
+    """A stand-in carrying the attribute names of the reference's Actor (network.py:17-39: layer1a, layer2a, layer3a, outputa, dropout); the
+    reference's own file cannot be imported here (its imports need gym), and only the names matter to ``actor_layers``."""
+
+    def __init__(self, s, a, h):
+        super().__init__()
+        self.layer1a, self.layer2a, self.layer3a = torch.nn.Linear(s, h), torch.nn.Linear(h, h), torch.nn.Linear(h, h)
+        self.outputa = torch.nn.Linear(h, a)
+        self.dropout = torch.nn.Dropout(0.5)
+
+    def forward(self, state):
+        x = state.to(torch.float32)
+        for layer in (self.layer1a, self.layer2a, self.layer3a):
+            x = self.dropout(torch.relu(layer(x)))
+        return self.outputa(x)
+
+
+def test_actor_layers_recognises_the_reference_actor_by_attribute_name():
+    from adaptive_optics_gym_amd.rollout import actor_layers
+
+    ref = ReferenceNamedActor(4, 6, 16)
+    assert [l is m for l, m in zip(actor_layers(ref), (ref.layer1a, ref.layer2a, ref.layer3a, ref.outputa))] == [True] * 4
+    mine = make_actor(4, 6, 16)
+    assert actor_layers(mine)[3] is mine.out and len(actor_layers(mine)) == 4
+    assert actor_layers(torch.nn.Linear(4, 6)) is None
+    out = rollout(FakeEnv(3, 4, 6, 4), ref, episodes=1)          # CPU module: the torch path, same result layout
+    assert out["act"].shape == (4, 3, 6)
+
+
+def test_rollout_returns_batch_lens_like_the_reference():
+    out = rollout(FakeEnv(2, 4, 6, 5), make_actor(4, 6, 8), episodes=3)
+    lens = out["batch_lens"]                     # algorithm.py:226,283: zeros(T * E) with the first E entries = episode lengths
+    assert lens.shape == (15,) and (lens[:3] == 5).all() and (lens[3:] == 0).all()
+
+
+class FakeShackEnv(FakeEnv):
+    SH_operation = True
+
+    def __init__(self, B, obs_n, A, T):
+        super().__init__(B, obs_n, A, T)
+        self.num_modes = A
+        self.sh_calls = 0
+
+    def SH_step(self):
+        self.sh_calls += 1
+        return torch.full((self.num_envs, self.A), 1e-7 * self.sh_calls, dtype=torch.float64), torch.tensor([1])
+
+
+def test_rollout_shack_policy_drives_sh_step():
+    env = FakeShackEnv(3, 25, 5, 4)
+    out = rollout(env, None, episodes=2, policy="shack")          # algorithm.py:252-253
+    assert env.sh_calls == 8 and out["act"].shape == (8, 3, 5)
+    torch.testing.assert_close(out["act"][:, 0, 0], torch.arange(1, 9, dtype=torch.float32) * 1e-7)
+    assert (out["log_prob"] == 1).all()
+    try:
+        rollout(FakeEnv(3, 4, 6, 4), None, policy="shack")
+        assert False, "an env without SH_operation must be refused"
+    except ValueError:
+        pass
+
+
+def test_ornstein_uhlenbeck_noise_update_rule_and_use_in_rollout():
+    from adaptive_optics_gym_amd.rollout import OrnsteinUhlenbeckNoise
+
+    g = torch.Generator().manual_seed(3)
+    ou = OrnsteinUhlenbeckNoise(4, 6, mu=0.1, theta=0.15, sigma=0.2, generator=g)
+    assert torch.equal(ou.state, torch.full((4, 6), 0.1))
+    g2 = torch.Generator().manual_seed(3)
+    x = torch.full((4, 6), 0.1)
+    for _ in range(3):                           # network.py:270-273: dx = theta (mu - x) + sigma randn; x += dx; return x
+        x = x + 0.15 * (0.1 - x) + 0.2 * torch.randn((4, 6), generator=g2)
+        torch.testing.assert_close(ou.sample(), x)
+    ou.reset()
+    assert torch.equal(ou.state, torch.full((4, 6), 0.1))
+    # in the rollout the sample is added to the action the env sees and to the stored action (algorithm.py:258-259)
+    torch.manual_seed(5)
+    actor = make_actor(4, 6, 8)
+    seen = []
+
+    class Spy(FakeEnv):
+        def step(self, a):
+            seen.append(a.clone())
+            return super().step(a)
+
+    ou = OrnsteinUhlenbeckNoise(4, 6, 0.0, 0.15, 0.2, generator=torch.Generator().manual_seed(7))
+    out = rollout(Spy(4, 4, 6, 3), actor, episodes=1, ou_noise=ou)
+    assert all(torch.equal(seen[t], out["act"][t]) for t in range(3))
