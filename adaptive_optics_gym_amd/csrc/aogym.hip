@@ -915,6 +915,13 @@ int aog_device_status(aog_env* e, int32_t* status_out) {
   int v[16];
   HIP_TRY(hipMemcpy(v, e->dev_status, sizeof v, hipMemcpyDeviceToHost));
   *status_out = v[0] | *static_cast<volatile int*>(e->host_flag);
+#ifdef AOG_DEV
+  if (getenv("AOG_X8_DEV") && (atoi(getenv("AOG_X8_DEV")) & 1024)) {
+    fprintf(stderr, "[aogym] k_x8_product: cycles per step max %d min %d, most steps %d, workgroups %d\n", v[8], v[9], v[10], v[11]);
+    const int init[4] = {0, 1 << 30, 0, 0};
+    HIP_TRY(hipMemcpy(e->dev_status + 8, init, sizeof init, hipMemcpyHostToDevice));
+  }
+#endif
   if (getenv("AOG_EXTRUDE_TIMING")) {   // developer aid: phase clocks (10 ns ticks) of workgroup 0 of k_extrude16_split
     if (v[1]) fprintf(stderr, "[aogym] extrude16_split WG0 ticks: gather %d noise %d compute %d (matrix passes %d, exchange %d) barrier %d rounds %d matrix passes run %d, shader clocks in them / 16: %d\n", v[4], v[5], v[6], v[9], v[10], v[7], v[8], v[11], v[12]);
     const int one = 1;

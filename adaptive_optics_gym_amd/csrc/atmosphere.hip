@@ -86,11 +86,15 @@ int x8_evolve(aog_env* e, hipStream_t s, long long step_index) {
   p.KsTot_max = e->x8_KsTot_max;
   p.rec = e->x8_rec;
   p.status = e->dev_status;
-  hipLaunchKernelGGL(aog::k_x8_plan, dim3(1), dim3(64), 0, s, p);
-  const dim3 gprep((e->B + aog::kX8PrepWaves - 1) / aog::kX8PrepWaves), gprod(e->x8_tiles64_max, (e->x8_rt_max + 1) / 2);
+#ifdef AOG_DEV
+  if (const char* v = getenv("AOG_X8_DEV")) p.dev = atoi(v);
+#endif
+  hipLaunchKernelGGL(aog::k_x8_plan, dim3(1), dim3(aog::kX8PlanThreads), 0, s, p);
+  const dim3 gprep(e->B), gprod(round_up((e->x8_rt_max + 1) / 2, 8), e->x8_tiles64_max);
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_x8_product), aog::kX8ProductLds, e->device)) return rc;
   for (int phase = 0; phase < 2; ++phase) {
-    hipLaunchKernelGGL(aog::k_x8_prepare, gprep, dim3(64 * aog::kX8PrepWaves), 0, s, p, phase);
-    hipLaunchKernelGGL(aog::k_x8_product, gprod, dim3(256), 0, s, p, phase);
+    hipLaunchKernelGGL(aog::k_x8_prepare, gprep, dim3(aog::kX8PrepThreads), 0, s, p, phase);
+    hipLaunchKernelGGL(aog::k_x8_product, gprod, dim3(512), aog::kX8ProductLds, s, p, phase);
   }
   HIP_TRY(hipGetLastError());
   return AOG_OK;
@@ -172,7 +176,10 @@ int evolve_layer(aog_env* e, hipStream_t s, long long step_index) {
     // int8 matrix-core form: the step's x shifts, then its y shifts, each as one exact fixed-point product (k_extrude_i8.h)
     if (int rc = x8_evolve(e, s, step_index)) return rc;
   } else if (e->ext_bar && !getenv("AOG_EXTRUDE_SIMPLE") && !getenv("AOG_EXTRUDE_NOSPLIT") && ext_split_lds(e) <= kLdsBytes) {
-    // float64 matrix-core form with each 16-env group's rows split over four workgroups + group barrier
+    // float64 matrix-core form with each 16-env group's rows split over four workgroups + group barrier.  Since round 4 this is the
+    // VALIDATION form (the int8 composite form above is the fast one), so its barrier runs the full agent-scope release / acquire protocol
+    // of MI355X_MICROARCH.md in every round; the same-XCD short form of round 3 (writer without the L2 write-back when the four partners
+    // measured that they share an XCD: 30 us per step faster, one intermittent mismatch in its history) is opt-in: AOG_EXTRUDE_SAME_XCD=1
     const size_t lds = ext_split_lds(e);
     auto kern = aog::k_extrude16_split<aog::kExtKs>;
     if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, e->device)) return rc;
@@ -197,7 +204,7 @@ int evolve_layer(aog_env* e, hipStream_t s, long long step_index) {
     for (int g0 = 0; g0 < groups8; g0 += groups_per_launch) {
       const int ng = std::min(groups_per_launch, groups8 - g0);
       hipLaunchKernelGGL(kern, dim3(ng * aog::kExtParts), dim3(256 * aog::kExtKs), lds, s, p, e->B, e->ext_perm, bar, e->dev_status,
-                         e->host_flag_dev, g0, e->ext_spin_limit, e->ext_absent_part, bar_next, getenv("AOG_EXTRUDE_AGENT_SCOPE") ? 1 : 0);
+                         e->host_flag_dev, g0, e->ext_spin_limit, e->ext_absent_part, bar_next, getenv("AOG_EXTRUDE_SAME_XCD") ? 0 : 1);
     }
     HIP_TRY(hipGetLastError());
   } else if (!getenv("AOG_EXTRUDE_SIMPLE") && ext16_lds(e) <= kLdsBytes) {
@@ -375,7 +382,8 @@ int aog_upload_layer_composite(aog_env* e, const aog_layer_composite* t) {
   if (e->x8_kmax[t->axis]) return fail(AOG_ERR_STATE, "aog_upload_layer_composite: axis %d already uploaded", t->axis);
   if (int rcp = refuse_pre_evolved(e, "aog_upload_layer_composite")) return rcp;
   const int N = e->cfg.n_pupil, K = t->k_max, U = t->n_old, Np = round_up(N, 64);
-  if (U > 64 * aog::kX8MaxChunks * 16) return fail(AOG_ERR_UNSUPPORTED, "aog_upload_layer_composite: union stencil of %d samples (at most %d built)", U, 64 * aog::kX8MaxChunks * 16);
+  if (U > aog::kX8PrepThreads * 16 || K * Np > aog::kX8PrepThreads * 16)
+    return fail(AOG_ERR_UNSUPPORTED, "aog_upload_layer_composite: union stencil of %d samples / %d normals per step (at most %d built)", U, K * Np, aog::kX8PrepThreads * 16);
   for (int c = 0; c < U; ++c)
     if ((t->old_yx[c] >> 16) < 0 || (t->old_yx[c] >> 16) >= N || (t->old_yx[c] & 0xffff) >= N) return fail(AOG_ERR_INVALID, "aog_upload_layer_composite: old_yx[%d] outside the screen", c);
   HIP_TRY(hipSetDevice(e->device));
@@ -409,9 +417,9 @@ int aog_upload_layer_composite(aog_env* e, const aog_layer_composite* t) {
       for (int c = 0; c < k * N; ++c) bmax = std::max(bmax, std::fabs(t->B[(size_t)r * K * N + c]) * e->sqrt_cn2);
     }
     if (!(amax > 0.0) || !(bmax > 0.0) || !std::isfinite(amax) || !std::isfinite(bmax)) return fail(AOG_ERR_INVALID, "aog_upload_layer_composite: empty or non-finite operator");
-    const int log2_qa = std::ilogb(amax) + 1 - 34, log2_qb = std::ilogb(bmax) + 1 - 27;   // |A| / qa < 2^34 (5 digits), |B| / qb < 2^27 (4 digits)
+    const int log2_qa = std::ilogb(amax) + 1 - 34, log2_qb = std::ilogb(bmax) + 1 - 34;   // |A| / qa, |B| / qb < 2^34 (5 digits each)
     std::vector<int32_t> yx((size_t)KsA * 32);
-    std::vector<int8_t> A8((size_t)RT * KsA * 5 * 1024, 0), B8((size_t)RT * KsB * 4 * 1024, 0);
+    std::vector<int8_t> A8((size_t)RT * KsA * 5 * 1024, 0), B8((size_t)RT * KsB * 5 * 1024, 0);
     std::vector<double> r1((size_t)RT * 32, 0.0), r2((size_t)RT * 32, 0.0);
     double sx = 0.0, sxx = 0.0;
     std::vector<double> xa((size_t)Uk);
@@ -444,10 +452,10 @@ int aog_upload_layer_composite(aog_env* e, const aog_layer_composite* t) {
             const double b = brow[(size_t)(jj - 1) * N + ii] * e->sqrt_cn2;
             if (b == 0.0) continue;
             const int cc = (jj - 1) * Np + ii;
-            int8_t d[4];
-            x8_digits_host(std::llrint(std::ldexp(b, -log2_qb)), 4, d);
-            const size_t base = (((size_t)rt * KsB + (cc >> 5)) * 4) * 1024 + (size_t)((row & 31) + 32 * ((cc & 31) >> 4)) * 16 + (cc & 15);
-            for (int dg = 0; dg < 4; ++dg) B8[base + (size_t)dg * 1024] = d[dg];
+            int8_t d[5];
+            x8_digits_host(std::llrint(std::ldexp(b, -log2_qb)), 5, d);
+            const size_t base = (((size_t)rt * KsB + (cc >> 5)) * 5) * 1024 + (size_t)((row & 31) + 32 * ((cc & 31) >> 4)) * 16 + (cc & 15);
+            for (int dg = 0; dg < 5; ++dg) B8[base + (size_t)dg * 1024] = d[dg];
           }
       }
     aog::X8Table& tb = h->tab[t->axis][k];
@@ -463,7 +471,7 @@ int aog_upload_layer_composite(aog_env* e, const aog_layer_composite* t) {
     tb.yx = d_yx; tb.A8 = d_A8; tb.B8 = d_B8; tb.r1 = d_r1; tb.r2 = d_r2;
     tb.k = k; tb.U = Uk; tb.KsA = KsA; tb.KsB = KsB; tb.RT = RT; tb.Np = Np;
     tb.log2_qa = log2_qa;
-    tb.log2_cn = log2_qa + 7 - log2_qb;
+    tb.log2_cn = log2_qa - log2_qb;
     tb.ez_floor = 3 - tb.log2_cn;
     tb.sx = sx;
     tb.sxx = sxx;
@@ -548,7 +556,10 @@ int aog_selftest_barrier_timeout(aog_env* e, void* stream) {
   e->ext_spin_limit = 1u << 10;
   e->ext_absent_part = 1;
   e->timestep += 1;
+  const int mode = e->ext_mode;
+  e->ext_mode = AOG_EXTRUDE_F64;   // (the barrier lives in the float64 round kernel: the int8 form has none)
   const int rc = evolve_layer(e, s, e->timestep);
+  e->ext_mode = mode;
   e->ext_spin_limit = 1u << 24;
   e->ext_absent_part = -1;
   if (rc != AOG_OK) return rc;

@@ -11,10 +11,11 @@
 // phase error (measured on the host: profiles/HISTORY.md), so new samples must be good to ~1e-8 rad of ~10: fp32 accumulation cannot do
 // that.  Integer accumulation can: every operand is written in balanced base-128 digits (int8),
 //     A_k = qa sum_s As 128^(4-s)   (5 digits, quantum qa = 2^(ea-34)),      z - c0 - c1 x = qz sum_t Zt 128^(4-t)   (5 digits, qz per env)
-//     sqrt(Cn^2) B_k = qb sum_s Bs 128^(3-s)   (4 digits),                     n = qn sum_t Nt 128^(4-t)               (5 digits)
+//     sqrt(Cn^2) B_k = qb sum_s Bs 128^(4-s)   (5 digits),                     n = qn sum_t Nt 128^(4-t)               (5 digits)
 // and v_mfma_i32_32x32x32_i8 sums the digit products EXACTLY in int32 (|digit product| <= 2^12, <= 2^26.5 per accumulator over the whole
-// contraction).  Products of equal weight 128^(8-l), l = s + t, share one accumulator; levels l <= 4 are kept (15 digit pairs for A z, 14
-// for B n: what is dropped is below 2^-35 of |A||z|).  With qn = qa qz 128 / qb per env the noise product lands on the same levels.  The
+// contraction).  Products of equal weight 128^(8-l), l = s + t, share one accumulator; levels l <= 5 are kept (19 of the 25 digit pairs: with
+// l <= 4 the dropped level-5 terms, 5e-9 rad per new sample at N = 256, were ten times the quantisation floor; so was a 4-digit B: both
+// measured on the host, profiles/HISTORY.md).  With qn = qa qz / qb per env the noise product lands on the same levels.  The
 // only rounding anywhere is the quantisation of the operands (A to 2^-34 of its largest coefficient, z to 2^-34 of the env's largest
 // detrended stencil sample): ~1e-9 rad per new sample at N = 256.  Piston and tilt of the stencil never enter the fixed-point product:
 // A z = c0 (A 1) + c1 (A x) + A (z - c0 - c1 x) with the two vectors A 1 and A x exact in float64 — a quantisation error of A multiplied by
@@ -24,26 +25,32 @@
 #pragma once
 #include "k_common.h"
 
+// developer experiments (timing ablations that break the results) exist only in -DAOG_DEV builds
+#ifdef AOG_DEV
+#define AOG_X8_DEV(p) ((p).dev)
+#else
+#define AOG_X8_DEV(p) 0
+#endif
+
 namespace aog {
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kX8DigA = 5, kX8DigZ = 5, kX8DigB = 4, kX8DigN = 5;
-constexpr int kX8Levels = 5;        // product levels l = s + t kept: 0 .. 4
+constexpr int kX8Levels = 6;        // product levels l = s + t kept: 0 .. 5 (19 of the 25 digit pairs)
 constexpr int kX8MaxK = 8;          // composite operators are built for k = 1 .. kcap <= 8 shifts per axis and step
 
 // one composite operator (axis, k) in device memory
 struct X8Table {
   const int32_t* yx;      // [U_pad] union stencil (sy << 16 | sx) on the screen hcipy's _extrude sees (rotated for 'top' / 'right'); padding repeats entry 0
   const int8_t* A8;       // [RT][KsA][5][64][16] digits of A_k as MFMA A operands: lane (row & 31, k-half g), byte b <-> column 32 ks + 16 g + b
-  const int8_t* B8;       // [RT][KsB][4][64][16] digits of sqrt(Cn^2) B_k
+  const int8_t* B8;       // [RT][KsB][5][64][16] digits of sqrt(Cn^2) B_k
   const double* r1;       // [RT * 32] A_k 1   (float64, exact piston response)
   const double* r2;       // [RT * 32] A_k x   (x = along-coordinate of the stencil sample - (N - 1) / 2)
   int k, U, KsA, KsB, RT; // U union size; k-steps (of 32) of the stencil and of the normals; row tiles (of 32 rows) = k Np / 32
   int Np;                 // rows per shift block: N rounded up to 64 (row (j - 1) Np + i = sample i of the slice shift j creates; i >= N: zero rows)
   int log2_qa;            // qa = 2^log2_qa
-  int log2_cn;            // qn = qz * 2^log2_cn  (= qa 128 / qb)
+  int log2_cn;            // qn = qz * 2^log2_cn  (= qa / qb)
   int ez_floor;           // smallest exponent of an env's stencil range: qz = 2^(ez - 34), ez >= ez_floor keeps |n| / qn inside 5 digits
   double sx, sxx;         // sum x, sum x^2 over the U stencil samples (detrending)
 };
@@ -72,19 +79,25 @@ struct X8Args {
   // prepared operands
   int8_t* Z8;                // [tiles32_max][KsTot_max][5][64][16]
   int KsTot_max;
-  double* rec;               // [slots_max][4]: scale (qa qz 128^4), c0, c1, unused
+  double* rec;               // [slots_max][4]: scale (qa qz 128^3), c0, c1, origin of the screen the phase reads
+  int dev;                   // AOG_DEV builds only (AOG_X8_DEV in the environment): 1 no matrix instructions, 2 no operand loads, 4 no result stores, 16 .. 128 prepare-kernel stages off, 1024 cycles per step read-out
   int* status;               // sticky error word (bit 2: a stencil sample or a normal left its fixed-point range)
 };
 
-// ---- plan: shifts of every env this step, envs grouped by shift count into 64-env tiles (one wave) ---------------------------------
-__global__ __launch_bounds__(64) void k_x8_plan(X8Args p) {
-  const int lane = threadIdx.x;
-  __shared__ int cnt[2][kX8MaxK + 1], base[2][kX8MaxK + 1];
-  if (lane < 2 * (kX8MaxK + 1)) (&cnt[0][0])[lane] = 0;
+// ---- plan: shifts of every env this step, envs grouped by shift count into 64-env tiles (one workgroup) -----------------------------------
+constexpr int kX8PlanThreads = 1024;
+__global__ __launch_bounds__(kX8PlanThreads) void k_x8_plan(X8Args p) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NW = kX8PlanThreads / 64, NC = kX8MaxK + 1;
+  __shared__ int wcnt[2][NC][NW];      // per wave and class: envs of this pass
+  __shared__ int base[2][NC];          // slots handed out so far per class
+  __shared__ int total[2][NC];
+  if (tid < 2 * NC) { (&base[0][0])[tid] = 0; (&total[0][0])[tid] = 0; }
+  for (int i = tid; i < 2 * p.slots_max; i += kX8PlanThreads) p.list[i] = -1;
   __syncthreads();
-  // pass 1: shifts and class counts
-  for (int e0 = 0; e0 < p.B; e0 += 64) {
-    const int e = e0 + lane;
+  // pass A: shifts and class totals (tile bases need the totals of every class before any slot can be handed out)
+  for (int e0 = 0; e0 < p.B; e0 += kX8PlanThreads) {
+    const int e = e0 + tid;
     int kx = 0, ky = 0;
     if (e < p.B) {
       const double vx = p.velocity[2 * e], vy = p.velocity[2 * e + 1];
@@ -102,42 +115,51 @@ __global__ __launch_bounds__(64) void k_x8_plan(X8Args p) {
       }
     }
     for (int k = 1; k <= p.kcap; ++k) {
-      const unsigned long long mx = __ballot(e < p.B && kx == k), my = __ballot(e < p.B && ky == k);
+      const unsigned long long mx = __ballot(kx == k), my = __ballot(ky == k);
       if (lane == 0) {
-        cnt[0][k] += __popcll(mx);
-        cnt[1][k] += __popcll(my);
+        if (mx) atomicAdd(&total[0][k], __popcll(mx));
+        if (my) atomicAdd(&total[1][k], __popcll(my));
       }
     }
   }
   __syncthreads();
-  if (lane < 2) {   // tile bases per class (in 64-env tiles), tile -> k
+  if (tid < 2) {   // tile bases per class (in 64-env tiles), tile -> k
     int t = 0;
     for (int k = 1; k <= p.kcap; ++k) {
-      base[lane][k] = t * 64;
-      const int nt = (cnt[lane][k] + 63) / 64;
-      for (int i = 0; i < nt; ++i) p.tile_k[lane * p.tiles64_max + t + i] = k;
+      base[tid][k] = t * 64;
+      const int nt = (total[tid][k] + 63) / 64;
+      for (int i = 0; i < nt; ++i) p.tile_k[tid * p.tiles64_max + t + i] = k;
       t += nt;
     }
-    for (; t < p.tiles64_max; ++t) p.tile_k[lane * p.tiles64_max + t] = 0;
+    for (; t < p.tiles64_max; ++t) p.tile_k[tid * p.tiles64_max + t] = 0;
   }
-  for (int i = lane; i < 2 * p.slots_max; i += 64) p.list[i] = -1;
   __syncthreads();
-  // pass 2: slots in env order within each class (deterministic, though nothing depends on it)
-  for (int e0 = 0; e0 < p.B; e0 += 64) {
-    const int e = e0 + lane;
+  // pass B: slots in env order within each class (deterministic, though no result depends on it)
+  for (int e0 = 0; e0 < p.B; e0 += kX8PlanThreads) {
+    const int e = e0 + tid;
     const int kx = e < p.B ? min(abs(p.dxy[2 * e]), p.kcap) : 0, ky = e < p.B ? min(abs(p.dxy[2 * e + 1]), p.kcap) : 0;
-    int sx = -1, sy = -1;
+    const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    int rx = 0, ry = 0;
     for (int k = 1; k <= p.kcap; ++k) {
       const unsigned long long mx = __ballot(kx == k), my = __ballot(ky == k);
-      const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
-      if (kx == k) sx = base[0][k] + __popcll(mx & below);
-      if (ky == k) sy = base[1][k] + __popcll(my & below);
-      __syncthreads();
+      if (kx == k) rx = __popcll(mx & below);
+      if (ky == k) ry = __popcll(my & below);
       if (lane == 0) {
-        base[0][k] += __popcll(mx);
-        base[1][k] += __popcll(my);
+        wcnt[0][k][wave] = __popcll(mx);
+        wcnt[1][k][wave] = __popcll(my);
       }
-      __syncthreads();
+    }
+    __syncthreads();
+    int sx = -1, sy = -1;
+    if (kx) {
+      int b = base[0][kx];
+      for (int w = 0; w < wave; ++w) b += wcnt[0][kx][w];
+      sx = b + rx;
+    }
+    if (ky) {
+      int b = base[1][ky];
+      for (int w = 0; w < wave; ++w) b += wcnt[1][ky][w];
+      sy = b + ry;
     }
     if (e < p.B) {
       p.slot[e] = sx;
@@ -145,201 +167,199 @@ __global__ __launch_bounds__(64) void k_x8_plan(X8Args p) {
       if (sx >= 0) p.list[sx] = e;
       if (sy >= 0) p.list[p.slots_max + sy] = e;
     }
+    __syncthreads();
+    if (tid < 2 * NC) {
+      const int ph = tid / NC, k = tid % NC;
+      int add = 0;
+      for (int w = 0; w < NW; ++w) add += wcnt[ph][k][w];
+      base[ph][k] += add;
+    }
+    __syncthreads();
   }
 }
 
-// balanced base-128 digits of x (|x| < 2^34 + 2^27), most significant first; ND of them
-template <int ND>
-__device__ __forceinline__ void x8_digits(long long x, int (&d)[ND]) {
-#pragma unroll
-  for (int t = ND - 1; t > 0; --t) {
-    const int dg = (int)((x + 64) & 127) - 64;
-    d[t] = dg;
-    x = (x - dg) >> 7;
-  }
-  d[0] = (int)x;   // whatever is left: within int8 for arguments in range (checked by the caller)
+// balanced base-128 digits of the integer-valued x (|x| <= 2^34), most significant first.  x = hi 2^21 + lo with |lo| <= 2^20, both int32:
+// three float64 operations, the rest 32-bit integer arithmetic.  Any digits in [-128, 127] that sum to x are as good as any other (the
+// product is exact); these stay within [-65, 64].
+__device__ __forceinline__ void x8_digits5(double x, int (&d)[5]) {
+  const double h = rint(x * (1.0 / 2097152.0));
+  int lo = (int)fma(h, -2097152.0, x), hi = (int)h;
+  d[4] = ((lo + 64) & 127) - 64;
+  lo = (lo - d[4]) >> 7;
+  d[3] = ((lo + 64) & 127) - 64;
+  d[2] = (lo - d[3]) >> 7;
+  d[1] = ((hi + 64) & 127) - 64;
+  d[0] = (hi - d[1]) >> 7;
 }
 
-__device__ __forceinline__ double x8_wave_sum(double v) {   // same association order whatever the data: results are reproducible
+// ---- prepare: one workgroup per env.  Gather the union stencil, detrend, choose the env's quantum, write the digits of z and of the
+// normals in the product's B-operand order; phase 1 also commits the step's origin and stream position. ------------------------------------
+constexpr int kX8PrepThreads = 256;
+__device__ __forceinline__ double x8_block_sum(double v, double* sm) {   // fixed association order: reproducible
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (sm[0] + sm[1]) + (sm[2] + sm[3]);
 }
-__device__ __forceinline__ double x8_wave_max(double v) {
+__device__ __forceinline__ double x8_block_max(double v, double* sm) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
-  return v;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
 }
 
-// ---- prepare: one wave per env.  Gather the union stencil, detrend, choose the env's quantum, write digits of z and of the normals in the
-// product's B-operand order; phase 1 also commits the step's origin and stream position. -------------------------------------------------
-constexpr int kX8PrepWaves = 4;
-constexpr int kX8MaxChunks = 3;   // 16-sample chunks per lane: union stencils of up to 64 * 3 * 16 = 3072 samples
-__global__ __launch_bounds__(64 * kX8PrepWaves) void k_x8_prepare(X8Args p, int phase) {
-  const int lane = threadIdx.x & 63;
-  const int env = blockIdx.x * kX8PrepWaves + (threadIdx.x >> 6);
-  if (env >= p.B) return;
+__global__ __launch_bounds__(kX8PrepThreads) void k_x8_prepare(X8Args p, int phase) {
+  __shared__ double sm[4];
+  const int tid = threadIdx.x;
+  const int env = blockIdx.x;
   const int N = p.N;
   const int dx = p.dxy[2 * env], dy = p.dxy[2 * env + 1];
   const int d = phase == 0 ? dx : dy, k = min(abs(d), p.kcap);
   int ox = p.origin[2 * env], oy = p.origin[2 * env + 1];
-  if (phase == 1) {   // the x shifts of this step have been applied
-    ox = ((ox + dx) % N + N) % N;
+  if (phase == 1) ox = ((ox + dx) % N + N) % N;   // the x shifts of this step have been applied
+  const uint32_t ext_old = p.ext_counter[env];
+  __syncthreads();   // (every thread has read the origin and the stream position before thread 0 commits the step below)
+  if (phase == 1 && tid == 0) {   // commit the step: the products read origins from `rec`, nothing reads these before the step's last launch has run
+    p.origin[2 * env] = ox;
+    p.origin[2 * env + 1] = ((oy + dy) % N + N) % N;
+    p.ext_counter[env] = ext_old + (uint32_t)(min(abs(dx), p.kcap) + min(abs(dy), p.kcap));
   }
-  if (k > 0) {
-    const X8Table& tb = p.tables[(phase == 0 ? 1 : 0) * (kX8MaxK + 1) + k];   // x shifts use the horizontal ('left') operator
-    const bool vertical = phase == 1, flipped = d > 0;
-    const int slot = p.slot[phase * p.B + env];
-    const int tile = slot >> 5, col = slot & 31;
-    const double* master = p.master + (size_t)env * N * N;
-    const int nchunk = tb.KsA * 2;   // 16-sample chunks of the (padded) union stencil
-    double v[kX8MaxChunks][16];
-    double s0 = 0.0, s1 = 0.0;
-    const double mid = 0.5 * (double)(N - 1);
+  if (k == 0) return;
+  const X8Table& tb = p.tables[(phase == 0 ? 1 : 0) * (kX8MaxK + 1) + k];   // x shifts use the horizontal ('left') operator
+  const bool vertical = phase == 1, flipped = d > 0;
+  const int slot = p.slot[phase * p.B + env];
+  const int tile = slot >> 5, col = slot & 31;
+  const double* master = p.master + (size_t)env * N * N;
+  const int nchunk = tb.KsA * 2, nchunk_n = tb.KsB * 2;   // 16-sample chunks of the (padded) union stencil / of the normals
+  const double mid = 0.5 * (double)(N - 1);
+  const int r0 = phase == 1 ? min(abs(dx), p.kcap) : 0;   // index of this phase's first shift among the step's shifts (stream position, replay buffer)
+
+  // stencil chunks: thread t takes chunks t, t + 256, ... (at most kX8ZChunks of them)
+  constexpr int kZC = 1;   // 256 threads x 16 samples = 4096 >= every union stencil built (aog_upload_layer_composite checks)
+  double v[kZC][16], xs[kZC][16];
+  double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-    for (int cc = 0; cc < kX8MaxChunks; ++cc) {
-      const int c = lane + 64 * cc;
+  for (int cc = 0; cc < kZC; ++cc) {
+    const int c = tid + kX8PrepThreads * cc;
 #pragma unroll
-      for (int b = 0; b < 16; ++b) v[cc][b] = 0.0;
-      if (c < nchunk) {
-        const i32x4* yq = reinterpret_cast<const i32x4*>(tb.yx + 16 * c);
+    for (int b = 0; b < 16; ++b) { v[cc][b] = 0.0; xs[cc][b] = 0.0; }
+    if (c < nchunk) {
+      const i32x4* yq = reinterpret_cast<const i32x4*>(tb.yx + 16 * c);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const i32x4 y4 = yq[q];
+      for (int q = 0; q < 4; ++q) {
+        const i32x4 y4 = yq[q];
 #pragma unroll
-          for (int b = 0; b < 4; ++b) {
-            const int kk = 16 * c + 4 * q + b;
-            int sy = y4[b] >> 16, sx = y4[b] & 0xffff;
-            const double xa = (double)(vertical ? sx : sy) - mid;
-            if (flipped) { sy = N - 1 - sy; sx = N - 1 - sx; }
-            int py = sy + oy, px = sx + ox;
-            if (py >= N) py -= N;
-            if (px >= N) px -= N;
-            const double val = kk < tb.U ? master[(size_t)py * N + px] : 0.0;
-            v[cc][4 * q + b] = val;
-            s0 += val;
-            s1 += kk < tb.U ? val * xa : 0.0;
-          }
+        for (int b = 0; b < 4; ++b) {
+          const int kk = 16 * c + 4 * q + b;
+          int sy = y4[b] >> 16, sx = y4[b] & 0xffff;
+          const double xa = (double)(vertical ? sx : sy) - mid;
+          if (flipped) { sy = N - 1 - sy; sx = N - 1 - sx; }
+          int py = sy + oy, px = sx + ox;
+          if (py >= N) py -= N;
+          if (px >= N) px -= N;
+          const bool in = kk < tb.U;
+          const double val = (in && !(AOG_X8_DEV(p) & 64)) ? master[(size_t)py * N + px] : 0.0;
+          v[cc][4 * q + b] = val;
+          xs[cc][4 * q + b] = in ? xa : 0.0;
+          s0 += val;
+          s1 += in ? val * xa : 0.0;
         }
       }
     }
-    s0 = x8_wave_sum(s0);
-    s1 = x8_wave_sum(s1);
-    const double U = (double)tb.U;
-    const double c1 = (s1 - s0 * tb.sx / U) / (tb.sxx - tb.sx * tb.sx / U);
-    const double c0 = s0 / U - c1 * tb.sx / U;
-    double m = 0.0;
+  }
+  // normals of this thread's chunks (independent of the stencil: drawn while the gathers are in flight)
+  constexpr int kNC = 1;   // 256 x 16 = 4096 >= k Np for every operator built (k <= 8, Np <= 512)
+  double nv[kNC][16];
 #pragma unroll
-    for (int cc = 0; cc < kX8MaxChunks; ++cc) {
-      const int c = lane + 64 * cc;
-      if (c < nchunk) {
-        const i32x4* yq = reinterpret_cast<const i32x4*>(tb.yx + 16 * c);
+  for (int cc = 0; cc < kNC; ++cc) {
+    const int c = (kX8PrepThreads - 1 - tid) + kX8PrepThreads * cc;   // dealt from the last thread down: the stencil's chunks start at thread 0
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const i32x4 y4 = yq[q];
-#pragma unroll
-          for (int b = 0; b < 4; ++b) {
-            const int kk = 16 * c + 4 * q + b;
-            const double xa = (double)(vertical ? (y4[b] & 0xffff) : (y4[b] >> 16)) - mid;
-            const double zp = kk < tb.U ? v[cc][4 * q + b] - c0 - c1 * xa : 0.0;
-            v[cc][4 * q + b] = zp;
-            m = fmax(m, fabs(zp));
-          }
-        }
-      }
-    }
-    m = x8_wave_max(m);
-    const int ez = max(tb.ez_floor, m > 0.0 ? ilogb(m) + 1 : tb.ez_floor);   // 2^ez > every |zp|
-    const double inv_qz = ldexp(1.0, 34 - ez);
-    const size_t tile_base = (size_t)tile * p.KsTot_max;
-    bool range_ok = isfinite(m);
-    // digits of the detrended stencil
-#pragma unroll
-    for (int cc = 0; cc < kX8MaxChunks; ++cc) {
-      const int c = lane + 64 * cc;
-      if (c < nchunk) {
-        uint32_t w[kX8DigZ][4];
-#pragma unroll
-        for (int t = 0; t < kX8DigZ; ++t)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) w[t][q] = 0u;
-#pragma unroll
-        for (int b = 0; b < 16; ++b) {
-          int dg[kX8DigZ];
-          x8_digits<kX8DigZ>((long long)rint(v[cc][b] * inv_qz), dg);
-#pragma unroll
-          for (int t = 0; t < kX8DigZ; ++t) w[t][b >> 2] |= (uint32_t)(dg[t] & 0xff) << (8 * (b & 3));
-        }
-        const int ks = c >> 1, g = c & 1;
-#pragma unroll
-        for (int t = 0; t < kX8DigZ; ++t) {
-          u32x4 o = {w[t][0], w[t][1], w[t][2], w[t][3]};
-          *reinterpret_cast<u32x4*>(p.Z8 + ((((tile_base + ks) * kX8DigZ + t) * 64 + (g * 32 + col)) << 4)) = o;
-        }
-      }
-    }
-    // digits of the normals: shift j' = 1 .. k, sample i' < N at contraction index (j' - 1) Np + i'
-    const double inv_qn = ldexp(1.0, 34 - ez - tb.log2_cn);
-    const uint32_t ext0 = p.ext_counter[env] + (phase == 1 ? (uint32_t)min(abs(dx), p.kcap) : 0u);
-    const int r0 = phase == 1 ? min(abs(dx), p.kcap) : 0;   // index of this phase's first shift among the step's shifts (replay buffer)
-    const int nchunk_n = tb.KsB * 2;
-    for (int c = lane; c < nchunk_n; c += 64) {
+    for (int b = 0; b < 16; ++b) nv[cc][b] = 0.0;
+    if (c < nchunk_n) {
       const int jj = (16 * c) / tb.Np, i0 = 16 * c - jj * tb.Np;   // shift jj + 1, samples i0 .. i0 + 15 (Np is a multiple of 64: no straddle)
-      uint32_t w[kX8DigN][4];
-#pragma unroll
-      for (int t = 0; t < kX8DigN; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) w[t][q] = 0u;
       if (i0 < N) {
+        const bool replay = p.noise && (r0 + jj) < p.max_ext;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           double n4[4];
-          const bool replay = p.noise && (r0 + jj) < p.max_ext;
           if (replay) {
 #pragma unroll
             for (int b = 0; b < 4; ++b) n4[b] = (i0 + 4 * q + b) < N ? p.noise[((size_t)env * p.max_ext + (r0 + jj)) * N + i0 + 4 * q + b] : 0.0;
+          } else if (!(AOG_X8_DEV(p) & 128)) {
+            philox_normal4(p.seed, (uint32_t)(p.env_base + env), ext_old + (uint32_t)(r0 + jj), (uint32_t)((i0 >> 2) + q), n4);
           } else {
-            philox_normal4(p.seed, (uint32_t)(p.env_base + env), ext0 + (uint32_t)jj, (uint32_t)((i0 >> 2) + q), n4);
+            n4[0] = n4[1] = n4[2] = n4[3] = 0.5;
           }
 #pragma unroll
-          for (int b = 0; b < 4; ++b) {
-            const double nv = (i0 + 4 * q + b) < N ? n4[b] : 0.0;
-            const double ni = rint(nv * inv_qn);
-            range_ok = range_ok && fabs(ni) < 17314086912.0;   // 2^34 + 2^27
-            int dg[kX8DigN];
-            x8_digits<kX8DigN>((long long)ni, dg);
-#pragma unroll
-            for (int t = 0; t < kX8DigN; ++t) w[t][q] |= (uint32_t)(dg[t] & 0xff) << (8 * b);
-          }
+          for (int b = 0; b < 4; ++b) nv[cc][4 * q + b] = (i0 + 4 * q + b) < N ? n4[b] : 0.0;
         }
       }
-      const int ks = tb.KsA + (c >> 1), g = c & 1;
-#pragma unroll
-      for (int t = 0; t < kX8DigN; ++t) {
-        u32x4 o = {w[t][0], w[t][1], w[t][2], w[t][3]};
-        *reinterpret_cast<u32x4*>(p.Z8 + ((((tile_base + ks) * kX8DigN + t) * 64 + (g * 32 + col)) << 4)) = o;
-      }
-    }
-    if (!__all(range_ok)) {
-      if (lane == 0) atomicOr(p.status, 4);
-    }
-    if (lane == 0) {
-      double* rc = p.rec + (size_t)slot * 4;
-      rc[0] = ldexp(1.0, tb.log2_qa + (ez - 34) + 28);   // qa qz 128^4
-      rc[1] = c0;
-      rc[2] = c1;
-      rc[3] = __hiloint2double(oy, ox);                  // origin of the screen this phase reads: (oy in the high word, ox in the low)
     }
   }
-  if (phase == 1 && lane == 0) {   // commit the step: the products read origins from `rec`, nothing reads these until the step's last launch has run
-    p.origin[2 * env] = ox;
-    p.origin[2 * env + 1] = ((oy + dy) % N + N) % N;
-    p.ext_counter[env] += (uint32_t)(min(abs(dx), p.kcap) + min(abs(dy), p.kcap));
+  s0 = x8_block_sum(s0, sm);
+  s1 = x8_block_sum(s1, sm);
+  const double U = (double)tb.U;
+  const double c1 = (s1 - s0 * tb.sx / U) / (tb.sxx - tb.sx * tb.sx / U);
+  const double c0 = s0 / U - c1 * tb.sx / U;
+  double m = 0.0;
+#pragma unroll
+  for (int cc = 0; cc < kZC; ++cc)
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+      const int kk = 16 * (tid + kX8PrepThreads * cc) + b;
+      const double zp = kk < tb.U ? v[cc][b] - c0 - c1 * xs[cc][b] : 0.0;
+      v[cc][b] = zp;
+      m = fmax(m, fabs(zp));
+    }
+  m = x8_block_max(m, sm);
+  const int ez = max(tb.ez_floor, m > 0.0 ? ilogb(m) + 1 : tb.ez_floor);   // 2^ez > every |zp|
+  const double inv_qz = ldexp(1.0, 34 - ez), inv_qn = ldexp(1.0, 34 - ez - tb.log2_cn);
+  const size_t tile_base = (size_t)tile * p.KsTot_max;
+  bool range_ok = isfinite(m);
+  auto put = [&](const double (&x)[16], double inv_q, int ks, int g) {
+    uint32_t w[5][4];
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) w[t][q] = 0u;
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+      const double xi = rint(x[b] * inv_q);
+      range_ok = range_ok && fabs(xi) <= 17179869184.0;   // 2^34
+      int dg[5] = {0, 0, 0, 0, (int)x[b]};
+      if (!(AOG_X8_DEV(p) & 32)) x8_digits5(xi, dg);
+#pragma unroll
+      for (int t = 0; t < 5; ++t) w[t][b >> 2] |= (uint32_t)(dg[t] & 0xff) << (8 * (b & 3));
+    }
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+      u32x4 o = {w[t][0], w[t][1], w[t][2], w[t][3]};
+      if (!(AOG_X8_DEV(p) & 16) || o[0] == 0x12345678u) *reinterpret_cast<u32x4*>(p.Z8 + ((((tile_base + ks) * 5 + t) * 64 + (g * 32 + col)) << 4)) = o;
+    }
+  };
+#pragma unroll
+  for (int cc = 0; cc < kZC; ++cc) {
+    const int c = tid + kX8PrepThreads * cc;
+    if (c < nchunk) put(v[cc], inv_qz, c >> 1, c & 1);
+  }
+#pragma unroll
+  for (int cc = 0; cc < kNC; ++cc) {
+    const int c = (kX8PrepThreads - 1 - tid) + kX8PrepThreads * cc;
+    if (c < nchunk_n) put(nv[cc], inv_qn, tb.KsA + (c >> 1), c & 1);
+  }
+  if (!range_ok) atomicOr(p.status, 4);
+  if (tid == 0) {
+    double* rc = p.rec + (size_t)slot * 4;
+    rc[0] = ldexp(1.0, tb.log2_qa + (ez - 34) + 21);   // qa qz 128^3: level l of the product carries 128^(8 - l), l = 0 .. 5
+    rc[1] = c0;
+    rc[2] = c1;
+    rc[3] = __hiloint2double(oy, ox);                  // origin of the screen this phase reads (oy in the high word, ox in the low)
   }
 }
-
-// ---- product: workgroup = 64 rows x 64 envs (four waves, 2 x 2 tiles of 32 x 32), digits of both operands staged through LDS ---------
-constexpr int kX8Blocks = 20;   // 1-KiB operand blocks per k-step: 2 row tiles x 5 digits + 2 env tiles x 5 digits
 
 __device__ __forceinline__ void x8_store(const X8Args& p, int env, int N, int py, int px, double v) {
   p.master[(size_t)env * N * N + (size_t)py * N + px] = v;
@@ -352,120 +372,185 @@ __device__ __forceinline__ void x8_store(const X8Args& p, int env, int N, int py
   }
 }
 
-__global__ __launch_bounds__(256, 2) void k_x8_product(X8Args p, int phase) {
-  __shared__ __attribute__((aligned(16))) int8_t lds[2][kX8Blocks * 1024];
-  const int tile64 = blockIdx.x;
+// ---- product: workgroup = 64 rows x 64 envs = 2 x 2 tiles of 32 x 32.  FOUR CONSUMER waves (one per tile and SIMD: 19 digit products per
+// 32-deep step into six int32 accumulators, the next step's operands read from LDS while this step's matrix instructions run) and FOUR LOADER
+// waves (one per SIMD: the 20 one-KiB operand blocks of a step — 2 row tiles x 5 digits + 2 env tiles x 5 — go global -> LDS by LDS-DMA into a
+// ring of kX8Stages stages, kX8Stages - 1 steps ahead; counted vmcnt waits).  One raw s_barrier per step hands a landed stage to the consumers
+// and a drained one back to the loaders.  Heaviest workgroups (most shifts, last shift block) are dispatched first.
+// How it got here (B = 1024, N = 256, v = 10 m/s: ~290 workgroups on 256 CUs, i.e. ONE wave-tile per SIMD — nothing to hide latency behind;
+// profiles/HISTORY.md): with each wave loading, reading and multiplying in turn a step took ~1100-1500 cycles against 608 of matrix
+// instructions (LDS-DMA issue ~60-100 cycles apiece, the 40-80 KB burst of LDS reads behind the barrier, then the matrix work, in series), a
+// deeper ring or cache-hot operands changed nothing, and splitting a tile's products by level over two waves of a SIMD only doubled the LDS reads.
+constexpr int kX8Blocks = 20;
+constexpr int kX8Stages = 5;   // an LDS-DMA lands ~1.1 us after its issue (MI355X_MICROARCH.md, ldsdma-fill): four steps of lead
+constexpr int kX8ProductLds = kX8Stages * kX8Blocks * 1024;   // (the epilogue's 32 KB transposition area lives in the ring)
+
+__global__ __launch_bounds__(512, 2) void k_x8_product(X8Args p, int phase) {
+  extern __shared__ __attribute__((aligned(1024))) int8_t lds8[];   // kX8ProductLds bytes
+  // grid.x = row pairs (a multiple of 8: workgroups that read the same table rows share an XCD and its L2 under round-robin dispatch — speed
+  // only), grid.y = 64-env tiles; both reversed: classes of more shifts sit in later tiles and later row pairs run more steps
+  const int tile64 = (int)gridDim.y - 1 - (int)blockIdx.y;
   const int k = p.tile_k[phase * p.tiles64_max + tile64];
   if (k == 0) return;
   const X8Table& tb = p.tables[(phase == 0 ? 1 : 0) * (kX8MaxK + 1) + k];
-  const int rt0 = 2 * blockIdx.y;
+  const int rt0 = 2 * ((int)gridDim.x - 1 - (int)blockIdx.x);
   if (rt0 >= tb.RT) return;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int rtl = wave & 1, ctl = wave >> 1;
-  const int N = p.N;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;   // (scalar: everything selected by it is wave-uniform)
+  const int tile = wave & 3;
+  const bool loader = wave >= 4;
+  const int rtl = tile & 1, ctl = tile >> 1;
+  const int N = p.N, KsA = tb.KsA, KsB = tb.KsB;
   const int shift = rt0 / (tb.Np / 32);                         // both row tiles lie in shift block `shift` + 1 (Np / 32 is even)
-  const int ksB_end = (shift + 1) * (tb.Np / 32);               // normals of later shifts do not reach these rows
-  const int n_steps = tb.KsA + ksB_end;
-  const size_t zt0 = (size_t)(2 * tile64) * p.KsTot_max, zt1 = (size_t)(2 * tile64 + 1) * p.KsTot_max;
+  const int n_steps = KsA + (shift + 1) * (tb.Np / 32);         // normals of later shifts do not reach these rows
 
-  // the 1-KiB block `blk` of step `st`: A-part st < KsA: blocks 0..9 = A digits of the two row tiles, 10..19 = Z digits of the two env tiles;
-  // B-part: blocks 0..7 = B digits (4 per row tile), 10..19 = N digits
-  auto block_ptr = [&](int st, int blk) -> const int8_t* {
-    if (blk >= 10) {
-      const int h = (blk - 10) / 5, dgt = (blk - 10) % 5;
-      return p.Z8 + ((((h ? zt1 : zt0) + st) * 5 + dgt) << 10);
-    }
-    if (st < tb.KsA) {
-      const int h = blk / 5, dgt = blk % 5;
-      return tb.A8 + ((((size_t)(rt0 + h) * tb.KsA + st) * kX8DigA + dgt) << 10);
-    }
-    const int h = blk >> 2, dgt = blk & 3;   // blocks 8, 9 unused in the B-part
-    return tb.B8 + ((((size_t)(rt0 + h) * tb.KsB + (st - tb.KsA)) * kX8DigB + dgt) << 10);
-  };
-  // wave w stages blocks w, w + 4, ... of a step (one contiguous KiB per wave instruction)
-  i32x4 stage[5];
-  auto load_step = [&](int st) {
+  if (loader) {
+    const int8_t* A8 = tb.A8;
+    const int8_t* B8 = tb.B8;
+    const int8_t* Z0 = p.Z8 + (((size_t)(2 * tile64) * p.KsTot_max * 5) << 10);
+    const int8_t* Z1 = p.Z8 + (((size_t)(2 * tile64 + 1) * p.KsTot_max * 5) << 10);
+    // block `blk` of step `st`: 0..9 = digits of the two row tiles of A_k (st < KsA) or of sqrt(Cn^2) B_k, 10..19 = digits of the two env tiles;
+    // loader w moves blocks w, w + 4, ..., w + 16
+    auto issue = [&](int st, int buf) {
+      st = min(st, n_steps - 1);   // (past the end: a harmless re-load into a free stage keeps the vmcnt arithmetic uniform)
 #pragma unroll
-    for (int r = 0; r < 5; ++r) {
-      const int blk = 4 * r + wave;
-      const bool used = st < tb.KsA || blk < 8 || blk >= 10;
-      stage[r] = used ? *reinterpret_cast<const i32x4*>(block_ptr(st, blk) + (lane << 4)) : i32x4{0, 0, 0, 0};
-    }
-  };
-  auto store_step = [&](int buf) {
+      for (int r = 0; r < 5; ++r) {
+        const int blk = 4 * r + tile, h = blk >= 10 ? (blk - 10) / 5 : blk / 5, dgt = blk % 5;
+        const int8_t* src;
+        if (blk >= 10) src = (h ? Z1 : Z0) + (((size_t)st * 5 + dgt) << 10);
+        else if (st < KsA) src = A8 + ((((size_t)(rt0 + h) * KsA + st) * 5 + dgt) << 10);
+        else src = B8 + ((((size_t)(rt0 + h) * KsB + (st - KsA)) * 5 + dgt) << 10);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (lane << 4)),
+                                         (__attribute__((address_space(3))) void*)(&lds8[(buf * kX8Blocks + blk) * 1024]), 16, 0, 0);
+      }
+    };
 #pragma unroll
-    for (int r = 0; r < 5; ++r) *reinterpret_cast<i32x4*>(&lds[buf][(4 * r + wave) * 1024 + (lane << 4)]) = stage[r];
-  };
+    for (int q = 0; q < kX8Stages; ++q) issue(q, q);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * (kX8Stages - 1)) : "memory");   // stage 0 has landed
+    __builtin_amdgcn_s_barrier();
+    int buf = 0;
+    for (int st = 0; st < n_steps; ++st) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * (kX8Stages - 2)) : "memory");   // this loader's blocks of step st + 1 have landed
+      __builtin_amdgcn_s_barrier();   // the consumers hold step st's operands in registers: its stage is free
+      asm volatile("" ::: "memory");
+      if (!(AOG_X8_DEV(p) & 2)) issue(st + kX8Stages, buf);
+      buf = buf + 1 == kX8Stages ? 0 : buf + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the re-loads past the end)
+    __syncthreads();                                     // (the consumers' epilogue reuses the ring)
+    return;
+  }
 
   i32x16 acc[kX8Levels];
 #pragma unroll
   for (int l = 0; l < kX8Levels; ++l)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[l][r] = 0;
-
-  load_step(0);
-  store_step(0);
-  __syncthreads();
-  for (int st = 0; st < n_steps; ++st) {
-    const int buf = st & 1;
-    if (st + 1 < n_steps) load_step(st + 1);
-    i32x4 a[5], z[5];
-    const bool apart = st < tb.KsA;
+  i32x4 a[5], z[5], an[5], zn[5];
+  auto read_ops = [&](int buf, i32x4 (&ao)[5], i32x4 (&zo)[5]) {
+    const int8_t* sb = &lds8[buf * kX8Blocks * 1024];
 #pragma unroll
-    for (int dgt = 0; dgt < 5; ++dgt) z[dgt] = *reinterpret_cast<const i32x4*>(&lds[buf][(10 + ctl * 5 + dgt) * 1024 + (lane << 4)]);
-    if (apart) {
-#pragma unroll
-      for (int dgt = 0; dgt < 5; ++dgt) a[dgt] = *reinterpret_cast<const i32x4*>(&lds[buf][(rtl * 5 + dgt) * 1024 + (lane << 4)]);
-#pragma unroll
-      for (int s = 0; s < kX8DigA; ++s)
-#pragma unroll
-        for (int t = 0; t < kX8DigZ; ++t)
-          if (s + t < kX8Levels) acc[s + t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], z[t], acc[s + t], 0, 0, 0);
-    } else {
-#pragma unroll
-      for (int dgt = 0; dgt < 4; ++dgt) a[dgt] = *reinterpret_cast<const i32x4*>(&lds[buf][(rtl * 4 + dgt) * 1024 + (lane << 4)]);
-#pragma unroll
-      for (int s = 0; s < kX8DigB; ++s)
-#pragma unroll
-        for (int t = 0; t < kX8DigN; ++t)
-          if (s + t < kX8Levels) acc[s + t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], z[t], acc[s + t], 0, 0, 0);
+    for (int dgt = 0; dgt < 5; ++dgt) {
+      ao[dgt] = *reinterpret_cast<const i32x4*>(sb + (rtl * 5 + dgt) * 1024 + (lane << 4));
+      zo[dgt] = *reinterpret_cast<const i32x4*>(sb + (10 + ctl * 5 + dgt) * 1024 + (lane << 4));
     }
-    if (st + 1 < n_steps) store_step(buf ^ 1);
-    __syncthreads();
+  };
+  __builtin_amdgcn_s_barrier();   // stage 0 is in LDS
+  asm volatile("" ::: "memory");
+  read_ops(0, a, z);
+  int bufn = 1;
+  // one step: wait for this step's operands (read a step ago: the stage they came from is then free), meet the loaders (step st + 1's stage has
+  // landed), issue the reads of the NEXT step's operands, then this step's 19 matrix instructions: the reads return while they run
+  auto step = [&](i32x4 (&ac)[5], i32x4 (&zc)[5], i32x4 (&ax)[5], i32x4 (&zx)[5]) {
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) (as a builtin: the compiler's own wait insertion then knows the counter is drained)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // the ten LDS reads of the next step's operands ride in the shadow of this step's first matrix instructions (an MFMA holds the issue
+    // port 8 of its 32 cycles): issued ahead of them they cost ~160 cycles of every step (one read too many at the very end: a landed stage)
+    const int8_t* sb = &lds8[bufn * kX8Blocks * 1024];
+    int q = 0;
+#pragma unroll
+    for (int l = 0; l < kX8Levels; ++l)
+#pragma unroll
+      for (int s = 0; s <= l; ++s)
+        if (s < 5 && l - s < 5) {
+          if (!(AOG_X8_DEV(p) & 1)) acc[l] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ac[s], zc[l - s], acc[l], 0, 0, 0);
+          if (q < 5) ax[q] = *reinterpret_cast<const i32x4*>(sb + (rtl * 5 + q) * 1024 + (lane << 4));
+          else if (q < 10) zx[q - 5] = *reinterpret_cast<const i32x4*>(sb + (10 + ctl * 5 + q - 5) * 1024 + (lane << 4));
+          ++q;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+    if (AOG_X8_DEV(p) & 1) acc[0][0] += ac[0][0] + zc[4][3] + ac[4][1] + zc[0][2];
+    bufn = bufn + 1 == kX8Stages ? 0 : bufn + 1;
+  };
+  const long long t_loop0 = (AOG_X8_DEV(p) & 1024) ? (long long)__builtin_amdgcn_s_memtime() : 0;
+  int st = 0;
+  for (; st + 1 < n_steps; st += 2) {   // operand sets ping-pong (no register copies)
+    step(a, z, an, zn);
+    step(an, zn, a, z);
   }
+  if (st < n_steps) step(a, z, an, zn);
+  if ((AOG_X8_DEV(p) & 1024) && wave == 0 && lane == 0) {   // developer read-out: cycles per step of the slowest and of the fastest workgroup, steps of the longest
+    const int cyc = (int)(((long long)__builtin_amdgcn_s_memtime() - t_loop0) / n_steps);
+    atomicMax(p.status + 8, cyc);
+    atomicMin(p.status + 9, cyc);
+    atomicMax(p.status + 10, n_steps);
+    atomicAdd(p.status + 11, 1);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();   // every wave is done with the ring: its memory serves the epilogue
 
-  // epilogue: fixed point -> float64, add the exact piston / tilt response, scatter into the toroidal master (and its fp32 ring copy)
+  // epilogue: fixed point -> float64 (sum_l acc_l 128^(5 - l): every term exact, the sum rounded at 2^-53), add the exact piston / tilt response,
+  // scatter into the toroidal master (and its fp32 ring copy)
   const int slot = (2 * tile64 + ctl) * 32 + (lane & 31);
   const int env = p.list[phase * p.slots_max + slot];
-  if (env < 0) return;
-  const double* rc = p.rec + (size_t)slot * 4;
-  const double scale = rc[0], c0 = rc[1], c1 = rc[2];
-  const int oy = __double2hiint(rc[3]), ox = __double2loint(rc[3]);
-  const int d = p.dxy[2 * env + phase];
-  const bool flipped = d > 0, vertical = phase == 1;
+  const bool vertical = phase == 1;
   const int j = shift + 1;   // these rows are the slice shift j creates
   const int row_base = (rt0 + rtl) * 32;
+  const double* rc = p.rec + (size_t)slot * 4;
+  const double scale = env >= 0 ? rc[0] : 0.0, c0 = env >= 0 ? rc[1] : 0.0, c1 = env >= 0 ? rc[2] : 0.0;
+  const int oy = env >= 0 ? __double2hiint(rc[3]) : 0, ox = env >= 0 ? __double2loint(rc[3]) : 0;
+  const bool flipped_h = env >= 0 && p.dxy[2 * env] > 0;
+  int pxh = flipped_h ? ox + j - 1 : ox - j;   // (new columns: every sample of this env and shift goes to this column)
+  pxh = ((pxh % N) + N) % N;
+  // new rows: the 32 samples of a tile row-block are consecutive in memory for each env: they are transposed through LDS (XOR-swizzled 32 x 32
+  // float64 image: conflict-free both ways) so that a store instruction writes two envs x 32 consecutive samples (2 x 256 bytes of the master,
+  // 2 x 128 of the ring) instead of 64 samples of 32 different envs.  New columns: sample i of an env goes to row (i + oy) of its screen, one
+  // 8-byte store per row whatever the order: stored as they come.
+  double* mt = reinterpret_cast<double*>(lds8) + (size_t)tile * 32 * 32;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int row = row_base + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    const int i = row - shift * tb.Np;
-    if (i >= N) continue;
-    // sum_l acc_l 128^(4 - l): exact in float64 up to its last bit (|acc| < 2^27)
+    const int rr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), row = row_base + rr;
     double f = (double)acc[0][r];
 #pragma unroll
     for (int l = 1; l < kX8Levels; ++l) f = f * 128.0 + (double)acc[l][r];
-    const double val = f * scale + c0 * tb.r1[row] + c1 * tb.r2[row];   // scale = qa qz 128^4: level l carries 128^(8 - l)
-    int py, px;
+    const double val = f * scale + c0 * tb.r1[row] + c1 * tb.r2[row];
     if (vertical) {
-      py = flipped ? oy + j - 1 : oy - j;
-      px = (flipped ? N - 1 - i : i) + ox;
+      mt[(lane & 31) * 32 + (rr ^ (lane & 31))] = val;
     } else {
-      px = flipped ? ox + j - 1 : ox - j;
-      py = (flipped ? N - 1 - i : i) + oy;
+      const int i = row - shift * tb.Np;
+      if (env < 0 || i >= N || (AOG_X8_DEV(p) & 4)) continue;
+      int py = (flipped_h ? N - 1 - i : i) + oy;
+      if (py >= N) py -= N;
+      x8_store(p, env, N, py, pxh, val);
     }
+  }
+  if (!vertical || (AOG_X8_DEV(p) & 4)) return;
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const int i = row_base + (lane & 31) - shift * tb.Np;
+  for (int e2 = 0; e2 < 16; ++e2) {
+    const int c = 2 * e2 + (lane >> 5);
+    const int sl = (2 * tile64 + ctl) * 32 + c;
+    const int en = p.list[p.slots_max + sl];
+    if (en < 0 || i >= N) continue;
+    const double* rc2 = p.rec + (size_t)sl * 4;
+    const int oy2 = __double2hiint(rc2[3]), ox2 = __double2loint(rc2[3]);
+    const bool flipped = p.dxy[2 * en + 1] > 0;
+    int py = flipped ? oy2 + j - 1 : oy2 - j;
     py = ((py % N) + N) % N;
-    px = ((px % N) + N) % N;
-    x8_store(p, env, N, py, px, val);
+    int px = (flipped ? N - 1 - i : i) + ox2;
+    if (px >= N) px -= N;
+    x8_store(p, en, N, py, px, mt[c * 32 + ((lane & 31) ^ c)]);
   }
 }
 

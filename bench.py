@@ -194,6 +194,12 @@ def cpu_baseline(w, budget_s=8.0):
 
     modes = {"1proc_1thread": one, "1proc_default_threads": dflt, "default_threads": int(dthreads), f"{share}procs_1thread": shr}
     modes[f"{allp}procs_1thread"] = allc
+    # BASELINE.md section 4 / configs[0] (the reference's own CPU-runnable case): 1 env, quasi_static, zernike act_dim = 6, obs_dim = 2,
+    # strehl_ratio, 30-step episodes, at N = 128 and at the reference's N = 240 — 1 process, 1 BLAS thread, a few seconds each
+    c1 = dict(w, act_type="zernike", act_dim=6, obs_dim=2, rew_type="strehl_ratio", timesteps_per_episode=30, atm_fried=0.20)
+    for n_c1 in (128, 240):
+        rate, _, n_done = _run_cpu_workers(dict(c1, n_pupil=n_c1), 1, 1, max(2.0, budget_s / 2))
+        modes[f"configs0_n{n_c1}_1proc_1thread"] = rate
     return {"value": allc, "unit": "env-steps/s", "cores": int(allp), "kind": "port", "modes": modes,
             "cpu_model": _cpu_model(), "os_cpu_count": int(total), "usable_cores": int(usable), "share_cores": int(share), "numpy": np.__version__,
             "sample": f"single-env steps of the float64 numpy restatement of the literal HCIPy dataflow (not HCIPy itself) at N={w['n_pupil']}, "

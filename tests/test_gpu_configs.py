@@ -141,6 +141,7 @@ def test_config4_dynamic_rollout_shard_sampled_envs_vs_oracle():
         _assert_obs_close(env.last_obs_raw[b].double().cpu().numpy(), refs[b].last_obs_raw)
     gen = torch.Generator("cuda").manual_seed(99)
     moved = 0
+    screen_err = {}
     for t in range(T):
         a, _, _ = dev_actor(obs, 0.5)
         shifts = integer_shifts(env.velocity_vectors, env.timestep * env.delta_t, (env.timestep + 1) * env.delta_t, env.params.pupil_pixel)
@@ -158,12 +159,19 @@ def test_config4_dynamic_rollout_shard_sampled_envs_vs_oracle():
             moved += int(not np.array_equal(before, refs[b].layer._achromatic_screen))
             _check_step(info, rew, done, refs[b], r_rew, r_done, r_info, b, True)
             if t in (0, T - 1):
+                # screens: the int8 composite extrusion is good to ~1e-9 rad per new sample, ~1e-7 rad after an episode's ~200 shifts (the
+                # float64 round kernels, extrusion='f64', agree with the oracle to 1e-9 relative: tests/test_gpu_parity.py); held to 1e-6 rad,
+                # a tenth of what the 1e-5 bound on the observations could tolerate, and reported
                 scr = env.get_screens(b, 1)[0].cpu().numpy().ravel()
-                np.testing.assert_allclose(scr, refs[b].layer._achromatic_screen, rtol=1e-9, atol=1e-12 * np.abs(before).max())
+                err = float(np.abs(scr - refs[b].layer._achromatic_screen).max()) / 1.5e-6
+                screen_err[t] = max(screen_err.get(t, 0.0), err)
+                assert err < 1e-6, f"step {t}, env {b}: screen error {err:.2e} rad"
         assert float(info["strehl"].min()) >= 0 and float(info["strehl"].max()) <= 1 and bool(torch.isfinite(info["obs_raw"]).all())
         assert bool(done.all()) == (t == T - 1)
     assert moved == 3 * T
     assert env.device_status() == 0
+    print(f"config 4, int8 extrusion vs the oracle's float64 recursion: screen error {screen_err[0]:.2e} rad after step 1, "
+          f"{screen_err[T - 1]:.2e} rad after step {T}")
     # episode 2: the rollout harness on the device Philox stream
     prev = env.get_screens(0, 8).cpu().numpy()
     sh = sum(integer_shifts(env.velocity_vectors[:8], (env.timestep + k) * env.delta_t, (env.timestep + k + 1) * env.delta_t, env.params.pupil_pixel)

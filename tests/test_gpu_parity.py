@@ -755,9 +755,9 @@ def test_batched_focal_images_in_several_chunks(monkeypatch):
 
 @pytest.mark.parametrize("N,vel", [(32, 35.0), (128, 20.0)])
 def test_dynamic_extrusion_kernel_variants_agree(monkeypatch, N, vel):
-    """The extrusion kernels — float64 matrix-core form with a group's rows split over four workgroups and a group barrier (default; at N = 128
-    its clamp-free fast form, at N = 32 the masked one; AOG_EXTRUDE_AGENT_SCOPE: agent-scope fences in every round of the group barrier
-    instead of the same-XCD form the group measured it may use: bit-identical), the same in one
+    """The float64 extrusion kernels (``extrusion='f64'``: the validation forms since round 4) — matrix-core form with a group's rows split over
+    four workgroups and a group barrier (at N = 128 its clamp-free fast form, at N = 32 the masked one; AOG_EXTRUDE_SAME_XCD: the writer-side
+    short form of the group barrier for groups that measured that they share an XCD, instead of agent-scope fences in every round: bit-identical), the same in one
     workgroup per group (AOG_EXTRUDE_NOSPLIT), per-group vector form (AOG_EXTRUDE_SIMPLE) — give the same screens on
     the same Philox stream (only the float64 summation order differs; the two matrix-core forms agree to 1e-12), no inter-workgroup
     wait timed out; and the step kernel reading the fp32 ring copy directly (default) gives the observations of the per-step repack
@@ -766,12 +766,12 @@ def test_dynamic_extrusion_kernel_variants_agree(monkeypatch, N, vel):
     from adaptive_optics_gym_amd import BatchedAOEnv
 
     def run(mode):
-        for k in ("AOG_EXTRUDE_SIMPLE", "AOG_EXTRUDE_NOSPLIT", "AOG_EXTRUDE_AGENT_SCOPE", "AOG_DYNAMIC_REPACK"):
+        for k in ("AOG_EXTRUDE_SIMPLE", "AOG_EXTRUDE_NOSPLIT", "AOG_EXTRUDE_SAME_XCD", "AOG_DYNAMIC_REPACK"):
             monkeypatch.delenv(k, raising=False)
         if mode:
             monkeypatch.setenv(mode, "1")
         env = BatchedAOEnv(70, "cuda:0", atm_type="dynamic", atm_vel=vel, atm_fried=0.15, act_dim=6, act_type="zernike", obs_dim=2,
-                           num_pupil_pixels=N, timesteps_per_episode=100, seed=11, screen_oversampling=4, verbose=False)
+                           num_pupil_pixels=N, timesteps_per_episode=100, seed=11, screen_oversampling=4, verbose=False, extrusion="f64")
         assert env.info.reserved == (0 if mode == "AOG_DYNAMIC_REPACK" else 1)      # ring-direct unless asked otherwise
         env.reset()
         a = torch.ones(70, 6, device="cuda")
@@ -785,7 +785,7 @@ def test_dynamic_extrusion_kernel_variants_agree(monkeypatch, N, vel):
 
     s_simple, o_simple, ph_simple, f_simple = run("AOG_EXTRUDE_SIMPLE")
     s_split = None
-    for mode in (None, "AOG_EXTRUDE_AGENT_SCOPE", "AOG_EXTRUDE_NOSPLIT", "AOG_DYNAMIC_REPACK"):
+    for mode in (None, "AOG_EXTRUDE_SAME_XCD", "AOG_EXTRUDE_NOSPLIT", "AOG_DYNAMIC_REPACK"):
         s_other, o_other, ph_other, f_other = run(mode)
         np.testing.assert_allclose(s_other, s_simple, rtol=1e-9, atol=1e-12 * np.abs(s_simple).max())
         _assert_obs_close(o_other, o_simple)
@@ -796,7 +796,7 @@ def test_dynamic_extrusion_kernel_variants_agree(monkeypatch, N, vel):
         np.testing.assert_allclose(np.abs(f_other), np.abs(f_simple), rtol=0, atol=1e-5 * np.abs(f_simple).max())   # (global phase = piston)
         if mode is None:
             s_split = s_other
-        elif mode == "AOG_EXTRUDE_AGENT_SCOPE":
+        elif mode == "AOG_EXTRUDE_SAME_XCD":
             assert np.array_equal(s_other, s_split)      # the same arithmetic behind a different fence: bit for bit
         elif mode == "AOG_EXTRUDE_NOSPLIT":
             np.testing.assert_allclose(s_other, s_split, rtol=1e-11, atol=1e-13 * np.abs(s_split).max())

@@ -319,3 +319,90 @@ def test_large_poisson_and_tikhonov():
     assert np.all(out == np.round(out))
     M = np.random.RandomState(1).randn(7, 4)
     np.testing.assert_allclose(H.inverse_tikhonov(M, 1e-12), np.linalg.pinv(M), rtol=1e-8, atol=1e-10)
+
+
+def test_lp_modes_are_orthonormal_and_fiber_power_ignores_length():
+    """StepIndexFiber (AO_env.py:393, 471-474): at V = 2.639 three guided modes (LP01, LP11 cos, LP11 sin), each with sum(mode^2 w) = 1 on the
+    128^2 focal grid and mutually orthogonal (by symmetry), so that ``forward(wf).total_power`` = sum |c_k|^2 — the propagation phases
+    exp(i beta_k L) are unit-modulus factors on orthogonal modes and cannot change it: the power is the same for any fiber length."""
+    grid = H.make_pupil_grid(128, 52.5e-6)
+    fiber = H.StepIndexFiber(4.5e-6, 0.14, 10.0)
+    M = fiber.modes_for(grid, 1.5e-6)
+    assert M.shape == (128 * 128, 3)
+    gram = M.T @ (M * grid.weights)
+    np.testing.assert_allclose(np.diag(gram), 1.0, rtol=1e-12)
+    assert np.abs(gram - np.diag(np.diag(gram))).max() < 1e-12
+    rng = np.random.RandomState(0)
+    field = rng.randn(128 * 128) + 1j * rng.randn(128 * 128)
+    wf = H.Wavefront(field, 1.5e-6, grid)
+    c = M.T @ (field * grid.weights)
+    p_forward = fiber.forward(wf).total_power
+    np.testing.assert_allclose(p_forward, np.sum(np.abs(c) ** 2), rtol=1e-12)
+    # with explicit propagation phases of arbitrary lengths the power of sum_k c_k e^{i beta_k L} mode_k is unchanged
+    for betas in ([0.0, 0.0, 0.0], [1.234e6, 1.231e6, 1.231e6], [7.0, -3.0, 11.0]):
+        for L in (0.0, 10.0, 123.456):
+            out = M @ (c * np.exp(1j * np.asarray(betas) * L))
+            np.testing.assert_allclose(np.sum(np.abs(out) ** 2 * grid.weights), p_forward, rtol=1e-12)
+    assert H.StepIndexFiber(4.5e-6, 0.14, 1e-3).forward(wf).total_power == p_forward
+
+
+def test_large_poisson_switches_at_the_threshold_and_draws_in_hcipy_order():
+    """hcipy.util.large_poisson (AO_env.py:274 through the noiseless detector's read-out): strictly above ``thresh`` the rounded normal
+    approximation, at or below it an exact Poisson draw; the normals of ALL large entries are drawn first (one ``normal(size=n_large)`` call),
+    then one ``poisson`` call for the small ones — what the single-env drop-in's host-noise path replays."""
+
+    class Spy:
+        def __init__(self):
+            self.calls = []
+
+        def normal(self, size):
+            self.calls.append(("normal", int(size)))
+            return np.full(size, 2.0)
+
+        def poisson(self, lam, size):
+            self.calls.append(("poisson", int(size)))
+            return np.asarray(lam).astype(int) + 7
+
+    lam = np.array([3.0, 1e6, 1e6 + 1, 4e6, 0.0])
+    spy = Spy()
+    out = H.large_poisson(lam, rng=spy)
+    assert spy.calls == [("normal", 2), ("poisson", 3)]
+    np.testing.assert_array_equal(out, [10.0, 1e6 + 7, np.round(1e6 + 1 + 2 * np.sqrt(1e6 + 1)), 4e6 + 4000.0, 7.0])
+    assert H.large_poisson(np.array([50.0]), thresh=10.0, rng=spy)[0] == np.round(50.0 + 2.0 * np.sqrt(50.0))
+
+
+def test_inverse_tikhonov_rcond_is_relative_to_the_largest_singular_value():
+    """hcipy inverse_tikhonov(M, rcond) (AO_env.py:464-465, rcond = 1e-3): filter s / (s^2 + (rcond s_max)^2) on every singular value — damping,
+    not truncation, and relative to s_max (not an absolute threshold)."""
+    U, _ = np.linalg.qr(np.random.RandomState(0).randn(6, 6))
+    V, _ = np.linalg.qr(np.random.RandomState(1).randn(4, 4))
+    s = np.array([10.0, 1.0, 1e-2, 1e-5])
+    M = U[:, :4] @ np.diag(s) @ V.T
+    for rcond in (1e-3, 0.5):
+        inv = H.inverse_tikhonov(M, rcond)
+        expect = V @ np.diag(s / (s ** 2 + (rcond * 10.0) ** 2)) @ U[:, :4].T
+        np.testing.assert_allclose(inv, expect, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(H.inverse_tikhonov(3.0 * M, 1e-3), H.inverse_tikhonov(M, 1e-3) / 3.0, rtol=1e-9)   # scale-covariant: relative rcond
+    # s = rcond s_max is damped to exactly half of its plain inverse; far above it the plain inverse survives
+    inv = H.inverse_tikhonov(np.diag([1.0, 1e-3]), 1e-3)
+    np.testing.assert_allclose(np.diag(inv), [1.0 / (1.0 + 1e-6), 0.5e3], rtol=1e-12)
+
+
+def test_shack_hartmann_estimator_measures_from_the_lenslet_centre():
+    """ShackHartmannWavefrontSensorEstimator.estimate (AO_env.py:418-425, 277): centre of gravity of each selected lenslet's pixels in the
+    IMAGE grid's coordinates, minus that lenslet's position (``mla_points``), x row first; unselected lenslets are not reported."""
+    grid = H.make_pupil_grid(8, 8.0)                 # pixel centres at -3.5 .. 3.5
+    pts = np.array([[-2.0, -2.0], [2.0, -2.0], [-2.0, 2.0], [2.0, 2.0]])      # four lenslets of 4 x 4 pixels
+    ix = (grid.x > 0).astype(int) + 2 * (grid.y > 0).astype(int)
+    est = H.ShackHartmannWavefrontSensorEstimator(pts, ix, grid, estimation_subapertures=np.array([1, 0, 1, 1]))
+    img = np.zeros(64)
+    img[np.flatnonzero((grid.x == -1.5) & (grid.y == -2.5))] = 5.0            # lenslet 0: one spot at (-1.5, -2.5)
+    img[np.flatnonzero((grid.x == -3.5) & (grid.y == 0.5))] = 1.0             # lenslet 2: two spots, 1 : 3
+    img[np.flatnonzero((grid.x == -0.5) & (grid.y == 2.5))] = 3.0
+    img[np.flatnonzero((grid.x == 2.5) & (grid.y == 2.5))] = 2.0              # lenslet 3
+    img[np.flatnonzero((grid.x == 1.5) & (grid.y == -1.5))] = 9.0             # lenslet 1: not selected
+    c = est.estimate([img])
+    assert c.shape == (2, 3)
+    np.testing.assert_allclose(c[:, 0], [-1.5 + 2.0, -2.5 + 2.0])
+    np.testing.assert_allclose(c[:, 1], [(-3.5 + 3 * -0.5) / 4 + 2.0, (0.5 + 3 * 2.5) / 4 - 2.0])
+    np.testing.assert_allclose(c[:, 2], [2.5 - 2.0, 2.5 - 2.0])
