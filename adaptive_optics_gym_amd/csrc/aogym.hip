@@ -917,8 +917,10 @@ int aog_device_status(aog_env* e, int32_t* status_out) {
   *status_out = v[0] | *static_cast<volatile int*>(e->host_flag);
 #ifdef AOG_DEV
   if (getenv("AOG_X8_DEV") && (atoi(getenv("AOG_X8_DEV")) & 1024)) {
-    fprintf(stderr, "[aogym] k_x8_product: cycles per step max %d min %d, most steps %d, workgroups %d\n", v[8], v[9], v[10], v[11]);
-    const int init[4] = {0, 1 << 30, 0, 0};
+    fprintf(stderr, "[aogym] k_x8_product: cycles per step max %d min %d, most steps %d, workgroups %d; one step of one consumer: operand wait %d, barrier %d, reads + matrix issue %d; of one loader: load wait %d, LDS writes issued %d, loads issued %d, LDS writes done %d, barrier %d\n", v[8], v[9], v[10], v[11], v[13], v[14], v[15], v[2], v[3], v[4], v[5], v[6]);
+    const int z6[6] = {0, 0, 0, 0, 0, 0};
+    HIP_TRY(hipMemcpy(e->dev_status + 2, z6, sizeof z6, hipMemcpyHostToDevice));
+    const int init[8] = {0, 1 << 30, 0, 0, 0, 0, 0, 0};
     HIP_TRY(hipMemcpy(e->dev_status + 8, init, sizeof init, hipMemcpyHostToDevice));
   }
 #endif

@@ -42,7 +42,7 @@ int x8_ensure_buffers(aog_env* e) {
     }
   e->x8_tiles64_max = (e->B + 63) / 64 + kcap;   // every shift class may end in a partly filled tile
   e->x8_slots_max = e->x8_tiles64_max * 64;
-  e->x8_KsTot_max = ks_max;
+  e->x8_KsTot_max = ks_max;   // (one 16-sample chunk per thread of k_x8_prepare: 2 KsTot chunks per env)
   e->x8_rt_max = rt_max;
   int rc;
   if ((rc = dev_alloc(e, &e->x8_dxy, (size_t)2 * e->B)) != AOG_OK) return rc;
@@ -90,10 +90,10 @@ int x8_evolve(aog_env* e, hipStream_t s, long long step_index) {
   if (const char* v = getenv("AOG_X8_DEV")) p.dev = atoi(v);
 #endif
   hipLaunchKernelGGL(aog::k_x8_plan, dim3(1), dim3(aog::kX8PlanThreads), 0, s, p);
-  const dim3 gprep(e->B), gprod(round_up((e->x8_rt_max + 1) / 2, 8), e->x8_tiles64_max);
+  const dim3 gprep(e->B), bprep(round_up(2 * e->x8_KsTot_max, 64)), gprod(round_up((e->x8_rt_max + 1) / 2, 8), e->x8_tiles64_max);
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_x8_product), aog::kX8ProductLds, e->device)) return rc;
   for (int phase = 0; phase < 2; ++phase) {
-    hipLaunchKernelGGL(aog::k_x8_prepare, gprep, dim3(aog::kX8PrepThreads), 0, s, p, phase);
+    hipLaunchKernelGGL(aog::k_x8_prepare, gprep, bprep, 0, s, p, phase);
     hipLaunchKernelGGL(aog::k_x8_product, gprod, dim3(512), aog::kX8ProductLds, s, p, phase);
   }
   HIP_TRY(hipGetLastError());
@@ -382,8 +382,8 @@ int aog_upload_layer_composite(aog_env* e, const aog_layer_composite* t) {
   if (e->x8_kmax[t->axis]) return fail(AOG_ERR_STATE, "aog_upload_layer_composite: axis %d already uploaded", t->axis);
   if (int rcp = refuse_pre_evolved(e, "aog_upload_layer_composite")) return rcp;
   const int N = e->cfg.n_pupil, K = t->k_max, U = t->n_old, Np = round_up(N, 64);
-  if (U > aog::kX8PrepThreads * 16 || K * Np > aog::kX8PrepThreads * 16)
-    return fail(AOG_ERR_UNSUPPORTED, "aog_upload_layer_composite: union stencil of %d samples / %d normals per step (at most %d built)", U, K * Np, aog::kX8PrepThreads * 16);
+  if (round_up(U, 32) + K * Np > aog::kX8PrepMaxThreads * 16)
+    return fail(AOG_ERR_UNSUPPORTED, "aog_upload_layer_composite: %d stencil samples + %d normals per step (at most %d together)", U, K * Np, aog::kX8PrepMaxThreads * 16);
   for (int c = 0; c < U; ++c)
     if ((t->old_yx[c] >> 16) < 0 || (t->old_yx[c] >> 16) >= N || (t->old_yx[c] & 0xffff) >= N) return fail(AOG_ERR_INVALID, "aog_upload_layer_composite: old_yx[%d] outside the screen", c);
   HIP_TRY(hipSetDevice(e->device));

@@ -192,16 +192,19 @@ __device__ __forceinline__ void x8_digits5(double x, int (&d)[5]) {
   d[0] = (hi - d[1]) >> 7;
 }
 
-// ---- prepare: one workgroup per env.  Gather the union stencil, detrend, choose the env's quantum, write the digits of z and of the
-// normals in the product's B-operand order; phase 1 also commits the step's origin and stream position. ------------------------------------
-constexpr int kX8PrepThreads = 256;
+// ---- prepare: one workgroup per env, one 16-sample chunk per thread: the first threads gather the union stencil (detrended, quantised with
+// the env's own quantum), the last ones draw the normals; both write base-128 digits in the product's B-operand order.  Phase 1 also commits
+// the step's origin and stream position. ---------------------------------------------------------------------------------------------------
+constexpr int kX8PrepMaxThreads = 512;   // >= stencil chunks + normal chunks of every operator built (aog_upload_layer_composite checks)
 __device__ __forceinline__ double x8_block_sum(double v, double* sm) {   // fixed association order: reproducible
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
   __syncthreads();
-  return (sm[0] + sm[1]) + (sm[2] + sm[3]);
+  double r = 0.0;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) r += sm[w];
+  return r;
 }
 __device__ __forceinline__ double x8_block_max(double v, double* sm) {
 #pragma unroll
@@ -209,12 +212,14 @@ __device__ __forceinline__ double x8_block_max(double v, double* sm) {
   __syncthreads();
   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
   __syncthreads();
-  return fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
+  double r = 0.0;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) r = fmax(r, sm[w]);
+  return r;
 }
 
-__global__ __launch_bounds__(kX8PrepThreads) void k_x8_prepare(X8Args p, int phase) {
-  __shared__ double sm[4];
-  const int tid = threadIdx.x;
+__global__ __launch_bounds__(kX8PrepMaxThreads) void k_x8_prepare(X8Args p, int phase) {
+  __shared__ double sm[kX8PrepMaxThreads / 64];
+  const int tid = threadIdx.x, nthr = blockDim.x;
   const int env = blockIdx.x;
   const int N = p.N;
   const int dx = p.dxy[2 * env], dy = p.dxy[2 * env + 1];
@@ -237,66 +242,54 @@ __global__ __launch_bounds__(kX8PrepThreads) void k_x8_prepare(X8Args p, int pha
   const int nchunk = tb.KsA * 2, nchunk_n = tb.KsB * 2;   // 16-sample chunks of the (padded) union stencil / of the normals
   const double mid = 0.5 * (double)(N - 1);
   const int r0 = phase == 1 ? min(abs(dx), p.kcap) : 0;   // index of this phase's first shift among the step's shifts (stream position, replay buffer)
+  const bool zjob = tid < nchunk;
+  const int cn = nthr - 1 - tid;                          // normals' chunks are dealt from the last thread down: a thread has one job
+  const bool njob = !zjob && cn < nchunk_n;
 
-  // stencil chunks: thread t takes chunks t, t + 256, ... (at most kX8ZChunks of them)
-  constexpr int kZC = 1;   // 256 threads x 16 samples = 4096 >= every union stencil built (aog_upload_layer_composite checks)
-  double v[kZC][16], xs[kZC][16];
+  double x[16];     // the job's 16 samples: stencil values (then detrended) or normals
+  i32x4 y4[4];      // stencil jobs: the samples' positions
   double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-  for (int cc = 0; cc < kZC; ++cc) {
-    const int c = tid + kX8PrepThreads * cc;
+  for (int b = 0; b < 16; ++b) x[b] = 0.0;
+  if (zjob) {
+    const i32x4* yq = reinterpret_cast<const i32x4*>(tb.yx + 16 * tid);
 #pragma unroll
-    for (int b = 0; b < 16; ++b) { v[cc][b] = 0.0; xs[cc][b] = 0.0; }
-    if (c < nchunk) {
-      const i32x4* yq = reinterpret_cast<const i32x4*>(tb.yx + 16 * c);
+    for (int q = 0; q < 4; ++q) y4[q] = yq[q];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        int sy = y4[q][b] >> 16, sx = y4[q][b] & 0xffff;
+        if (flipped) { sy = N - 1 - sy; sx = N - 1 - sx; }
+        int py = sy + oy, px = sx + ox;
+        if (py >= N) py -= N;
+        if (px >= N) px -= N;
+        const bool in = 16 * tid + 4 * q + b < tb.U;
+        x[4 * q + b] = (in && !(AOG_X8_DEV(p) & 64)) ? master[(size_t)py * N + px] : 0.0;
+      }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const double xa = (double)(vertical ? (y4[q][b] & 0xffff) : (y4[q][b] >> 16)) - mid;
+        s0 += x[4 * q + b];
+        s1 += 16 * tid + 4 * q + b < tb.U ? x[4 * q + b] * xa : 0.0;
+      }
+  } else if (njob) {
+    const int jj = (16 * cn) / tb.Np, i0 = 16 * cn - jj * tb.Np;   // shift jj + 1, samples i0 .. i0 + 15 (Np is a multiple of 64: no straddle)
+    if (i0 < N) {
+      const bool replay = p.noise && (r0 + jj) < p.max_ext;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const i32x4 y4 = yq[q];
+        double n4[4];
+        if (replay) {
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const int kk = 16 * c + 4 * q + b;
-          int sy = y4[b] >> 16, sx = y4[b] & 0xffff;
-          const double xa = (double)(vertical ? sx : sy) - mid;
-          if (flipped) { sy = N - 1 - sy; sx = N - 1 - sx; }
-          int py = sy + oy, px = sx + ox;
-          if (py >= N) py -= N;
-          if (px >= N) px -= N;
-          const bool in = kk < tb.U;
-          const double val = (in && !(AOG_X8_DEV(p) & 64)) ? master[(size_t)py * N + px] : 0.0;
-          v[cc][4 * q + b] = val;
-          xs[cc][4 * q + b] = in ? xa : 0.0;
-          s0 += val;
-          s1 += in ? val * xa : 0.0;
+          for (int b = 0; b < 4; ++b) n4[b] = (i0 + 4 * q + b) < N ? p.noise[((size_t)env * p.max_ext + (r0 + jj)) * N + i0 + 4 * q + b] : 0.0;
+        } else {
+          philox_normal4(p.seed, (uint32_t)(p.env_base + env), ext_old + (uint32_t)(r0 + jj), (uint32_t)((i0 >> 2) + q), n4);
         }
-      }
-    }
-  }
-  // normals of this thread's chunks (independent of the stencil: drawn while the gathers are in flight)
-  constexpr int kNC = 1;   // 256 x 16 = 4096 >= k Np for every operator built (k <= 8, Np <= 512)
-  double nv[kNC][16];
 #pragma unroll
-  for (int cc = 0; cc < kNC; ++cc) {
-    const int c = (kX8PrepThreads - 1 - tid) + kX8PrepThreads * cc;   // dealt from the last thread down: the stencil's chunks start at thread 0
-#pragma unroll
-    for (int b = 0; b < 16; ++b) nv[cc][b] = 0.0;
-    if (c < nchunk_n) {
-      const int jj = (16 * c) / tb.Np, i0 = 16 * c - jj * tb.Np;   // shift jj + 1, samples i0 .. i0 + 15 (Np is a multiple of 64: no straddle)
-      if (i0 < N) {
-        const bool replay = p.noise && (r0 + jj) < p.max_ext;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          double n4[4];
-          if (replay) {
-#pragma unroll
-            for (int b = 0; b < 4; ++b) n4[b] = (i0 + 4 * q + b) < N ? p.noise[((size_t)env * p.max_ext + (r0 + jj)) * N + i0 + 4 * q + b] : 0.0;
-          } else if (!(AOG_X8_DEV(p) & 128)) {
-            philox_normal4(p.seed, (uint32_t)(p.env_base + env), ext_old + (uint32_t)(r0 + jj), (uint32_t)((i0 >> 2) + q), n4);
-          } else {
-            n4[0] = n4[1] = n4[2] = n4[3] = 0.5;
-          }
-#pragma unroll
-          for (int b = 0; b < 4; ++b) nv[cc][4 * q + b] = (i0 + 4 * q + b) < N ? n4[b] : 0.0;
-        }
+        for (int b = 0; b < 4; ++b) x[4 * q + b] = (i0 + 4 * q + b) < N ? n4[b] : 0.0;
       }
     }
   }
@@ -306,21 +299,23 @@ __global__ __launch_bounds__(kX8PrepThreads) void k_x8_prepare(X8Args p, int pha
   const double c1 = (s1 - s0 * tb.sx / U) / (tb.sxx - tb.sx * tb.sx / U);
   const double c0 = s0 / U - c1 * tb.sx / U;
   double m = 0.0;
+  if (zjob) {
 #pragma unroll
-  for (int cc = 0; cc < kZC; ++cc)
+    for (int q = 0; q < 4; ++q)
 #pragma unroll
-    for (int b = 0; b < 16; ++b) {
-      const int kk = 16 * (tid + kX8PrepThreads * cc) + b;
-      const double zp = kk < tb.U ? v[cc][b] - c0 - c1 * xs[cc][b] : 0.0;
-      v[cc][b] = zp;
-      m = fmax(m, fabs(zp));
-    }
+      for (int b = 0; b < 4; ++b) {
+        const double xa = (double)(vertical ? (y4[q][b] & 0xffff) : (y4[q][b] >> 16)) - mid;
+        const double zp = 16 * tid + 4 * q + b < tb.U ? x[4 * q + b] - c0 - c1 * xa : 0.0;
+        x[4 * q + b] = zp;
+        m = fmax(m, fabs(zp));
+      }
+  }
   m = x8_block_max(m, sm);
   const int ez = max(tb.ez_floor, m > 0.0 ? ilogb(m) + 1 : tb.ez_floor);   // 2^ez > every |zp|
-  const double inv_qz = ldexp(1.0, 34 - ez), inv_qn = ldexp(1.0, 34 - ez - tb.log2_cn);
-  const size_t tile_base = (size_t)tile * p.KsTot_max;
-  bool range_ok = isfinite(m);
-  auto put = [&](const double (&x)[16], double inv_q, int ks, int g) {
+  if (zjob || njob) {
+    const double inv_q = zjob ? ldexp(1.0, 34 - ez) : ldexp(1.0, 34 - ez - tb.log2_cn);
+    const int c = zjob ? tid : cn, ks = (zjob ? 0 : tb.KsA) + (c >> 1), g = c & 1;
+    bool range_ok = isfinite(m);
     uint32_t w[5][4];
 #pragma unroll
     for (int t = 0; t < 5; ++t)
@@ -330,28 +325,19 @@ __global__ __launch_bounds__(kX8PrepThreads) void k_x8_prepare(X8Args p, int pha
     for (int b = 0; b < 16; ++b) {
       const double xi = rint(x[b] * inv_q);
       range_ok = range_ok && fabs(xi) <= 17179869184.0;   // 2^34
-      int dg[5] = {0, 0, 0, 0, (int)x[b]};
-      if (!(AOG_X8_DEV(p) & 32)) x8_digits5(xi, dg);
+      int dg[5];
+      x8_digits5(xi, dg);
 #pragma unroll
       for (int t = 0; t < 5; ++t) w[t][b >> 2] |= (uint32_t)(dg[t] & 0xff) << (8 * (b & 3));
     }
+    int8_t* dst = p.Z8 + ((((size_t)tile * p.KsTot_max + ks) * 5 * 64 + (g * 32 + col)) << 4);
 #pragma unroll
     for (int t = 0; t < 5; ++t) {
       u32x4 o = {w[t][0], w[t][1], w[t][2], w[t][3]};
-      if (!(AOG_X8_DEV(p) & 16) || o[0] == 0x12345678u) *reinterpret_cast<u32x4*>(p.Z8 + ((((tile_base + ks) * 5 + t) * 64 + (g * 32 + col)) << 4)) = o;
+      *reinterpret_cast<u32x4*>(dst + t * 1024) = o;
     }
-  };
-#pragma unroll
-  for (int cc = 0; cc < kZC; ++cc) {
-    const int c = tid + kX8PrepThreads * cc;
-    if (c < nchunk) put(v[cc], inv_qz, c >> 1, c & 1);
+    if (!range_ok) atomicOr(p.status, 4);
   }
-#pragma unroll
-  for (int cc = 0; cc < kNC; ++cc) {
-    const int c = (kX8PrepThreads - 1 - tid) + kX8PrepThreads * cc;
-    if (c < nchunk_n) put(nv[cc], inv_qn, tb.KsA + (c >> 1), c & 1);
-  }
-  if (!range_ok) atomicOr(p.status, 4);
   if (tid == 0) {
     double* rc = p.rec + (size_t)slot * 4;
     rc[0] = ldexp(1.0, tb.log2_qa + (ez - 34) + 21);   // qa qz 128^3: level l of the product carries 128^(8 - l), l = 0 .. 5
@@ -468,12 +454,14 @@ __global__ __launch_bounds__(512, 2) void k_x8_product(X8Args p, int phase) {
     // port 8 of its 32 cycles): issued ahead of them they cost ~160 cycles of every step (one read too many at the very end: a landed stage)
     const int8_t* sb = &lds8[bufn * kX8Blocks * 1024];
     int q = 0;
+    // digit-major order: consecutive matrix instructions never write the same accumulator (level-major, five in a row on one accumulator, measured
+    // 78 cycles per instruction in isolation against 56: tools/microbench/mfma_i8_step.hip)
 #pragma unroll
-    for (int l = 0; l < kX8Levels; ++l)
+    for (int s = 0; s < 5; ++s)
 #pragma unroll
-      for (int s = 0; s <= l; ++s)
-        if (s < 5 && l - s < 5) {
-          if (!(AOG_X8_DEV(p) & 1)) acc[l] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ac[s], zc[l - s], acc[l], 0, 0, 0);
+      for (int t = 0; t < 5; ++t)
+        if (s + t < kX8Levels) {
+          if (!(AOG_X8_DEV(p) & 1)) acc[s + t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ac[s], zc[t], acc[s + t], 0, 0, 0);
           if (q < 5) ax[q] = *reinterpret_cast<const i32x4*>(sb + (rtl * 5 + q) * 1024 + (lane << 4));
           else if (q < 10) zx[q - 5] = *reinterpret_cast<const i32x4*>(sb + (10 + ctl * 5 + q - 5) * 1024 + (lane << 4));
           ++q;

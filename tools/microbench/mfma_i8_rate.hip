@@ -1,3 +1,4 @@
+// (independent accumulators, then ONE accumulator = a dependent chain, then two alternating)
 // Cycles per v_mfma_i32_32x32x32_i8 / v_mfma_i32_16x16x64_i8 / v_mfma_f32_32x32x16_f16, back to back on one SIMD (one wave per SIMD,
 // independent accumulators).    hipcc -O2 --offload-arch=gfx950 mfma_i8_rate.hip -o mfma_i8_rate && ./mfma_i8_rate
 #include <hip/hip_runtime.h>
@@ -21,6 +22,16 @@ __global__ void k(long long* out, int* sink, int iters) {
       c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c1, 0, 0, 0);
       c2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c2, 0, 0, 0);
       c3 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c3, 0, 0, 0);
+    } else if (WHICH == 3) {   // ONE accumulator: a chain of dependent instructions
+      c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c0, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c0, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c0, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c0, 0, 0, 0);
+    } else if (WHICH == 4) {   // two accumulators alternating
+      c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c1, 0, 0, 0);
     } else if (WHICH == 1) {
       d0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, d0, 0, 0, 0);
       d1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, d1, 0, 0, 0);
@@ -41,12 +52,14 @@ int main() {
   long long* out; int* sink;
   (void)hipMalloc(&out, 8 * 1024); (void)hipMalloc(&sink, 4 * 64 * 1024);
   const int iters = 4096;
-  const char* names[3] = {"v_mfma_i32_32x32x32_i8", "v_mfma_i32_16x16x64_i8", "v_mfma_f32_32x32x16_f16"};
-  for (int w = 0; w < 3; ++w)
+  const char* names[5] = {"v_mfma_i32_32x32x32_i8", "v_mfma_i32_16x16x64_i8", "v_mfma_f32_32x32x16_f16", "i8 32x32x32, ONE accumulator", "i8 32x32x32, two accumulators"};
+  for (int w = 0; w < 5; ++w)
     for (int blocks : {1, 1024}) {
       if (w == 0) hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(64), 0, 0, out, sink, iters);
       if (w == 1) hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(64), 0, 0, out, sink, iters);
       if (w == 2) hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(64), 0, 0, out, sink, iters);
+      if (w == 3) hipLaunchKernelGGL(k<3>, dim3(blocks), dim3(64), 0, 0, out, sink, iters);
+      if (w == 4) hipLaunchKernelGGL(k<4>, dim3(blocks), dim3(64), 0, 0, out, sink, iters);
       long long t;
       (void)hipMemcpy(&t, out, 8, hipMemcpyDeviceToHost);
       printf("%-26s %4d waves: %.1f s_memtime ticks per instruction\n", names[w], blocks, (double)t / (4.0 * iters));
