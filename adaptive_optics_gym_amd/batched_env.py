@@ -293,11 +293,16 @@ class BatchedAOEnv:
             return
         N = self.num_pupil_pixels
         keep = []
+        self.extrusion_union = {}     # axis -> [U_1 .. U_kmax]: union stencil sizes of the operators the library cuts out of the uploaded one
         for axis, (st, A, B) in enumerate(((layer["stencil_vertical"], layer["A_vertical"], layer["B_vertical"]),
                                             (layer["stencil_horizontal"], layer["A_horizontal"], layer["B_horizontal"]))):
             yx, Ak, Bk = compose_extrusions(st, A, B, N, k_need, vertical=axis == 0)
             yx, Ak, Bk = np.ascontiguousarray(yx, dtype=np.int32), np.ascontiguousarray(Ak), np.ascontiguousarray(Bk)
             keep.append((yx, Ak, Bk))
+            first_use = np.full(yx.size, k_need + 1)
+            for j in range(k_need, 0, -1):
+                first_use[np.abs(Ak[(j - 1) * N:j * N]).sum(axis=0) > 0] = j
+            self.extrusion_union[axis] = [int((first_use <= k).sum()) for k in range(1, k_need + 1)]
             op = _lib.AogLayerComposite(axis, k_need, int(yx.size), 0, _dptr(yx, C.c_int32), _dptr(Ak, C.c_double), _dptr(Bk, C.c_double))
             _lib.check(self.lib.aog_upload_layer_composite(self._handle, C.byref(op)))
         self.extrusion_kmax = k_need

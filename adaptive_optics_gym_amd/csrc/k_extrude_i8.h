@@ -367,9 +367,10 @@ __device__ __forceinline__ void x8_store(const X8Args& p, int env, int N, int py
 // profiles/HISTORY.md): with each wave loading, reading and multiplying in turn a step took ~1100-1500 cycles against 608 of matrix
 // instructions (LDS-DMA issue ~60-100 cycles apiece, the 40-80 KB burst of LDS reads behind the barrier, then the matrix work, in series), a
 // deeper ring or cache-hot operands changed nothing, and splitting a tile's products by level over two waves of a SIMD only doubled the LDS reads.
-constexpr int kX8Blocks = 20;
-constexpr int kX8Stages = 5;   // an LDS-DMA lands ~1.1 us after its issue (MI355X_MICROARCH.md, ldsdma-fill): four steps of lead
-constexpr int kX8ProductLds = kX8Stages * kX8Blocks * 1024;   // (the epilogue's 32 KB transposition area lives in the ring)
+constexpr int kX8Blocks = 20;   // 1-KiB operand blocks per 32-deep step
+constexpr int kX8Sub = 2;       // steps per LDS stage = per barrier (the barrier's bubble in the matrix stream, ~300 cycles, is paid once per stage)
+constexpr int kX8Stages = 3;    // an LDS-DMA lands ~1.1 us after its issue (MI355X_MICROARCH.md, ldsdma-fill): two stages = four steps of lead
+constexpr int kX8ProductLds = kX8Stages * kX8Sub * kX8Blocks * 1024;   // (the epilogue's 32 KB transposition area lives in the ring)
 
 __global__ __launch_bounds__(512, 2) void k_x8_product(X8Args p, int phase) {
   extern __shared__ __attribute__((aligned(1024))) int8_t lds8[];   // kX8ProductLds bytes
@@ -388,6 +389,7 @@ __global__ __launch_bounds__(512, 2) void k_x8_product(X8Args p, int phase) {
   const int N = p.N, KsA = tb.KsA, KsB = tb.KsB;
   const int shift = rt0 / (tb.Np / 32);                         // both row tiles lie in shift block `shift` + 1 (Np / 32 is even)
   const int n_steps = KsA + (shift + 1) * (tb.Np / 32);         // normals of later shifts do not reach these rows
+  const int n_stages = (n_steps + kX8Sub - 1) / kX8Sub;
 
   if (loader) {
     const int8_t* A8 = tb.A8;
@@ -396,29 +398,32 @@ __global__ __launch_bounds__(512, 2) void k_x8_product(X8Args p, int phase) {
     const int8_t* Z1 = p.Z8 + (((size_t)(2 * tile64 + 1) * p.KsTot_max * 5) << 10);
     // block `blk` of step `st`: 0..9 = digits of the two row tiles of A_k (st < KsA) or of sqrt(Cn^2) B_k, 10..19 = digits of the two env tiles;
     // loader w moves blocks w, w + 4, ..., w + 16
-    auto issue = [&](int st, int buf) {
-      st = min(st, n_steps - 1);   // (past the end: a harmless re-load into a free stage keeps the vmcnt arithmetic uniform)
+    auto issue = [&](int stage, int buf) {
 #pragma unroll
-      for (int r = 0; r < 5; ++r) {
-        const int blk = 4 * r + tile, h = blk >= 10 ? (blk - 10) / 5 : blk / 5, dgt = blk % 5;
-        const int8_t* src;
-        if (blk >= 10) src = (h ? Z1 : Z0) + (((size_t)st * 5 + dgt) << 10);
-        else if (st < KsA) src = A8 + ((((size_t)(rt0 + h) * KsA + st) * 5 + dgt) << 10);
-        else src = B8 + ((((size_t)(rt0 + h) * KsB + (st - KsA)) * 5 + dgt) << 10);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (lane << 4)),
-                                         (__attribute__((address_space(3))) void*)(&lds8[(buf * kX8Blocks + blk) * 1024]), 16, 0, 0);
+      for (int sub = 0; sub < kX8Sub; ++sub) {
+        const int st = min(stage * kX8Sub + sub, n_steps - 1);   // (past the end: a harmless re-load keeps the vmcnt arithmetic uniform)
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+          const int blk = 4 * r + tile, h = blk >= 10 ? (blk - 10) / 5 : blk / 5, dgt = blk % 5;
+          const int8_t* src;
+          if (blk >= 10) src = (h ? Z1 : Z0) + (((size_t)st * 5 + dgt) << 10);
+          else if (st < KsA) src = A8 + ((((size_t)(rt0 + h) * KsA + st) * 5 + dgt) << 10);
+          else src = B8 + ((((size_t)(rt0 + h) * KsB + (st - KsA)) * 5 + dgt) << 10);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (lane << 4)),
+                                           (__attribute__((address_space(3))) void*)(&lds8[((buf * kX8Sub + sub) * kX8Blocks + blk) * 1024]), 16, 0, 0);
+        }
       }
     };
 #pragma unroll
     for (int q = 0; q < kX8Stages; ++q) issue(q, q);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * (kX8Stages - 1)) : "memory");   // stage 0 has landed
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * kX8Sub * (kX8Stages - 1)) : "memory");   // stage 0 has landed
     __builtin_amdgcn_s_barrier();
     int buf = 0;
-    for (int st = 0; st < n_steps; ++st) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * (kX8Stages - 2)) : "memory");   // this loader's blocks of step st + 1 have landed
-      __builtin_amdgcn_s_barrier();   // the consumers hold step st's operands in registers: its stage is free
+    for (int q = 0; q < n_stages; ++q) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * kX8Sub * (kX8Stages - 2)) : "memory");   // this loader's blocks of stage q + 1 have landed
+      __builtin_amdgcn_s_barrier();   // the consumers are done reading stage q (they read its second step's operands during its first step) ...
       asm volatile("" ::: "memory");
-      if (!(AOG_X8_DEV(p) & 2)) issue(st + kX8Stages, buf);
+      issue(q + kX8Stages, buf);      // ... whose buffer takes stage q + kX8Stages
       buf = buf + 1 == kX8Stages ? 0 : buf + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the re-loads past the end)
@@ -432,8 +437,8 @@ __global__ __launch_bounds__(512, 2) void k_x8_product(X8Args p, int phase) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[l][r] = 0;
   i32x4 a[5], z[5], an[5], zn[5];
-  auto read_ops = [&](int buf, i32x4 (&ao)[5], i32x4 (&zo)[5]) {
-    const int8_t* sb = &lds8[buf * kX8Blocks * 1024];
+  auto read_ops = [&](int slot, i32x4 (&ao)[5], i32x4 (&zo)[5]) {   // slot = stage buffer * kX8Sub + step within the stage
+    const int8_t* sb = &lds8[slot * kX8Blocks * 1024];
 #pragma unroll
     for (int dgt = 0; dgt < 5; ++dgt) {
       ao[dgt] = *reinterpret_cast<const i32x4*>(sb + (rtl * 5 + dgt) * 1024 + (lane << 4));
@@ -443,40 +448,37 @@ __global__ __launch_bounds__(512, 2) void k_x8_product(X8Args p, int phase) {
   __builtin_amdgcn_s_barrier();   // stage 0 is in LDS
   asm volatile("" ::: "memory");
   read_ops(0, a, z);
-  int bufn = 1;
-  // one step: wait for this step's operands (read a step ago: the stage they came from is then free), meet the loaders (step st + 1's stage has
-  // landed), issue the reads of the NEXT step's operands, then this step's 19 matrix instructions: the reads return while they run
-  auto step = [&](i32x4 (&ac)[5], i32x4 (&zc)[5], i32x4 (&ax)[5], i32x4 (&zx)[5]) {
-    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) (as a builtin: the compiler's own wait insertion then knows the counter is drained)
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    // the ten LDS reads of the next step's operands ride in the shadow of this step's first matrix instructions (an MFMA holds the issue
-    // port 8 of its 32 cycles): issued ahead of them they cost ~160 cycles of every step (one read too many at the very end: a landed stage)
-    const int8_t* sb = &lds8[bufn * kX8Blocks * 1024];
+  // one step: the ten LDS reads of the NEXT step's operands ride in the shadow of this step's first matrix instructions (an MFMA holds the issue
+  // port 8 of its 32 cycles); digit-major order: consecutive matrix instructions never write the same accumulator.  `live` = this step exists
+  // (the last stage of an odd count holds a repeated step)
+  auto step = [&](bool live, int next_slot, i32x4 (&ac)[5], i32x4 (&zc)[5], i32x4 (&ax)[5], i32x4 (&zx)[5]) {
+    const int8_t* sb = &lds8[next_slot * kX8Blocks * 1024];
     int q = 0;
-    // digit-major order: consecutive matrix instructions never write the same accumulator (level-major, five in a row on one accumulator, measured
-    // 78 cycles per instruction in isolation against 56: tools/microbench/mfma_i8_step.hip)
 #pragma unroll
     for (int s = 0; s < 5; ++s)
 #pragma unroll
       for (int t = 0; t < 5; ++t)
         if (s + t < kX8Levels) {
-          if (!(AOG_X8_DEV(p) & 1)) acc[s + t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ac[s], zc[t], acc[s + t], 0, 0, 0);
+          if (live && !(AOG_X8_DEV(p) & 1)) acc[s + t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ac[s], zc[t], acc[s + t], 0, 0, 0);
           if (q < 5) ax[q] = *reinterpret_cast<const i32x4*>(sb + (rtl * 5 + q) * 1024 + (lane << 4));
           else if (q < 10) zx[q - 5] = *reinterpret_cast<const i32x4*>(sb + (10 + ctl * 5 + q - 5) * 1024 + (lane << 4));
           ++q;
           __builtin_amdgcn_sched_barrier(0);
         }
-    if (AOG_X8_DEV(p) & 1) acc[0][0] += ac[0][0] + zc[4][3] + ac[4][1] + zc[0][2];
-    bufn = bufn + 1 == kX8Stages ? 0 : bufn + 1;
   };
   const long long t_loop0 = (AOG_X8_DEV(p) & 1024) ? (long long)__builtin_amdgcn_s_memtime() : 0;
-  int st = 0;
-  for (; st + 1 < n_steps; st += 2) {   // operand sets ping-pong (no register copies)
-    step(a, z, an, zn);
-    step(an, zn, a, z);
+  int buf = 0;
+  for (int q = 0; q < n_stages; ++q) {
+    // first step of stage q (operands in a, z): the reads of its second step (same stage: visible since the last barrier) run beside it
+    step(true, buf * kX8Sub + 1, a, z, an, zn);
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): every read of stage q is done — as a builtin, so that the compiler's own wait insertion knows it
+    __builtin_amdgcn_s_barrier();          // stage q + 1 has landed; the loaders refill stage q's buffer
+    asm volatile("" ::: "memory");
+    const int nb = buf + 1 == kX8Stages ? 0 : buf + 1;
+    // second step (operands in an, zn), beside the reads of stage q + 1's first step (one read too many at the very end: a landed stage)
+    step(q * kX8Sub + 1 < n_steps, nb * kX8Sub, an, zn, a, z);
+    buf = nb;
   }
-  if (st < n_steps) step(a, z, an, zn);
   if ((AOG_X8_DEV(p) & 1024) && wave == 0 && lane == 0) {   // developer read-out: cycles per step of the slowest and of the fastest workgroup, steps of the longest
     const int cyc = (int)(((long long)__builtin_amdgcn_s_memtime() - t_loop0) / n_steps);
     atomicMax(p.status + 8, cyc);

@@ -279,17 +279,44 @@ def roofline_dominant(env, w, kernels, steps_range):
 
         ms, n = kernels["extrude"]
         shifts = 0
-        for t in range(steps_range[0], steps_range[1]):
-            sh = integer_shifts(env.velocity_vectors, t * env.delta_t, (t + 1) * env.delta_t, env.params.pupil_pixel)
-            shifts += int(np.abs(sh).sum())
-        nz = int(max(env._layer["stencil_vertical"].size, env._layer["stencil_horizontal"].size))
+        int8_mfma = 0.0     # v_mfma_i32_32x32x32_i8 per step (int8 composite form), summed over the timed steps
+        f64_flop = 0.0      # flops of the same products in plain float64 arithmetic
         n_steps = max(1, steps_range[1] - steps_range[0])
-        flop = 2.0 * N * (nz + N) * shifts / n_steps          # per step (= per launch), mean over the timed region
-        out["extrude"] = {"kernel": "k_extrude16_split", "bound": "mfma_f64", "ms": ms, "launches": n, "achieved": flop / (ms * 1e-3) / 1e12,
-                          "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flop / (ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS,
-                          "shifts_per_env_step": shifts / max(1, B * n_steps),
-                          "note": "2 N (nz + N) flop per one-pixel shift of one env, shifts recomputed on the host for the timed steps (mean per "
-                                  "step); ms = mean duration of the sampled launches (HIP events around one block of 8 steps in 8)"}
+        i8 = getattr(env, "extrusion_kmax", 0) > 0
+        Np = -(-N // 64) * 64
+        for t in range(steps_range[0], steps_range[1]):
+            sh = np.abs(integer_shifts(env.velocity_vectors, t * env.delta_t, (t + 1) * env.delta_t, env.params.pupil_pixel))
+            shifts += int(sh.sum())
+            if i8:
+                for phase, axis in ((0, 1), (1, 0)):          # x shifts use the horizontal operator
+                    for k in range(1, env.extrusion_kmax + 1):
+                        cnt = int((sh[:, phase] == k).sum())
+                        if not cnt:
+                            continue
+                        ksa = -(-env.extrusion_union[axis][k - 1] // 32)
+                        tiles32 = 2 * (-(-cnt // 64))          # 64-env workgroup tiles, partly filled ones included (they run in full)
+                        steps = sum((Np // 32) * (ksa + j * (Np // 32)) for j in range(1, k + 1))   # row tiles x steps of the contraction
+                        int8_mfma += 19.0 * steps * tiles32
+                        f64_flop += 2.0 * cnt * sum(N * (env.extrusion_union[axis][k - 1] + j * N) for j in range(1, k + 1))
+        nz = int(max(env._layer["stencil_vertical"].size, env._layer["stencil_horizontal"].size))
+        if i8:
+            ops = int8_mfma / n_steps * 65536.0        # 32 x 32 x 32 multiply-adds = 65 536 integer operations per instruction
+            out["extrude"] = {"kernel": "k_x8_plan + k_x8_prepare x 2 + k_x8_product x 2", "bound": "mfma_i8", "ms": ms, "launches": n,
+                              "achieved": ops / (ms * 1e-3) / 1e12, "peak": 2 * F16_MFMA_PEAK_TFLOPS, "unit": "TOP/s",
+                              "frac": ops / (ms * 1e-3) / 1e12 / (2 * F16_MFMA_PEAK_TFLOPS),
+                              "equivalent_float64_tflops": f64_flop / n_steps / (ms * 1e-3) / 1e12,
+                              "shifts_per_env_step": shifts / max(1, B * n_steps),
+                              "note": "int8 composite extrusion: digit products as issued (19 v_mfma_i32_32x32x32_i8 per 32 x 32 tile and 32-deep step, "
+                                      "partly filled env tiles included) against the dense int8 matrix peak (2 x the f16 peak); ms = mean duration of the "
+                                      "sampled steps' five launches together (HIP events around one block of 8 steps in 8); equivalent_float64_tflops = "
+                                      "the same composite products counted as float64 flops (float64 matrix peak: 78.6)"}
+        else:
+            flop = 2.0 * N * (nz + N) * shifts / n_steps          # per step (= per launch), mean over the timed region
+            out["extrude"] = {"kernel": "k_extrude16_split", "bound": "mfma_f64", "ms": ms, "launches": n, "achieved": flop / (ms * 1e-3) / 1e12,
+                              "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flop / (ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS,
+                              "shifts_per_env_step": shifts / max(1, B * n_steps),
+                              "note": "2 N (nz + N) flop per one-pixel shift of one env, shifts recomputed on the host for the timed steps (mean per "
+                                      "step); ms = mean duration of the sampled launches (HIP events around one block of 8 steps in 8)"}
     if all(k in kernels for k in ("sh_rows_fwd", "sh_cols")):
         three = "sh_rows_inv" in kernels                      # (transfer functions that do not factorise keep the three-pass form)
         names = ("sh_rows_fwd", "sh_cols", "sh_rows_inv") if three else ("sh_rows_fwd", "sh_cols")
@@ -401,6 +428,7 @@ def main():
     ap.add_argument("--no-spinup", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the second timed region (aog_step_pipelined: `value_pipelined`) of configs 2 and 3")
     ap.add_argument("--no-b4096", action="store_true", help="config 2: skip the HBM-resident (B = 4096) measurement of the fused kernel")
+    ap.add_argument("--extrusion", default="auto", choices=["auto", "f64"], help="config 4: 'f64' = the float64 round kernels (validation form) instead of the int8 composite form")
     ap.add_argument("--lookahead", action="store_true", help="config 4: launch each step's wind extrusion one step ahead on the library's own stream")
     args = ap.parse_args()
     w = dict(WORKLOADS[args.config])
@@ -453,7 +481,7 @@ def main():
     env = BatchedAOEnv(B, device, atm_type=w["atm_type"], atm_vel=w["atm_vel"], atm_fried=w["atm_fried"], act_type=w["act_type"],
                        act_dim=w["act_dim"], obs_dim=w["obs_dim"], rew_type=w["rew_type"], timesteps_per_episode=T,
                        SH_operation=w["SH_operation"], num_pupil_pixels=w["n_pupil"], seed=1234, screen_source="device",
-                       screen_oversampling=16, kernel=args.kernel, verbose=False, global_env_offset=rank * B, total_envs=total)
+                       screen_oversampling=16, kernel=args.kernel, verbose=False, global_env_offset=rank * B, total_envs=total, extrusion=args.extrusion)
     # actions of the GLOBAL batch from one seed (main.py:155; cov 0.5 I, algorithm.py:107), this rank's slice kept
     agen = torch.Generator(device).manual_seed(10)
     actions = (torch.randn((T, total, w["act_dim"]), device=device, generator=agen) * (0.5 ** 0.5))[:, rank * B:(rank + 1) * B].contiguous()

@@ -11,7 +11,7 @@ typedef int i32x16 __attribute__((ext_vector_type(16)));
 #define MF(acc, x, y) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(x, y, acc, 0, 0, 0)
 #endif
 template <int ORDER>
-__global__ void k(long long* out, int* sink, const i32x4* src, int iters, int trivial) {
+__global__ __launch_bounds__(64) void k(long long* out, int* sink, const i32x4* src, int iters, int trivial) {
   i32x4 a0 = src[threadIdx.x], a1 = src[threadIdx.x + 64], a2 = src[threadIdx.x + 128], a3 = src[threadIdx.x + 192], a4 = src[threadIdx.x + 256];
   i32x4 z0 = src[threadIdx.x + 320], z1 = src[threadIdx.x + 384], z2 = src[threadIdx.x + 448], z3 = src[threadIdx.x + 512], z4 = src[threadIdx.x + 576];
   if (trivial) { a0 = a1 = a2 = a3 = a4 = i32x4{1, 0, 0, 0}; z0 = z1 = z2 = z3 = z4 = i32x4{0, 1, 0, 0}; }
