@@ -249,15 +249,6 @@ int launch_epilogue(aog_env* e, bool is_step, float* obs_raw, uint16_t* obs, flo
   p.Bp = e->Bp;
   const bool ref = e->cfg.precision == AOG_PRECISION_FP64;
   p.n_chunks = ref ? 1 : e->n_chunks;
-  if (e->kernel == AOG_KERNEL_MFMA && e->MRW > 8 && e->cfg.precision == AOG_PRECISION_FAST) {
-    // many short float chunks: fold them first with a fully coalesced pass, the epilogue then reads one float64 slab
-    const int NSr = 2 * (e->MRW + e->MRS);
-    hipLaunchKernelGGL(aog::k_reduce_slabs, dim3(e->Bp / 64, (NSr + 3) / 4), dim3(256), 0, s, reinterpret_cast<const float*>(e->partials),
-                       e->slab_reduced, e->n_chunks, NSr, e->Bp);
-    p.partials = e->slab_reduced;
-    p.n_chunks = 1;
-    p.partials_f32 = 0;
-  }
   p.MRW = ref ? e->MRW_used : e->MRW;
   p.MRS = ref ? e->MRS_used : e->MRS;
   p.MRW_used = e->MRW_used;
@@ -269,7 +260,6 @@ int launch_epilogue(aog_env* e, bool is_step, float* obs_raw, uint16_t* obs, flo
   p.max_steps = e->cfg.max_steps;
   p.is_step = is_step ? 1 : 0;
   p.ret_acc = is_step ? e->ret_acc : nullptr;
-  p.partials_f32 = 0;   // (float slabs are folded by k_reduce_slabs above; the epilogue's own float path is kept for reference)
   p.thr = e->cfg.rew_threshold;
   p.ssim_peak = e->cfg.ssim_ref_peak;
   p.ssim_alpha = e->cfg.ssim_alpha;
@@ -433,14 +423,16 @@ int aog_create(const aog_config* cfg, int device, aog_env** out) {
     // Asymmetric wave pairs (see k_fused_tab): the float64-flush variant with at least 4 env tiles runs 8-wave workgroups, one per
     // CU, whose two pixel sub-chunks split a chunk about 2 : 1 with the priority on the larger share; the many-table variants keep the
     // 4-wave interleaved form (their chunks are short and come in many rounds, which balances itself).
-    const bool asym = e->kernel == AOG_KERNEL_MFMA && e->MRW <= 8 && e->n_etiles >= 4;
+    // (every table count since round 4: the many-table variants keep their float64 sums in LDS and run chunks as long as o = 2's; eight waves
+    // of them need 8 x 2 LIVE x 512 B of LDS — 128 KB at o = 5 — beside the chunk's science rows: one workgroup per CU, which is what this form runs)
+    const bool asym = e->kernel == AOG_KERNEL_MFMA && e->n_etiles >= 4 && !getenv("AOG_FUSED_4WAVE");
     e->mfma_waves = asym ? 8 : 4;
     e->mfma_heavy = asym ? 672 : 0;
     const int wp = e->mfma_waves / e->mfma_we;
     const int wg_y = (e->n_etiles + e->mfma_we - 1) / e->mfma_we;
     // P pixel chunks (proportional split of the tiles), 8 waves per CU when the batch allows
     int Pm = cfg->pixel_chunks > 0 ? cfg->pixel_chunks : std::max(1, (asym ? 256 : 256 * 2) / wg_y);
-    const int max_tpc = e->MRW > 8 ? aog::kTabF32Tiles * wp : 4096;   // fp32-only sums (many-table variants): bounded chunks
+    const int max_tpc = 4096;   // (every variant keeps float64 sums now — registers for o = 2, an LDS plane per wave beyond — so a chunk may be long)
     Pm = std::max(Pm, (e->n_ptiles + max_tpc - 1) / max_tpc);
     Pm = std::min(Pm, e->n_ptiles);
     e->mfma_chunks_x = Pm;
@@ -481,7 +473,6 @@ int aog_create(const aog_config* cfg, int device, aog_env** out) {
     e->host_flag_dev = static_cast<int*>(dp);
   }
   TRY_ALLOC(dev_alloc(e, &e->partials, e->partial_elems));
-  TRY_ALLOC(dev_alloc(e, &e->slab_reduced, (size_t)2 * 64 * e->Bp));   // [NS <= 58][Bp] float64 (k_reduce_slabs)
   if (cfg->atm_dynamic) {
     const size_t N2 = (size_t)cfg->n_pupil * cfg->n_pupil;
     TRY_ALLOC(dev_alloc(e, &e->psi_master, (size_t)e->B * N2));

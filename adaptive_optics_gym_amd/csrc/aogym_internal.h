@@ -171,7 +171,6 @@ struct aog_env {
   int next_noise_max_ext = 0;
   unsigned long long rng_seed = 1234;
   double* partials = nullptr;
-  double* slab_reduced = nullptr;   // single float64 slab [NS][Bp] after k_reduce_slabs
   size_t partial_elems = 0;
   // profiling of the fused kernel
   float* ret_acc = nullptr;      // caller-owned episode-return accumulator (aog_set_return_accumulator)

@@ -52,8 +52,11 @@ int launch_tab(aog_env* e, hipStream_t s) {
   const int wgs_per_xcd = g.pair ? round_up(chunks_per_xcd, 64 / g.wg_y) * g.wg_y : chunks_per_xcd * g.wg_y;
   dim3 grid(8 * wgs_per_xcd);
   const float ratio = (float)(e->cfg.wavelength_wfs / e->cfg.wavelength_sci);
-  const size_t lds_t = (size_t)e->mfma_tpc * 8 * 16 + ((A_PAD > 64 || e->ring_direct) ? (size_t)e->mfma_waves * (A_PAD / 16) * 2 * 64 * 16 : 0) +   // science rows (+ actuator operands)
+  const size_t lds_0 = (size_t)e->mfma_tpc * 8 * 16 + ((A_PAD > 64 || e->ring_direct) ? (size_t)e->mfma_waves * (A_PAD / 16) * 2 * 64 * 16 : 0) +   // science rows (+ actuator operands)
                        (e->ring_direct ? (size_t)e->mfma_waves * 32 * 36 * 4 : 0);                                             // (+ ring-direct transpose tiles)
+  g.acc_off = (int)((lds_0 + 15) / 16 * 16);
+  // many-table variants: float64 table sums per wave, [2 LIVE][64 lanes]
+  const size_t lds_t = g.acc_off + (aog::TabGeom<MRW>::kF64 ? 0 : (size_t)e->mfma_waves * 2 * aog::TabGeom<MRW>::kLiveRegs * 64 * sizeof(double));
   aog::DynPsi dyn{};
   if (e->ring_direct) {   // dynamic atmosphere: the screens come straight from the fp32 ring copy of the master screens
     dyn.ring = e->psi_ring;

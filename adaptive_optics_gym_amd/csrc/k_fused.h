@@ -101,6 +101,7 @@ struct MfmaGeom {
   int skew;   // start-up skew of every second workgroup, x 16 cycles
   int pair;   // 1: the two workgroups that share a CU walk the SAME pixel chunk (different env groups), see fused_wg_map
   int heavy;  // > 0: asymmetric wave pairs, sub-chunk 0 takes heavy / 1024 of a chunk's tiles (see k_fused_tab); 0: interleaved
+  int acc_off;   // many-table variants: byte offset of the float64 table-sum accumulators in the workgroup's dynamic LDS (behind everything else)
   int dev;    // developer experiments (AOG_DEV builds only; 0 in the product)
   long long* timeline;   // AOG_DEV builds: per-wave time stamps (wall_clock64, 10 ns ticks) [wave][8], or null
 };
@@ -342,6 +343,15 @@ __global__ __launch_bounds__(512, 2) void k_fused_tab(const f16x8* __restrict__ 
 #endif
   f32x16 Dc = zero16, Ds = zero16;          // table sums (cos, sin), rows by register
   float sc_c = 0.f, sc_s = 0.f;             // science-table sums of this lane's pixels
+  // Many-table variants (o >= 3): 2 x LIVE live accumulator registers per lane are too many to mirror in float64 registers, so the float64
+  // sums live in this wave's own plane of LDS, [2 LIVE][64 lanes], and the fp32 registers are folded into it every kTabF32Tiles tiles (the fp32
+  // run length the tolerances were set for).  Round 3 instead cut the pixel range into chunks of <= 13 tiles per wave and wrote a float slab
+  // per chunk (124+ slabs, a fold kernel, and every wave's 5 us of set-up amortised over 13 tiles: 267 us per 4096 envs at o = 5 against 4 x 52).
+  double* lds_acc = reinterpret_cast<double*>(reinterpret_cast<char*>(lds_sci) + geo.acc_off) + (size_t)wave * 2 * LIVE * 64 + lane;
+  if constexpr (!F64) {
+#pragma unroll
+    for (int a = 0; a < 2 * LIVE; ++a) lds_acc[a * 64] = 0.0;
+  }
   double acc_t[F64 ? 2 * LIVE : 1];
   double acc_sc = 0.0, acc_ss = 0.0;
 #pragma unroll
@@ -436,6 +446,15 @@ __global__ __launch_bounds__(512, 2) void k_fused_tab(const f16x8* __restrict__ 
         });
       }
     };
+    auto fold_lds = [&] {   // (!F64) fp32 table sums of the last run of tiles -> this wave's float64 plane in LDS
+      static_for<LIVE>([&](auto ac) {
+        constexpr int a = decltype(ac)::v;
+        lds_acc[(2 * a) * 64] += (double)Dc[a];
+        lds_acc[(2 * a + 1) * 64] += (double)Ds[a];
+        Dc[a] = 0.f;
+        Ds[a] = 0.f;
+      });
+    };
     // stage: vector work of tile t (accumulator D, screen P); PREV: the previous tile still owes its step-1 table MFMAs; NEXT: the next tile
     // gets its phase contraction into Dn (its screen is already in the other screen set)
     auto stage = [&](auto prevc, auto nextc, int i, int t, f32x16& D, f32x16& Dn, f32x16& P) {
@@ -489,6 +508,9 @@ __global__ __launch_bounds__(512, 2) void k_fused_tab(const f16x8* __restrict__ 
         else load_psi(IC<2>{}, IC<2>{}, P, t + 2 * stride);
       }
       if ((i % kFlushTiles) == kFlushTiles - 1) flush();
+      if constexpr (!F64) {
+        if ((i % kTabF32Tiles) == kTabF32Tiles - 1) fold_lds();
+      }
     };
     if (n == 1) {
       stage(IC<0>{}, IC<0>{}, 0, first, X, Y, Pa);
@@ -512,6 +534,7 @@ __global__ __launch_bounds__(512, 2) void k_fused_tab(const f16x8* __restrict__ 
     // the last tile's step-1 table MFMAs
     static_for<6>([&](auto kc) { tab_one(kc, ta[2], ta[3], c1, l1, s1, m1); });
     flush();
+    if constexpr (!F64) fold_lds();
   }
 #ifdef AOG_DEV
   if (geo.timeline) { asm volatile("" ::"v"(acc_sc)); tl[3] = wall_clock64(); }
@@ -533,20 +556,19 @@ __global__ __launch_bounds__(512, 2) void k_fused_tab(const f16x8* __restrict__ 
       out[(size_t)(2 * MRW + 1) * geo.Bp] = vs;
     }
   } else {
-    // the sums of these variants are fp32 anyway: the slabs are written (and read by the epilogue) as float, half the traffic
-    float* out = reinterpret_cast<float*>(partials) + (size_t)chunk * NS * geo.Bp + (size_t)etile * 32 + (lane & 31);
+    double* out = partials + (size_t)chunk * NS * geo.Bp + (size_t)etile * 32 + (lane & 31);
     static_for<LIVE>([&](auto ac) {
       constexpr int a = decltype(ac)::v;
       const int m = (a & 3) + 8 * (a >> 2) + 4 * h;
       if (m < MRW) {
-        out[(size_t)(2 * m) * geo.Bp] = Dc[a];
-        out[(size_t)(2 * m + 1) * geo.Bp] = Ds[a];
+        out[(size_t)(2 * m) * geo.Bp] = lds_acc[(2 * a) * 64];
+        out[(size_t)(2 * m + 1) * geo.Bp] = lds_acc[(2 * a + 1) * 64];
       }
     });
     const double vc = acc_sc + __shfl_down(acc_sc, 32, 64), vs = acc_ss + __shfl_down(acc_ss, 32, 64);
     if (h == 0) {
-      out[(size_t)(2 * MRW) * geo.Bp] = (float)vc;
-      out[(size_t)(2 * MRW + 1) * geo.Bp] = (float)vs;
+      out[(size_t)(2 * MRW) * geo.Bp] = vc;
+      out[(size_t)(2 * MRW + 1) * geo.Bp] = vs;
     }
   }
 #ifdef AOG_DEV

@@ -183,7 +183,6 @@ struct EpilogueArgs {
   int32_t* t_render;
   float* ret_acc;   // nullable: episode-return accumulator [B] (aog_set_return_accumulator)
   int B, Bp, n_chunks, MRW, MRS, MRW_used, MRS_used, n_obs, n_fiber, reward_type, has_thr, max_steps, is_step;
-  int partials_f32;   // slabs hold float (table-MFMA variants with fp32-only sums) instead of double
   double thr, ssim_peak, ssim_alpha;
 };
 
@@ -207,24 +206,6 @@ __device__ inline double ssim_1d_delta_ref(const double* x, int stride, int n, d
     ++cnt;
   }
   return sum / cnt;
-}
-
-// Pre-reduction of float slabs (table-MFMA variants write many short chunks): out[s][env] = sum_c part[c][s][env], one thread per
-// (s, env), envs along the lanes (256-B rows), eight independent loads in flight.  The epilogue then sees a single float64 slab.
-__global__ __launch_bounds__(256) void k_reduce_slabs(const float* __restrict__ part, double* __restrict__ out, int n_chunks, int NS, int Bp) {
-  const int env = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int s = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (env >= Bp || s >= NS) return;
-  const size_t cstride = (size_t)NS * Bp;
-  const float* src = part + (size_t)s * Bp + env;
-  double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  int c = 0;
-  for (; c + 7 < n_chunks; c += 8) {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) a[u] += (double)src[(size_t)(c + u) * cstride];
-  }
-  for (; c < n_chunks; ++c) a[0] += (double)src[(size_t)c * cstride];
-  out[(size_t)s * Bp + env] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
 }
 
 // block = 16 envs x 16 sum slots x 4 chunk groups (1024 threads, grid = Bp / 16: 64 workgroups at B = 1024):
@@ -265,14 +246,7 @@ __device__ __forceinline__ void epilogue_body(const EpilogueArgs& p, int block, 
   for (int s = q; s < NS; s += 16) {
     double a[4] = {0, 0, 0, 0};
     int c = cq;
-    if (p.partials_f32) {
-      const float* src = reinterpret_cast<const float*>(p.partials) + (size_t)s * p.Bp + env;
-      for (; c + 3 * kEpiGroups < p.n_chunks; c += 4 * kEpiGroups) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) a[u] += (double)src[(size_t)(c + kEpiGroups * u) * cstride];
-      }
-      for (; c < p.n_chunks; c += kEpiGroups) a[0] += (double)src[(size_t)c * cstride];
-    } else {
+    {
       const double* src = p.partials + (size_t)s * p.Bp + env;
       for (; c + 3 * kEpiGroups < p.n_chunks; c += 4 * kEpiGroups) {
 #pragma unroll
