@@ -459,7 +459,7 @@ int aog_create(const aog_config* cfg, int device, aog_env** out) {
   TRY_ALLOC(dev_alloc(e, &e->act16, (size_t)e->n_etiles * e->A_pad * 32 * 2));
   TRY_ALLOC(dev_alloc(e, &e->t_render, e->B));
   TRY_ALLOC(dev_alloc(e, &e->screen_gen, e->B));
-  TRY_ALLOC(dev_alloc(e, &e->dev_status, 16));
+  TRY_ALLOC(dev_alloc(e, &e->dev_status, 16 + 4 * 2048));   // (16 status words; the rest: developer read-outs)
   {
     void* hp = nullptr;
     void* dp = nullptr;
@@ -908,8 +908,17 @@ int aog_device_status(aog_env* e, int32_t* status_out) {
   *status_out = v[0] | *static_cast<volatile int*>(e->host_flag);
 #ifdef AOG_DEV
   if (getenv("AOG_X8_DEV") && (atoi(getenv("AOG_X8_DEV")) & 1024)) {
-    fprintf(stderr, "[aogym] k_x8_product: cycles per step max %d min %d, most steps %d, workgroups %d; one step of one consumer: operand wait %d, barrier %d, reads + matrix issue %d; of one loader: load wait %d, LDS writes issued %d, loads issued %d, LDS writes done %d, barrier %d\n", v[8], v[9], v[10], v[11], v[13], v[14], v[15], v[2], v[3], v[4], v[5], v[6]);
-    const int z6[6] = {0, 0, 0, 0, 0, 0};
+    fprintf(stderr, "[aogym] k_x8_product: cycles per step max %d min %d, most steps %d, workgroups %d; 10 ns ticks from the first workgroup's start: last start %d, last loop end %d, last end %d; mean start-to-loop-end %d\n", v[8], v[9], v[10], v[11], v[3] - v[2], v[4] - v[2], v[5] - v[2], v[11] ? v[6] / v[11] : 0);
+    if (const char* path = getenv("AOG_X8_DEV_DUMP")) {   // per-workgroup records: steps | k << 8 | phase << 12 | xcc << 16 | hw cu/sh/se << 20, cycles per step, start, loop end (10 ns ticks)
+      static int rec[4 * 2048];
+      HIP_TRY(hipMemcpy(rec, e->dev_status + 16, sizeof rec, hipMemcpyDeviceToHost));
+      if (FILE* f = fopen(path, "w")) {
+        for (int w = 0; w < v[12] && w < 2048; ++w)
+          fprintf(f, "%d %d %d %d %d %d %d %d\n", rec[4 * w] & 255, (rec[4 * w] >> 8) & 15, (rec[4 * w] >> 12) & 1, (rec[4 * w] >> 16) & 15, (rec[4 * w] >> 20) & 255, rec[4 * w + 1], rec[4 * w + 2] - v[2], rec[4 * w + 3] - v[2]);
+        fclose(f);
+      }
+    }
+    const int z6[6] = {1 << 30, 0, 0, 0, 0, 0};
     HIP_TRY(hipMemcpy(e->dev_status + 2, z6, sizeof z6, hipMemcpyHostToDevice));
     const int init[8] = {0, 1 << 30, 0, 0, 0, 0, 0, 0};
     HIP_TRY(hipMemcpy(e->dev_status + 8, init, sizeof init, hipMemcpyHostToDevice));

@@ -162,9 +162,10 @@ struct aog_env {
   int32_t* x8_slot = nullptr;
   int32_t* x8_list = nullptr;
   int32_t* x8_tile_k = nullptr;
+  int32_t* x8_items = nullptr;
   int8_t* x8_Z8 = nullptr;
   double* x8_rec = nullptr;
-  int x8_tiles64_max = 0, x8_slots_max = 0, x8_KsTot_max = 0, x8_rt_max = 0;
+  int x8_tiles64_max = 0, x8_slots_max = 0, x8_KsTot_max = 0, x8_rt_max = 0, x8_items_max = 0;
   int near_v = 0, near_h = 0;    // stencil samples in the two newest slices come first in the uploaded order (aog_upload_layer)
   double sqrt_cn2 = 0, pitch = 0, delta_t = 0;
   const double* next_noise = nullptr;

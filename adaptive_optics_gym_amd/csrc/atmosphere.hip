@@ -49,8 +49,10 @@ int x8_ensure_buffers(aog_env* e) {
   if ((rc = dev_alloc(e, &e->x8_slot, (size_t)2 * e->B)) != AOG_OK) return rc;
   if ((rc = dev_alloc(e, &e->x8_list, (size_t)2 * e->x8_slots_max)) != AOG_OK) return rc;
   if ((rc = dev_alloc(e, &e->x8_tile_k, (size_t)2 * e->x8_tiles64_max)) != AOG_OK) return rc;
+  e->x8_items_max = round_up(e->x8_tiles64_max * ((rt_max + 1) / 2), 256);   // every (64-env tile, row pair): the plan's list is dense
+  if ((rc = dev_alloc(e, &e->x8_items, (size_t)2 * e->x8_items_max)) != AOG_OK) return rc;
   if ((rc = dev_alloc(e, &e->x8_rec, (size_t)4 * e->x8_slots_max)) != AOG_OK) return rc;
-  if ((rc = dev_alloc(e, &e->x8_Z8, (size_t)2 * e->x8_tiles64_max * ks_max * 5 * 1024)) != AOG_OK) return rc;   // (zeroed: unused columns hold zeros, not junk)
+  if ((rc = dev_alloc(e, &e->x8_Z8, ((size_t)2 * e->x8_tiles64_max * ks_max + aog::kX8PadSteps) * 5 * 1024)) != AOG_OK) return rc;   // (zeroed: unused columns hold zeros, not junk)
   return AOG_OK;
 }
 
@@ -80,6 +82,8 @@ int x8_evolve(aog_env* e, hipStream_t s, long long step_index) {
   p.slot = e->x8_slot;
   p.list = e->x8_list;
   p.tile_k = e->x8_tile_k;
+  p.items = e->x8_items;
+  p.items_max = e->x8_items_max;
   p.tiles64_max = e->x8_tiles64_max;
   p.slots_max = e->x8_slots_max;
   p.Z8 = e->x8_Z8;
@@ -90,7 +94,7 @@ int x8_evolve(aog_env* e, hipStream_t s, long long step_index) {
   if (const char* v = getenv("AOG_X8_DEV")) p.dev = atoi(v);
 #endif
   hipLaunchKernelGGL(aog::k_x8_plan, dim3(1), dim3(aog::kX8PlanThreads), 0, s, p);
-  const dim3 gprep(e->B), bprep(round_up(2 * e->x8_KsTot_max, 64)), gprod(round_up((e->x8_rt_max + 1) / 2, 8), e->x8_tiles64_max);
+  const dim3 gprep(e->B), bprep(round_up(2 * e->x8_KsTot_max, 64)), gprod(e->x8_items_max);
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_x8_product), aog::kX8ProductLds, e->device)) return rc;
   for (int phase = 0; phase < 2; ++phase) {
     hipLaunchKernelGGL(aog::k_x8_prepare, gprep, bprep, 0, s, p, phase);
@@ -419,7 +423,8 @@ int aog_upload_layer_composite(aog_env* e, const aog_layer_composite* t) {
     if (!(amax > 0.0) || !(bmax > 0.0) || !std::isfinite(amax) || !std::isfinite(bmax)) return fail(AOG_ERR_INVALID, "aog_upload_layer_composite: empty or non-finite operator");
     const int log2_qa = std::ilogb(amax) + 1 - 34, log2_qb = std::ilogb(bmax) + 1 - 34;   // |A| / qa, |B| / qb < 2^34 (5 digits each)
     std::vector<int32_t> yx((size_t)KsA * 32);
-    std::vector<int8_t> A8((size_t)RT * KsA * 5 * 1024, 0), B8((size_t)RT * KsB * 5 * 1024, 0);
+    const int KsT = KsA + KsB + aog::kX8PadSteps;
+    std::vector<int8_t> T8((size_t)RT * KsT * 5 * 1024, 0);
     std::vector<double> r1((size_t)RT * 32, 0.0), r2((size_t)RT * 32, 0.0);
     double sx = 0.0, sxx = 0.0;
     std::vector<double> xa((size_t)Uk);
@@ -441,8 +446,8 @@ int aog_upload_layer_composite(aog_env* e, const aog_layer_composite* t) {
           s2 += (long double)a * xa[cc];
           int8_t d[5];
           x8_digits_host(std::llrint(std::ldexp(a, -log2_qa)), 5, d);
-          const size_t base = (((size_t)rt * KsA + (cc >> 5)) * 5) * 1024 + (size_t)((row & 31) + 32 * ((cc & 31) >> 4)) * 16 + (cc & 15);
-          for (int dg = 0; dg < 5; ++dg) A8[base + (size_t)dg * 1024] = d[dg];
+          const size_t base = (((size_t)rt * KsT + (cc >> 5)) * 5) * 1024 + (size_t)((row & 31) + 32 * ((cc & 31) >> 4)) * 16 + (cc & 15);
+          for (int dg = 0; dg < 5; ++dg) T8[base + (size_t)dg * 1024] = d[dg];
         }
         r1[row] = (double)s1;
         r2[row] = (double)s2;
@@ -454,22 +459,21 @@ int aog_upload_layer_composite(aog_env* e, const aog_layer_composite* t) {
             const int cc = (jj - 1) * Np + ii;
             int8_t d[5];
             x8_digits_host(std::llrint(std::ldexp(b, -log2_qb)), 5, d);
-            const size_t base = (((size_t)rt * KsB + (cc >> 5)) * 5) * 1024 + (size_t)((row & 31) + 32 * ((cc & 31) >> 4)) * 16 + (cc & 15);
-            for (int dg = 0; dg < 5; ++dg) B8[base + (size_t)dg * 1024] = d[dg];
+            const size_t base = (((size_t)rt * KsT + KsA + (cc >> 5)) * 5) * 1024 + (size_t)((row & 31) + 32 * ((cc & 31) >> 4)) * 16 + (cc & 15);
+            for (int dg = 0; dg < 5; ++dg) T8[base + (size_t)dg * 1024] = d[dg];
           }
       }
     aog::X8Table& tb = h->tab[t->axis][k];
     tb = aog::X8Table{};
     int32_t* d_yx = nullptr;
-    int8_t *d_A8 = nullptr, *d_B8 = nullptr;
+    int8_t* d_T8 = nullptr;
     double *d_r1 = nullptr, *d_r2 = nullptr;
     if ((rc = up(&d_yx, yx.data(), yx.size())) != AOG_OK) return rc;
-    if ((rc = up(&d_A8, A8.data(), A8.size())) != AOG_OK) return rc;
-    if ((rc = up(&d_B8, B8.data(), B8.size())) != AOG_OK) return rc;
+    if ((rc = up(&d_T8, T8.data(), T8.size())) != AOG_OK) return rc;
     if ((rc = up(&d_r1, r1.data(), r1.size())) != AOG_OK) return rc;
     if ((rc = up(&d_r2, r2.data(), r2.size())) != AOG_OK) return rc;
-    tb.yx = d_yx; tb.A8 = d_A8; tb.B8 = d_B8; tb.r1 = d_r1; tb.r2 = d_r2;
-    tb.k = k; tb.U = Uk; tb.KsA = KsA; tb.KsB = KsB; tb.RT = RT; tb.Np = Np;
+    tb.yx = d_yx; tb.T8 = d_T8; tb.r1 = d_r1; tb.r2 = d_r2;
+    tb.k = k; tb.U = Uk; tb.KsA = KsA; tb.KsB = KsB; tb.KsT = KsT; tb.RT = RT; tb.Np = Np;
     tb.log2_qa = log2_qa;
     tb.log2_cn = log2_qa - log2_qb;
     tb.ez_floor = 3 - tb.log2_cn;

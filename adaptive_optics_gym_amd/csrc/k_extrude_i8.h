@@ -39,15 +39,16 @@ typedef int i32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kX8Levels = 6;        // product levels l = s + t kept: 0 .. 5 (19 of the 25 digit pairs)
 constexpr int kX8MaxK = 8;          // composite operators are built for k = 1 .. kcap <= 8 shifts per axis and step
+constexpr int kX8PadSteps = 3;      // zero steps behind every table row tile (and behind Z8): the product runs its steps in fours
 
 // one composite operator (axis, k) in device memory
 struct X8Table {
   const int32_t* yx;      // [U_pad] union stencil (sy << 16 | sx) on the screen hcipy's _extrude sees (rotated for 'top' / 'right'); padding repeats entry 0
-  const int8_t* A8;       // [RT][KsA][5][64][16] digits of A_k as MFMA A operands: lane (row & 31, k-half g), byte b <-> column 32 ks + 16 g + b
-  const int8_t* B8;       // [RT][KsB][5][64][16] digits of sqrt(Cn^2) B_k
+  const int8_t* T8;       // [RT][KsT][5][64][16] digits of [A_k | sqrt(Cn^2) B_k | kX8PadSteps zero steps] as MFMA A operands: lane (row & 31, k-half g), byte b <-> column 32 ks + 16 g + b
   const double* r1;       // [RT * 32] A_k 1   (float64, exact piston response)
   const double* r2;       // [RT * 32] A_k x   (x = along-coordinate of the stencil sample - (N - 1) / 2)
   int k, U, KsA, KsB, RT; // U union size; k-steps (of 32) of the stencil and of the normals; row tiles (of 32 rows) = k Np / 32
+  int KsT;                // KsA + KsB + kX8PadSteps
   int Np;                 // rows per shift block: N rounded up to 64 (row (j - 1) Np + i = sample i of the slice shift j creates; i >= N: zero rows)
   int log2_qa;            // qa = 2^log2_qa
   int log2_cn;            // qn = qz * 2^log2_cn  (= qa / qb)
@@ -75,12 +76,13 @@ struct X8Args {
   int32_t* slot;             // [2][B] phase (0 = x shifts, 1 = y shifts) -> slot = tile32 * 32 + column, -1 = no shift in that phase
   int32_t* list;             // [2][slots_max] slot -> env, -1 = empty
   int32_t* tile_k;           // [2][tiles64_max] k of each 64-env tile, 0 = unused
-  int tiles64_max, slots_max;
+  int32_t* items;            // [2][items_max] workgroup -> (64-env tile | row pair << 16) of k_x8_product, heaviest first, -1 = none
+  int tiles64_max, slots_max, items_max;
   // prepared operands
   int8_t* Z8;                // [tiles32_max][KsTot_max][5][64][16]
   int KsTot_max;
   double* rec;               // [slots_max][4]: scale (qa qz 128^3), c0, c1, origin of the screen the phase reads
-  int dev;                   // AOG_DEV builds only (AOG_X8_DEV in the environment): 1 no matrix instructions, 2 no operand loads, 4 no result stores, 16 .. 128 prepare-kernel stages off, 1024 cycles per step read-out
+  int dev;                   // AOG_DEV builds only (AOG_X8_DEV in the environment): 4 no result stores, 16 .. 128 prepare-kernel stages off, 1024 cycles per step read-out
   int* status;               // sticky error word (bit 2: a stencil sample or a normal left its fixed-point range)
 };
 
@@ -92,8 +94,10 @@ __global__ __launch_bounds__(kX8PlanThreads) void k_x8_plan(X8Args p) {
   __shared__ int wcnt[2][NC][NW];      // per wave and class: envs of this pass
   __shared__ int base[2][NC];          // slots handed out so far per class
   __shared__ int total[2][NC];
+  __shared__ int tile0[2][NC], ntile[2][NC], grp0[2][NC + 1];   // first tile, tiles and first group (row pair) of each class
   if (tid < 2 * NC) { (&base[0][0])[tid] = 0; (&total[0][0])[tid] = 0; }
   for (int i = tid; i < 2 * p.slots_max; i += kX8PlanThreads) p.list[i] = -1;
+  for (int i = tid; i < 2 * p.items_max; i += kX8PlanThreads) p.items[i] = -1;
   __syncthreads();
   // pass A: shifts and class totals (tile bases need the totals of every class before any slot can be handed out)
   for (int e0 = 0; e0 < p.B; e0 += kX8PlanThreads) {
@@ -124,14 +128,42 @@ __global__ __launch_bounds__(kX8PlanThreads) void k_x8_plan(X8Args p) {
   }
   __syncthreads();
   if (tid < 2) {   // tile bases per class (in 64-env tiles), tile -> k
-    int t = 0;
+    int t = 0, g = 0;
     for (int k = 1; k <= p.kcap; ++k) {
       base[tid][k] = t * 64;
       const int nt = (total[tid][k] + 63) / 64;
       for (int i = 0; i < nt; ++i) p.tile_k[tid * p.tiles64_max + t + i] = k;
+      tile0[tid][k] = t;
+      ntile[tid][k] = nt;
+      grp0[tid][k] = g;
+      if (nt) g += p.tables[(tid == 0 ? 1 : 0) * (kX8MaxK + 1) + k].RT / 2;
       t += nt;
     }
+    for (int k = p.kcap + 1; k <= NC; ++k) grp0[tid][k] = g;
     for (; t < p.tiles64_max; ++t) p.tile_k[tid * p.tiles64_max + t] = 0;
+  }
+  __syncthreads();
+  // the product's workgroups: one per (64-env tile, row pair), listed class by class (most shifts first), within a class by row pair (last,
+  // i.e. longest, first) and then tile, and that list dealt to the XCDs in runs of 32 (workgroup L runs on XCD L mod 8; 32 CUs each): a run is a
+  // rectangle of tiles x row pairs, so an XCD's L2 serves each table row to all the class's tiles and each env tile's operands to several row
+  // pairs — operand traffic over the fabric, not matrix work, is what bounds this kernel when every workgroup streams its own copies (measured:
+  // 2500 .. 3600 cycles per double step for the workgroups of a one-tile class against 1300 where operands are shared).  Runs go to the XCDs
+  // in snake order (0..7, 7..0, ...) so that a second round evens out the first.
+  {
+    const int ph = tid >> 9, t0 = tid & 511;
+    for (int k = p.kcap; k >= 1; --k) {
+      const int nt = ntile[ph][k];
+      if (nt == 0) continue;
+      const int nrp = grp0[ph][k + 1] - grp0[ph][k];
+      int before = 0;
+      for (int k2 = p.kcap; k2 > k; --k2) before += (grp0[ph][k2 + 1] - grp0[ph][k2]) * ntile[ph][k2];
+      for (int i = t0; i < nrp * nt; i += 512) {
+        const int rp = nrp - 1 - i / nt, j = i % nt, pos = before + i;
+        const int run = pos >> 5, round = run >> 3, x = (round & 1) ? 7 - (run & 7) : (run & 7), L = ((round << 5) + (pos & 31)) * 8 + x;
+        if (L < p.items_max) p.items[ph * p.items_max + L] = (tile0[ph][k] + j) | (rp << 16);
+        else atomicOr(p.status, 4);   // (cannot happen: items_max covers every tile x row pair)
+      }
+    }
   }
   __syncthreads();
   // pass B: slots in env order within each class (deterministic, though no result depends on it)
@@ -358,78 +390,53 @@ __device__ __forceinline__ void x8_store(const X8Args& p, int env, int N, int py
   }
 }
 
-// ---- product: workgroup = 64 rows x 64 envs = 2 x 2 tiles of 32 x 32.  FOUR CONSUMER waves (one per tile and SIMD: 19 digit products per
-// 32-deep step into six int32 accumulators, the next step's operands read from LDS while this step's matrix instructions run) and FOUR LOADER
-// waves (one per SIMD: the 20 one-KiB operand blocks of a step — 2 row tiles x 5 digits + 2 env tiles x 5 — go global -> LDS by LDS-DMA into a
-// ring of kX8Stages stages, kX8Stages - 1 steps ahead; counted vmcnt waits).  One raw s_barrier per step hands a landed stage to the consumers
-// and a drained one back to the loaders.  Heaviest workgroups (most shifts, last shift block) are dispatched first.
-// How it got here (B = 1024, N = 256, v = 10 m/s: ~290 workgroups on 256 CUs, i.e. ONE wave-tile per SIMD — nothing to hide latency behind;
-// profiles/HISTORY.md): with each wave loading, reading and multiplying in turn a step took ~1100-1500 cycles against 608 of matrix
-// instructions (LDS-DMA issue ~60-100 cycles apiece, the 40-80 KB burst of LDS reads behind the barrier, then the matrix work, in series), a
-// deeper ring or cache-hot operands changed nothing, and splitting a tile's products by level over two waves of a SIMD only doubled the LDS reads.
+// ---- product: workgroup = 64 rows x 64 envs = 2 x 2 tiles of 32 x 32, EIGHT waves: wave = (tile, half); the two waves of a tile sit on the same
+// SIMD and share the tile's 32-deep steps (even / odd), each into its own six int32 accumulators (19 digit products per step) — summed at the
+// end, exactly, so the split changes no bit.  Every wave moves its share of its half's operand blocks (5 of the 20 one-KiB blocks of a step: 2
+// row tiles x 5 digits + 2 env tiles x 5) global -> LDS by LDS-DMA, kX8Stages - 1 double steps ahead (counted vmcnt waits), reads the NEXT
+// step's ten operand blocks from LDS and issues the loads of a later stage in between this step's matrix instructions; one raw s_barrier per
+// double step.  Workgroups come from the plan's list (heaviest first, balanced over the XCDs).
+// How it got here (B = 1024, N = 256, v = 10 m/s: ~250 workgroups per phase on 256 CUs — one tile per SIMD; profiles/HISTORY.md): a tile's
+// steps are a serial chain on one SIMD (up to 81 x 608 cycles of matrix instructions) and with one wave per SIMD nothing hides a stall: four
+// consumer + four loader waves ran 950 .. 1800 cycles per step (measured per workgroup) and the longest chain set the launch time (67 .. 78 us
+// against ~18 us of matrix work).  Two waves per SIMD halve the chain and fill each other's stalls.
 constexpr int kX8Blocks = 20;   // 1-KiB operand blocks per 32-deep step
-constexpr int kX8Sub = 2;       // steps per LDS stage = per barrier (the barrier's bubble in the matrix stream, ~300 cycles, is paid once per stage)
-constexpr int kX8Stages = 3;    // an LDS-DMA lands ~1.1 us after its issue (MI355X_MICROARCH.md, ldsdma-fill): two stages = four steps of lead
-constexpr int kX8ProductLds = kX8Stages * kX8Sub * kX8Blocks * 1024;   // (the epilogue's 32 KB transposition area lives in the ring)
+constexpr int kX8Halves = 2;    // waves per tile = steps per stage
+constexpr int kX8Stages = 3;    // an LDS-DMA lands ~1.1 us after its issue (MI355X_MICROARCH.md, ldsdma-fill): loads run two double steps ahead
+constexpr int kX8ProductLds = kX8Stages * kX8Halves * kX8Blocks * 1024;   // (the epilogue's exchange / transposition areas live in the ring)
 
 __global__ __launch_bounds__(512, 2) void k_x8_product(X8Args p, int phase) {
   extern __shared__ __attribute__((aligned(1024))) int8_t lds8[];   // kX8ProductLds bytes
-  // grid.x = row pairs (a multiple of 8: workgroups that read the same table rows share an XCD and its L2 under round-robin dispatch — speed
-  // only), grid.y = 64-env tiles; both reversed: classes of more shifts sit in later tiles and later row pairs run more steps
-  const int tile64 = (int)gridDim.y - 1 - (int)blockIdx.y;
+  const int item = p.items[phase * p.items_max + (int)blockIdx.x];
+  if (item < 0) return;
+  const int tile64 = item & 0xffff, rt0 = 2 * (item >> 16);
   const int k = p.tile_k[phase * p.tiles64_max + tile64];
-  if (k == 0) return;
   const X8Table& tb = p.tables[(phase == 0 ? 1 : 0) * (kX8MaxK + 1) + k];
-  const int rt0 = 2 * ((int)gridDim.x - 1 - (int)blockIdx.x);
-  if (rt0 >= tb.RT) return;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;   // (scalar: everything selected by it is wave-uniform)
-  const int tile = wave & 3;
-  const bool loader = wave >= 4;
+  const int t_wg0 = (AOG_X8_DEV(p) & 1024) ? (int)(__builtin_amdgcn_s_memrealtime() & 0x3fffffff) : 0;   // 10 ns ticks
+  const int tile = wave & 3, half = wave >> 2;
   const int rtl = tile & 1, ctl = tile >> 1;
-  const int N = p.N, KsA = tb.KsA, KsB = tb.KsB;
+  const int N = p.N;
   const int shift = rt0 / (tb.Np / 32);                         // both row tiles lie in shift block `shift` + 1 (Np / 32 is even)
-  const int n_steps = KsA + (shift + 1) * (tb.Np / 32);         // normals of later shifts do not reach these rows
-  const int n_stages = (n_steps + kX8Sub - 1) / kX8Sub;
+  const int n_steps = tb.KsA + (shift + 1) * (tb.Np / 32);         // normals of later shifts do not reach these rows
+  // double steps (this wave's step of double step q is 2 q + half), an even count: the steps past n_steps multiply by exact zeros — normals of
+  // later shifts (their B_k blocks are zero for these rows) or the table's zero padding
+  const int n_q = ((n_steps + 3) >> 2) << 1;
+  const int st_last = tb.KsT - 1;
 
-  if (loader) {
-    const int8_t* A8 = tb.A8;
-    const int8_t* B8 = tb.B8;
-    const int8_t* Z0 = p.Z8 + (((size_t)(2 * tile64) * p.KsTot_max * 5) << 10);
-    const int8_t* Z1 = p.Z8 + (((size_t)(2 * tile64 + 1) * p.KsTot_max * 5) << 10);
-    // block `blk` of step `st`: 0..9 = digits of the two row tiles of A_k (st < KsA) or of sqrt(Cn^2) B_k, 10..19 = digits of the two env tiles;
-    // loader w moves blocks w, w + 4, ..., w + 16
-    auto issue = [&](int stage, int buf) {
+  // block `blk` of a step: 0..9 = digits of the two row tiles of [A_k | sqrt(Cn^2) B_k], 10..19 = digits of the two env tiles; this wave moves
+  // blocks tile, tile + 4, ..., tile + 16 of its own half's step.  Every block advances 5 KiB per step.
+  const int8_t* src0[5];
 #pragma unroll
-      for (int sub = 0; sub < kX8Sub; ++sub) {
-        const int st = min(stage * kX8Sub + sub, n_steps - 1);   // (past the end: a harmless re-load keeps the vmcnt arithmetic uniform)
-#pragma unroll
-        for (int r = 0; r < 5; ++r) {
-          const int blk = 4 * r + tile, h = blk >= 10 ? (blk - 10) / 5 : blk / 5, dgt = blk % 5;
-          const int8_t* src;
-          if (blk >= 10) src = (h ? Z1 : Z0) + (((size_t)st * 5 + dgt) << 10);
-          else if (st < KsA) src = A8 + ((((size_t)(rt0 + h) * KsA + st) * 5 + dgt) << 10);
-          else src = B8 + ((((size_t)(rt0 + h) * KsB + (st - KsA)) * 5 + dgt) << 10);
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (lane << 4)),
-                                           (__attribute__((address_space(3))) void*)(&lds8[((buf * kX8Sub + sub) * kX8Blocks + blk) * 1024]), 16, 0, 0);
-        }
-      }
-    };
-#pragma unroll
-    for (int q = 0; q < kX8Stages; ++q) issue(q, q);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * kX8Sub * (kX8Stages - 1)) : "memory");   // stage 0 has landed
-    __builtin_amdgcn_s_barrier();
-    int buf = 0;
-    for (int q = 0; q < n_stages; ++q) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * kX8Sub * (kX8Stages - 2)) : "memory");   // this loader's blocks of stage q + 1 have landed
-      __builtin_amdgcn_s_barrier();   // the consumers are done reading stage q (they read its second step's operands during its first step) ...
-      asm volatile("" ::: "memory");
-      issue(q + kX8Stages, buf);      // ... whose buffer takes stage q + kX8Stages
-      buf = buf + 1 == kX8Stages ? 0 : buf + 1;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the re-loads past the end)
-    __syncthreads();                                     // (the consumers' epilogue reuses the ring)
-    return;
+  for (int r = 0; r < 5; ++r) {
+    const int blk = 4 * r + tile, h = blk >= 10 ? (blk - 10) / 5 : blk / 5, dgt = blk % 5;
+    src0[r] = blk >= 10 ? p.Z8 + ((((size_t)(2 * tile64 + h) * p.KsTot_max) * 5 + dgt) << 10) : tb.T8 + ((((size_t)(rt0 + h) * tb.KsT) * 5 + dgt) << 10);
   }
+  auto issue1 = [&](int stage, int buf, int r) {
+    const unsigned off = (unsigned)min(stage * kX8Halves + half, st_last) * 5120u + ((unsigned)lane << 4);   // (past the end: a harmless re-load keeps the vmcnt arithmetic uniform)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src0[r] + off),
+                                     (__attribute__((address_space(3))) void*)(&lds8[((buf * kX8Halves + half) * kX8Blocks + 4 * r + tile) * 1024]), 16, 0, 0);
+  };
 
   i32x16 acc[kX8Levels];
 #pragma unroll
@@ -437,111 +444,165 @@ __global__ __launch_bounds__(512, 2) void k_x8_product(X8Args p, int phase) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[l][r] = 0;
   i32x4 a[5], z[5], an[5], zn[5];
-  auto read_ops = [&](int slot, i32x4 (&ao)[5], i32x4 (&zo)[5]) {   // slot = stage buffer * kX8Sub + step within the stage
-    const int8_t* sb = &lds8[slot * kX8Blocks * 1024];
-#pragma unroll
-    for (int dgt = 0; dgt < 5; ++dgt) {
-      ao[dgt] = *reinterpret_cast<const i32x4*>(sb + (rtl * 5 + dgt) * 1024 + (lane << 4));
-      zo[dgt] = *reinterpret_cast<const i32x4*>(sb + (10 + ctl * 5 + dgt) * 1024 + (lane << 4));
-    }
-  };
-  __builtin_amdgcn_s_barrier();   // stage 0 is in LDS
-  asm volatile("" ::: "memory");
-  read_ops(0, a, z);
-  // one step: the ten LDS reads of the NEXT step's operands ride in the shadow of this step's first matrix instructions (an MFMA holds the issue
-  // port 8 of its 32 cycles); digit-major order: consecutive matrix instructions never write the same accumulator.  `live` = this step exists
-  // (the last stage of an odd count holds a repeated step)
-  auto step = [&](bool live, int next_slot, i32x4 (&ac)[5], i32x4 (&zc)[5], i32x4 (&ax)[5], i32x4 (&zx)[5]) {
-    const int8_t* sb = &lds8[next_slot * kX8Blocks * 1024];
+  // one step: the ten LDS reads of this wave's NEXT step's operands and its five loads of a later stage ride in between this step's matrix
+  // instructions (an MFMA holds the issue port 8 of its 32 cycles); digit-major order: consecutive matrix instructions never write the same
+  // accumulator
+  auto step = [&](int read_buf, int load_stage, int load_buf, i32x4 (&ac)[5], i32x4 (&zc)[5], i32x4 (&ax)[5], i32x4 (&zx)[5]) {
+    const int8_t* sb = &lds8[(read_buf * kX8Halves + half) * kX8Blocks * 1024];
     int q = 0;
 #pragma unroll
     for (int s = 0; s < 5; ++s)
 #pragma unroll
       for (int t = 0; t < 5; ++t)
         if (s + t < kX8Levels) {
-          if (live && !(AOG_X8_DEV(p) & 1)) acc[s + t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ac[s], zc[t], acc[s + t], 0, 0, 0);
+          acc[s + t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ac[s], zc[t], acc[s + t], 0, 0, 0);
           if (q < 5) ax[q] = *reinterpret_cast<const i32x4*>(sb + (rtl * 5 + q) * 1024 + (lane << 4));
           else if (q < 10) zx[q - 5] = *reinterpret_cast<const i32x4*>(sb + (10 + ctl * 5 + q - 5) * 1024 + (lane << 4));
+          else if (q >= 11 && q < 16) issue1(load_stage, load_buf, q - 11);
           ++q;
           __builtin_amdgcn_sched_barrier(0);
         }
   };
-  const long long t_loop0 = (AOG_X8_DEV(p) & 1024) ? (long long)__builtin_amdgcn_s_memtime() : 0;
-  int buf = 0;
-  for (int q = 0; q < n_stages; ++q) {
-    // first step of stage q (operands in a, z): the reads of its second step (same stage: visible since the last barrier) run beside it
-    step(true, buf * kX8Sub + 1, a, z, an, zn);
-    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): every read of stage q is done — as a builtin, so that the compiler's own wait insertion knows it
-    __builtin_amdgcn_s_barrier();          // stage q + 1 has landed; the loaders refill stage q's buffer
-    asm volatile("" ::: "memory");
-    const int nb = buf + 1 == kX8Stages ? 0 : buf + 1;
-    // second step (operands in an, zn), beside the reads of stage q + 1's first step (one read too many at the very end: a landed stage)
-    step(q * kX8Sub + 1 < n_steps, nb * kX8Sub, an, zn, a, z);
-    buf = nb;
+  auto next = [](int b) { return b + 1 == kX8Stages ? 0 : b + 1; };
+
+#pragma unroll
+  for (int st = 0; st < kX8Stages; ++st)
+#pragma unroll
+    for (int r = 0; r < 5; ++r) issue1(st, st, r);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * (kX8Stages - 1)) : "memory");   // this wave's blocks of stage 0 have landed
+  __builtin_amdgcn_s_barrier();                                                  // ... and everybody's
+  asm volatile("" ::: "memory");
+  {
+    const int8_t* sb = &lds8[half * kX8Blocks * 1024];
+#pragma unroll
+    for (int dgt = 0; dgt < 5; ++dgt) {
+      a[dgt] = *reinterpret_cast<const i32x4*>(sb + (rtl * 5 + dgt) * 1024 + (lane << 4));
+      z[dgt] = *reinterpret_cast<const i32x4*>(sb + (10 + ctl * 5 + dgt) * 1024 + (lane << 4));
+    }
   }
-  if ((AOG_X8_DEV(p) & 1024) && wave == 0 && lane == 0) {   // developer read-out: cycles per step of the slowest and of the fastest workgroup, steps of the longest
-    const int cyc = (int)(((long long)__builtin_amdgcn_s_memtime() - t_loop0) / n_steps);
+  const long long t_loop0 = (AOG_X8_DEV(p) & 1024) ? (long long)__builtin_amdgcn_s_memtime() : 0;
+  // double step q (operands of stage q in registers): behind the barrier every wave has read stage q (so its buffer takes stage q + kX8Stages)
+  // and stage q + 1 has landed (so the next step's operands can be read)
+  int buf = 0;
+  for (int q = 0; q < n_q; q += 2) {
+    __builtin_amdgcn_s_waitcnt(0x0070 | (5 * (kX8Stages - 2)));   // lgkmcnt(0), vmcnt(5 (kX8Stages - 2)) — as a builtin, so that the compiler's own wait insertion knows it
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    step(next(buf), q + kX8Stages, buf, a, z, an, zn);
+    buf = next(buf);
+    __builtin_amdgcn_s_waitcnt(0x0070 | (5 * (kX8Stages - 2)));
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    step(next(buf), q + 1 + kX8Stages, buf, an, zn, a, z);
+    buf = next(buf);
+  }
+  if ((AOG_X8_DEV(p) & 1024) && wave == 0 && lane == 0) {   // developer read-out: cycles per step of the slowest and of the fastest workgroup, steps of the longest, timeline
+    const int cyc = (int)(((long long)__builtin_amdgcn_s_memtime() - t_loop0) / n_q);
     atomicMax(p.status + 8, cyc);
     atomicMin(p.status + 9, cyc);
     atomicMax(p.status + 10, n_steps);
     atomicAdd(p.status + 11, 1);
+    atomicMin(p.status + 2, t_wg0);
+    atomicMax(p.status + 3, t_wg0);
+    atomicMax(p.status + 4, (int)(__builtin_amdgcn_s_memrealtime() & 0x3fffffff));
+    atomicAdd(p.status + 6, (int)(__builtin_amdgcn_s_memrealtime() & 0x3fffffff) - t_wg0);
+    const int w = atomicAdd(p.status + 12, 1);
+    if (w < 2048) {   // per-workgroup records behind the 16 status words (aog_device_status writes them out)
+      int* r = p.status + 16 + 4 * w;
+      r[0] = n_steps | (k << 8) | (phase << 12) | ((__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15) << 16) | ((__builtin_amdgcn_s_getreg(4 | (8 << 6) | (7 << 11)) & 255) << 20);
+      r[1] = cyc;
+      r[2] = t_wg0;
+      r[3] = (int)(__builtin_amdgcn_s_memrealtime() & 0x3fffffff);
+    }
   }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (the re-loads past the end)
   __syncthreads();   // every wave is done with the ring: its memory serves the epilogue
 
-  // epilogue: fixed point -> float64 (sum_l acc_l 128^(5 - l): every term exact, the sum rounded at 2^-53), add the exact piston / tilt response,
-  // scatter into the toroidal master (and its fp32 ring copy)
+  // epilogue.  The two waves of a tile swap half of their accumulators (exact int32 sums) and each finishes 8 of the tile's 16 register rows:
+  // fixed point -> float64 (sum_l acc_l 128^(5 - l): every term exact, the sum rounded at 2^-53), add the exact piston / tilt response, scatter
+  // into the toroidal master (and its fp32 ring copy)
+  int* const xch = reinterpret_cast<int*>(lds8);   // [tile][destination half][level][8][64] int32: 96 KB
+  auto xat = [&](int dest, int l, int r8) { return xch + ((((tile * 2 + dest) * kX8Levels + l) * 8 + r8) << 6) + lane; };
+  if (half == 0) {
+#pragma unroll
+    for (int l = 0; l < kX8Levels; ++l)
+#pragma unroll
+      for (int r8 = 0; r8 < 8; ++r8) *xat(1, l, r8) = acc[l][8 + r8];
+  } else {
+#pragma unroll
+    for (int l = 0; l < kX8Levels; ++l)
+#pragma unroll
+      for (int r8 = 0; r8 < 8; ++r8) *xat(0, l, r8) = acc[l][r8];
+  }
+  __syncthreads();
+  double f8[8];
+  if (half == 0) {
+#pragma unroll
+    for (int r8 = 0; r8 < 8; ++r8) {
+      double f = (double)(acc[0][r8] + *xat(0, 0, r8));
+#pragma unroll
+      for (int l = 1; l < kX8Levels; ++l) f = f * 128.0 + (double)(acc[l][r8] + *xat(0, l, r8));
+      f8[r8] = f;
+    }
+  } else {
+#pragma unroll
+    for (int r8 = 0; r8 < 8; ++r8) {
+      double f = (double)(acc[0][8 + r8] + *xat(1, 0, r8));
+#pragma unroll
+      for (int l = 1; l < kX8Levels; ++l) f = f * 128.0 + (double)(acc[l][8 + r8] + *xat(1, l, r8));
+      f8[r8] = f;
+    }
+  }
+  const bool vertical = phase == 1;
+  if (vertical) __syncthreads();   // (the transposition area overlaps the exchange area)
+
   const int slot = (2 * tile64 + ctl) * 32 + (lane & 31);
   const int env = p.list[phase * p.slots_max + slot];
-  const bool vertical = phase == 1;
   const int j = shift + 1;   // these rows are the slice shift j creates
   const int row_base = (rt0 + rtl) * 32;
   const double* rc = p.rec + (size_t)slot * 4;
   const double scale = env >= 0 ? rc[0] : 0.0, c0 = env >= 0 ? rc[1] : 0.0, c1 = env >= 0 ? rc[2] : 0.0;
   const int oy = env >= 0 ? __double2hiint(rc[3]) : 0, ox = env >= 0 ? __double2loint(rc[3]) : 0;
-  const bool flipped_h = env >= 0 && p.dxy[2 * env] > 0;
-  int pxh = flipped_h ? ox + j - 1 : ox - j;   // (new columns: every sample of this env and shift goes to this column)
-  pxh = ((pxh % N) + N) % N;
+  const bool flipped = env >= 0 && p.dxy[2 * env + (vertical ? 1 : 0)] > 0;
   // new rows: the 32 samples of a tile row-block are consecutive in memory for each env: they are transposed through LDS (XOR-swizzled 32 x 32
   // float64 image: conflict-free both ways) so that a store instruction writes two envs x 32 consecutive samples (2 x 256 bytes of the master,
   // 2 x 128 of the ring) instead of 64 samples of 32 different envs.  New columns: sample i of an env goes to row (i + oy) of its screen, one
   // 8-byte store per row whatever the order: stored as they come.
   double* mt = reinterpret_cast<double*>(lds8) + (size_t)tile * 32 * 32;
+  int pxh = flipped ? ox + j - 1 : ox - j;   // (new columns: every sample of this env and shift goes to this column)
+  pxh = ((pxh % N) + N) % N;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int rr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), row = row_base + rr;
-    double f = (double)acc[0][r];
-#pragma unroll
-    for (int l = 1; l < kX8Levels; ++l) f = f * 128.0 + (double)acc[l][r];
-    const double val = f * scale + c0 * tb.r1[row] + c1 * tb.r2[row];
+  for (int r8 = 0; r8 < 8; ++r8) {
+    const int r = 8 * half + r8, rr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), row = row_base + rr;
+    const double val = f8[r8] * scale + c0 * tb.r1[row] + c1 * tb.r2[row];
     if (vertical) {
       mt[(lane & 31) * 32 + (rr ^ (lane & 31))] = val;
     } else {
       const int i = row - shift * tb.Np;
       if (env < 0 || i >= N || (AOG_X8_DEV(p) & 4)) continue;
-      int py = (flipped_h ? N - 1 - i : i) + oy;
+      int py = (flipped ? N - 1 - i : i) + oy;
       if (py >= N) py -= N;
       x8_store(p, env, N, py, pxh, val);
     }
   }
-  if (!vertical || (AOG_X8_DEV(p) & 4)) return;
-  __builtin_amdgcn_wave_barrier();
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  const int i = row_base + (lane & 31) - shift * tb.Np;
-  for (int e2 = 0; e2 < 16; ++e2) {
-    const int c = 2 * e2 + (lane >> 5);
-    const int sl = (2 * tile64 + ctl) * 32 + c;
-    const int en = p.list[p.slots_max + sl];
-    if (en < 0 || i >= N) continue;
-    const double* rc2 = p.rec + (size_t)sl * 4;
-    const int oy2 = __double2hiint(rc2[3]), ox2 = __double2loint(rc2[3]);
-    const bool flipped = p.dxy[2 * en + 1] > 0;
-    int py = flipped ? oy2 + j - 1 : oy2 - j;
-    py = ((py % N) + N) % N;
-    int px = (flipped ? N - 1 - i : i) + ox2;
-    if (px >= N) px -= N;
-    x8_store(p, en, N, py, px, mt[c * 32 + ((lane & 31) ^ c)]);
+  if (vertical && !(AOG_X8_DEV(p) & 4)) {
+    // lane c (and c + 32) holds what the stores of env column c need: its screen row and the start and direction of the run along it
+    int pyv = flipped ? oy + j - 1 : oy - j;
+    pyv = ((pyv % N) + N) % N;
+    const int info = env < 0 ? -1 : (pyv | (ox << 12) | ((flipped ? 1 : 0) << 24));   // (N <= 4096)
+    __syncthreads();   // both waves of the tile have written their rows of the image
+    const int i = row_base + (lane & 31) - shift * tb.Np;
+#pragma unroll
+    for (int e8 = 0; e8 < 8; ++e8) {
+      const int c = 2 * (8 * half + e8) + (lane >> 5);
+      const int en = __shfl(env, c, 64), inf = __shfl(info, c, 64);
+      if (en < 0 || i >= N) continue;
+      int px = ((inf >> 24) ? N - 1 - i : i) + ((inf >> 12) & 4095);
+      if (px >= N) px -= N;
+      x8_store(p, en, N, inf & 4095, px, mt[c * 32 + ((lane & 31) ^ c)]);
+    }
   }
+  if ((AOG_X8_DEV(p) & 1024) && wave == 0 && lane == 0) atomicMax(p.status + 5, (int)(__builtin_amdgcn_s_memrealtime() & 0x3fffffff));
 }
 
 }  // namespace aog
