@@ -432,7 +432,12 @@ int aog_create(const aog_config* cfg, int device, aog_env** out) {
     const int wg_y = (e->n_etiles + e->mfma_we - 1) / e->mfma_we;
     // P pixel chunks (proportional split of the tiles), 8 waves per CU when the batch allows
     int Pm = cfg->pixel_chunks > 0 ? cfg->pixel_chunks : std::max(1, (asym ? 256 : 256 * 2) / wg_y);
-    const int max_tpc = 4096;   // (every variant keeps float64 sums now — registers for o = 2, an LDS plane per wave beyond — so a chunk may be long)
+    // (every variant keeps float64 sums now — registers for o = 2, an LDS plane per wave beyond — so a chunk may be long: as long as its
+    // science rows (128 B a tile) fit in the LDS beside that plane and the actuator operands; fused_inst.hip lays the same areas out)
+    const int live = e->MRW <= 8 ? 0 : (e->MRW <= 16 ? 8 : (e->MRW <= 24 ? 12 : 16));
+    const size_t lds_fixed = (size_t)e->mfma_waves * 2 * live * 64 * sizeof(double) +
+                             ((e->A_pad > 64 || cfg->atm_dynamic) ? (size_t)e->mfma_waves * (e->A_pad / 16) * 2 * 64 * 16 + (size_t)e->mfma_waves * 32 * 36 * 4 : 0) + 64;
+    const int max_tpc = std::min(4096, (int)((aog_host::kLdsBytes - lds_fixed) / 128));
     Pm = std::max(Pm, (e->n_ptiles + max_tpc - 1) / max_tpc);
     Pm = std::min(Pm, e->n_ptiles);
     e->mfma_chunks_x = Pm;

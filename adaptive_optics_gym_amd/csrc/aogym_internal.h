@@ -165,6 +165,7 @@ struct aog_env {
   int32_t* x8_items = nullptr;
   int8_t* x8_Z8 = nullptr;
   double* x8_rec = nullptr;
+  double* x8_colbuf = nullptr;
   int x8_tiles64_max = 0, x8_slots_max = 0, x8_KsTot_max = 0, x8_rt_max = 0, x8_items_max = 0;
   int near_v = 0, near_h = 0;    // stencil samples in the two newest slices come first in the uploaded order (aog_upload_layer)
   double sqrt_cn2 = 0, pitch = 0, delta_t = 0;

@@ -37,10 +37,10 @@ int x8_ensure_buffers(aog_env* e) {
   int ks_max = 0, rt_max = 0;
   for (int a = 0; a < 2; ++a)
     for (int k = 1; k <= kcap; ++k) {
-      ks_max = std::max(ks_max, h->tab[a][k].KsA + h->tab[a][k].KsB);
+      ks_max = std::max(ks_max, h->tab[a][k].KsAmax + h->tab[a][k].KsB);   // (the normals' steps sit behind the K-shift stencil's)
       rt_max = std::max(rt_max, h->tab[a][k].RT);
     }
-  e->x8_tiles64_max = (e->B + 63) / 64 + kcap;   // every shift class may end in a partly filled tile
+  e->x8_tiles64_max = (e->B + 63) / 64;   // envs are packed densely, most shifts first
   e->x8_slots_max = e->x8_tiles64_max * 64;
   e->x8_KsTot_max = ks_max;   // (one 16-sample chunk per thread of k_x8_prepare: 2 KsTot chunks per env)
   e->x8_rt_max = rt_max;
@@ -49,9 +49,11 @@ int x8_ensure_buffers(aog_env* e) {
   if ((rc = dev_alloc(e, &e->x8_slot, (size_t)2 * e->B)) != AOG_OK) return rc;
   if ((rc = dev_alloc(e, &e->x8_list, (size_t)2 * e->x8_slots_max)) != AOG_OK) return rc;
   if ((rc = dev_alloc(e, &e->x8_tile_k, (size_t)2 * e->x8_tiles64_max)) != AOG_OK) return rc;
-  e->x8_items_max = round_up(e->x8_tiles64_max * ((rt_max + 1) / 2), 256);   // every (64-env tile, row pair): the plan's list is dense
+  // k_x8_plan deals groups of at most 4 row pairs x chunk tiles to the least loaded XCD: no queue is longer than the mean + one group
+  e->x8_items_max = 8 * ((e->x8_tiles64_max * ((rt_max + 1) / 2) + 7) / 8 + 4 * aog::x8_chunk_tiles(e->x8_tiles64_max));
   if ((rc = dev_alloc(e, &e->x8_items, (size_t)2 * e->x8_items_max)) != AOG_OK) return rc;
   if ((rc = dev_alloc(e, &e->x8_rec, (size_t)4 * e->x8_slots_max)) != AOG_OK) return rc;
+  if ((rc = dev_alloc(e, &e->x8_colbuf, (size_t)e->x8_slots_max * kcap * h->tab[1][1].Np)) != AOG_OK) return rc;
   if ((rc = dev_alloc(e, &e->x8_Z8, ((size_t)2 * e->x8_tiles64_max * ks_max + aog::kX8PadSteps) * 5 * 1024)) != AOG_OK) return rc;   // (zeroed: unused columns hold zeros, not junk)
   return AOG_OK;
 }
@@ -89,6 +91,7 @@ int x8_evolve(aog_env* e, hipStream_t s, long long step_index) {
   p.Z8 = e->x8_Z8;
   p.KsTot_max = e->x8_KsTot_max;
   p.rec = e->x8_rec;
+  p.colbuf = e->x8_colbuf;
   p.status = e->dev_status;
 #ifdef AOG_DEV
   if (const char* v = getenv("AOG_X8_DEV")) p.dev = atoi(v);
@@ -395,7 +398,8 @@ int aog_upload_layer_composite(aog_env* e, const aog_layer_composite* t) {
   X8Host* h = static_cast<X8Host*>(e->x8_host);
   const bool vertical = t->axis == 0;
   const double mid = 0.5 * (double)(N - 1);
-  // the first shift whose rows touch each union column (exact zeros elsewhere: compose_extrusions never writes them)
+  // the first shift whose rows touch each union column (exact zeros elsewhere: compose_extrusions never writes them); columns in that order:
+  // the rows of shift j — and an env that shifts k >= j times — need only the first U_j columns
   std::vector<int> first_use((size_t)U, K + 1);
   for (int j = 1; j <= K; ++j)
     for (int i = 0; i < N; ++i) {
@@ -403,77 +407,85 @@ int aog_upload_layer_composite(aog_env* e, const aog_layer_composite* t) {
       for (int c = 0; c < U; ++c)
         if (row[c] != 0.0 && first_use[c] > j) first_use[c] = j;
     }
+  std::vector<int> cols;
+  std::vector<int> Uk((size_t)K + 1, 0);
+  for (int j = 1; j <= K; ++j) {
+    for (int c = 0; c < U; ++c)
+      if (first_use[c] == j) cols.push_back(c);
+    Uk[j] = (int)cols.size();
+  }
+  const int UK = Uk[K];
+  if (Uk[1] < 2) return fail(AOG_ERR_INVALID, "aog_upload_layer_composite: the first shift reads %d columns", Uk[1]);
   int rc;
   auto up = [&](auto** dst, const auto* src, size_t count) -> int {
     if ((rc = dev_alloc(e, dst, count, false)) != AOG_OK) return rc;
     HIP_TRY(hipMemcpy(*dst, src, sizeof(**dst) * count, hipMemcpyHostToDevice));
     return AOG_OK;
   };
-  for (int k = 1; k <= K; ++k) {
-    std::vector<int> cols;
-    for (int c = 0; c < U; ++c)
-      if (first_use[c] <= k) cols.push_back(c);
-    const int Uk = (int)cols.size(), KsA = (Uk + 31) / 32, KsB = k * Np / 32, RT = k * Np / 32;
-    if (Uk < 2) return fail(AOG_ERR_INVALID, "aog_upload_layer_composite: operator for k = %d has %d columns", k, Uk);
-    double amax = 0.0, bmax = 0.0;
-    for (int r = 0; r < k * N; ++r) {
-      for (int c : cols) amax = std::max(amax, std::fabs(t->A[(size_t)r * U + c]));
-      for (int c = 0; c < k * N; ++c) bmax = std::max(bmax, std::fabs(t->B[(size_t)r * K * N + c]) * e->sqrt_cn2);
+  // ONE table per axis: the rows of shift j of the K-shift operator are the rows of shift j of every k-shift operator, k >= j (slice j depends
+  // on the old screen and on the normals of shifts 1 .. j only), so envs of every shift count share it
+  const int KsAK = (UK + 31) / 32, KsBK = K * Np / 32, RT = K * Np / 32, KsT = KsAK + KsBK + aog::kX8PadSteps;
+  double amax = 0.0, bmax = 0.0;
+  for (int r = 0; r < K * N; ++r) {
+    for (int c : cols) amax = std::max(amax, std::fabs(t->A[(size_t)r * U + c]));
+    for (int c = 0; c < K * N; ++c) bmax = std::max(bmax, std::fabs(t->B[(size_t)r * K * N + c]) * e->sqrt_cn2);
+  }
+  if (!(amax > 0.0) || !(bmax > 0.0) || !std::isfinite(amax) || !std::isfinite(bmax)) return fail(AOG_ERR_INVALID, "aog_upload_layer_composite: empty or non-finite operator");
+  const int log2_qa = std::ilogb(amax) + 1 - 34, log2_qb = std::ilogb(bmax) + 1 - 34;   // |A| / qa, |B| / qb < 2^34 (5 digits each)
+  std::vector<int32_t> yx((size_t)KsAK * 32);
+  std::vector<int8_t> T8((size_t)RT * KsT * 5 * 1024, 0);
+  std::vector<double> r1((size_t)RT * 32, 0.0), r2((size_t)RT * 32, 0.0);
+  std::vector<double> xa((size_t)UK);
+  for (int cc = 0; cc < UK; ++cc) {
+    const int32_t q = t->old_yx[cols[cc]];
+    xa[cc] = (double)(vertical ? (q & 0xffff) : (q >> 16)) - mid;
+  }
+  for (int cc = 0; cc < KsAK * 32; ++cc) yx[cc] = t->old_yx[cols[cc < UK ? cc : 0]];
+  for (int j = 1; j <= K; ++j)
+    for (int i = 0; i < N; ++i) {
+      const int row = (j - 1) * Np + i, rt = row >> 5;
+      const double* arow = t->A + (size_t)((j - 1) * N + i) * U;
+      long double s1 = 0.0L, s2 = 0.0L;
+      for (int cc = 0; cc < Uk[j]; ++cc) {
+        const double a = arow[cols[cc]];
+        s1 += a;
+        s2 += (long double)a * xa[cc];
+        int8_t d[5];
+        x8_digits_host(std::llrint(std::ldexp(a, -log2_qa)), 5, d);
+        const size_t base = (((size_t)rt * KsT + (cc >> 5)) * 5) * 1024 + (size_t)((row & 31) + 32 * ((cc & 31) >> 4)) * 16 + (cc & 15);
+        for (int dg = 0; dg < 5; ++dg) T8[base + (size_t)dg * 1024] = d[dg];
+      }
+      r1[row] = (double)s1;
+      r2[row] = (double)s2;
+      const double* brow = t->B + (size_t)((j - 1) * N + i) * K * N;
+      for (int jj = 1; jj <= j; ++jj)
+        for (int ii = 0; ii < N; ++ii) {
+          const double b = brow[(size_t)(jj - 1) * N + ii] * e->sqrt_cn2;
+          if (b == 0.0) continue;
+          const int cc = (jj - 1) * Np + ii;
+          int8_t d[5];
+          x8_digits_host(std::llrint(std::ldexp(b, -log2_qb)), 5, d);
+          const size_t base = (((size_t)rt * KsT + KsAK + (cc >> 5)) * 5) * 1024 + (size_t)((row & 31) + 32 * ((cc & 31) >> 4)) * 16 + (cc & 15);
+          for (int dg = 0; dg < 5; ++dg) T8[base + (size_t)dg * 1024] = d[dg];
+        }
     }
-    if (!(amax > 0.0) || !(bmax > 0.0) || !std::isfinite(amax) || !std::isfinite(bmax)) return fail(AOG_ERR_INVALID, "aog_upload_layer_composite: empty or non-finite operator");
-    const int log2_qa = std::ilogb(amax) + 1 - 34, log2_qb = std::ilogb(bmax) + 1 - 34;   // |A| / qa, |B| / qb < 2^34 (5 digits each)
-    std::vector<int32_t> yx((size_t)KsA * 32);
-    const int KsT = KsA + KsB + aog::kX8PadSteps;
-    std::vector<int8_t> T8((size_t)RT * KsT * 5 * 1024, 0);
-    std::vector<double> r1((size_t)RT * 32, 0.0), r2((size_t)RT * 32, 0.0);
-    double sx = 0.0, sxx = 0.0;
-    std::vector<double> xa((size_t)Uk);
-    for (int cc = 0; cc < Uk; ++cc) {
-      const int32_t q = t->old_yx[cols[cc]];
-      xa[cc] = (double)(vertical ? (q & 0xffff) : (q >> 16)) - mid;
+  int32_t* d_yx = nullptr;
+  int8_t* d_T8 = nullptr;
+  double *d_r1 = nullptr, *d_r2 = nullptr;
+  if ((rc = up(&d_yx, yx.data(), yx.size())) != AOG_OK) return rc;
+  if ((rc = up(&d_T8, T8.data(), T8.size())) != AOG_OK) return rc;
+  if ((rc = up(&d_r1, r1.data(), r1.size())) != AOG_OK) return rc;
+  if ((rc = up(&d_r2, r2.data(), r2.size())) != AOG_OK) return rc;
+  double sx = 0.0, sxx = 0.0;
+  for (int k = 1, cc = 0; k <= K; ++k) {   // per shift count: how much of the table an env of that count (prepare) or a row of that shift (product) uses
+    for (; cc < Uk[k]; ++cc) {
       sx += xa[cc];
       sxx += xa[cc] * xa[cc];
     }
-    for (int cc = 0; cc < KsA * 32; ++cc) yx[cc] = t->old_yx[cols[cc < Uk ? cc : 0]];
-    for (int j = 1; j <= k; ++j)
-      for (int i = 0; i < N; ++i) {
-        const int row = (j - 1) * Np + i, rt = row >> 5;
-        const double* arow = t->A + (size_t)((j - 1) * N + i) * U;
-        long double s1 = 0.0L, s2 = 0.0L;
-        for (int cc = 0; cc < Uk; ++cc) {
-          const double a = arow[cols[cc]];
-          s1 += a;
-          s2 += (long double)a * xa[cc];
-          int8_t d[5];
-          x8_digits_host(std::llrint(std::ldexp(a, -log2_qa)), 5, d);
-          const size_t base = (((size_t)rt * KsT + (cc >> 5)) * 5) * 1024 + (size_t)((row & 31) + 32 * ((cc & 31) >> 4)) * 16 + (cc & 15);
-          for (int dg = 0; dg < 5; ++dg) T8[base + (size_t)dg * 1024] = d[dg];
-        }
-        r1[row] = (double)s1;
-        r2[row] = (double)s2;
-        const double* brow = t->B + (size_t)((j - 1) * N + i) * K * N;
-        for (int jj = 1; jj <= j; ++jj)
-          for (int ii = 0; ii < N; ++ii) {
-            const double b = brow[(size_t)(jj - 1) * N + ii] * e->sqrt_cn2;
-            if (b == 0.0) continue;
-            const int cc = (jj - 1) * Np + ii;
-            int8_t d[5];
-            x8_digits_host(std::llrint(std::ldexp(b, -log2_qb)), 5, d);
-            const size_t base = (((size_t)rt * KsT + KsA + (cc >> 5)) * 5) * 1024 + (size_t)((row & 31) + 32 * ((cc & 31) >> 4)) * 16 + (cc & 15);
-            for (int dg = 0; dg < 5; ++dg) T8[base + (size_t)dg * 1024] = d[dg];
-          }
-      }
     aog::X8Table& tb = h->tab[t->axis][k];
     tb = aog::X8Table{};
-    int32_t* d_yx = nullptr;
-    int8_t* d_T8 = nullptr;
-    double *d_r1 = nullptr, *d_r2 = nullptr;
-    if ((rc = up(&d_yx, yx.data(), yx.size())) != AOG_OK) return rc;
-    if ((rc = up(&d_T8, T8.data(), T8.size())) != AOG_OK) return rc;
-    if ((rc = up(&d_r1, r1.data(), r1.size())) != AOG_OK) return rc;
-    if ((rc = up(&d_r2, r2.data(), r2.size())) != AOG_OK) return rc;
     tb.yx = d_yx; tb.T8 = d_T8; tb.r1 = d_r1; tb.r2 = d_r2;
-    tb.k = k; tb.U = Uk; tb.KsA = KsA; tb.KsB = KsB; tb.KsT = KsT; tb.RT = RT; tb.Np = Np;
+    tb.k = k; tb.U = Uk[k]; tb.KsA = (Uk[k] + 31) / 32; tb.KsB = k * Np / 32; tb.KsAmax = KsAK; tb.KsT = KsT; tb.RT = k * Np / 32; tb.Np = Np;
     tb.log2_qa = log2_qa;
     tb.log2_cn = log2_qa - log2_qb;
     tb.ez_floor = 3 - tb.log2_cn;

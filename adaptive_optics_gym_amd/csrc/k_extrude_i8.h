@@ -41,14 +41,16 @@ constexpr int kX8Levels = 6;        // product levels l = s + t kept: 0 .. 5 (19
 constexpr int kX8MaxK = 8;          // composite operators are built for k = 1 .. kcap <= 8 shifts per axis and step
 constexpr int kX8PadSteps = 3;      // zero steps behind every table row tile (and behind Z8): the product runs its steps in fours
 
-// one composite operator (axis, k) in device memory
+// composite operator of one axis in device memory, as seen by shift count k: the arrays are the K-shift operator's (shared by every k: the rows
+// of shift j are the same in every operator of at least j shifts, and the stencil columns are ordered by first use), U / KsA / KsB / RT / sx /
+// sxx say how much of them k shifts use
 struct X8Table {
   const int32_t* yx;      // [U_pad] union stencil (sy << 16 | sx) on the screen hcipy's _extrude sees (rotated for 'top' / 'right'); padding repeats entry 0
-  const int8_t* T8;       // [RT][KsT][5][64][16] digits of [A_k | sqrt(Cn^2) B_k | kX8PadSteps zero steps] as MFMA A operands: lane (row & 31, k-half g), byte b <-> column 32 ks + 16 g + b
+  const int8_t* T8;       // [K Np / 32][KsT][5][64][16] digits of [A_K | sqrt(Cn^2) B_K | kX8PadSteps zero steps] as MFMA A operands: lane (row & 31, k-half g), byte b <-> column 32 ks + 16 g + b
   const double* r1;       // [RT * 32] A_k 1   (float64, exact piston response)
   const double* r2;       // [RT * 32] A_k x   (x = along-coordinate of the stencil sample - (N - 1) / 2)
   int k, U, KsA, KsB, RT; // U union size; k-steps (of 32) of the stencil and of the normals; row tiles (of 32 rows) = k Np / 32
-  int KsT;                // KsA + KsB + kX8PadSteps
+  int KsAmax, KsT;        // the K-shift operator's stencil steps (the normals' steps start there); steps per table row tile: KsAmax + K Np / 32 + kX8PadSteps
   int Np;                 // rows per shift block: N rounded up to 64 (row (j - 1) Np + i = sample i of the slice shift j creates; i >= N: zero rows)
   int log2_qa;            // qa = 2^log2_qa
   int log2_cn;            // qn = qz * 2^log2_cn  (= qa / qb)
@@ -82,24 +84,32 @@ struct X8Args {
   int8_t* Z8;                // [tiles32_max][KsTot_max][5][64][16]
   int KsTot_max;
   double* rec;               // [slots_max][4]: scale (qa qz 128^3), c0, c1, origin of the screen the phase reads
+  double* colbuf;            // [slots_max][kcap][Np] the new COLUMNS of phase 0, one contiguous run per (env slot, shift): k_x8_prepare of phase 1 puts them into the screens
   int dev;                   // AOG_DEV builds only (AOG_X8_DEV in the environment): 4 no result stores, 16 .. 128 prepare-kernel stages off, 1024 cycles per step read-out
   int* status;               // sticky error word (bit 2: a stencil sample or a normal left its fixed-point range)
 };
 
-// ---- plan: shifts of every env this step, envs grouped by shift count into 64-env tiles (one workgroup) -----------------------------------
+// ---- plan: shifts of every env this step; envs packed into 64-env tiles, most shifts first (a tile runs the rows of its first env's shift
+// count; an env stores the slices of its own shifts only); the product's workgroups dealt to the XCDs -----------------------------------------
 constexpr int kX8PlanThreads = 1024;
+constexpr int kX8MaxPlanTiles = 1024;   // 64-env tiles per axis the plan kernel's shared arrays hold (B <= 65536)
+constexpr int kX8MaxPlanGroups = 8 * 64;
+__host__ __device__ constexpr int x8_chunk_tiles(int tiles) { return tiles <= 128 ? 4 : (tiles + 31) / 32; }   // tiles per workgroup group: at most 32 groups per shift
 __global__ __launch_bounds__(kX8PlanThreads) void k_x8_plan(X8Args p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int NW = kX8PlanThreads / 64, NC = kX8MaxK + 1;
   __shared__ int wcnt[2][NC][NW];      // per wave and class: envs of this pass
   __shared__ int base[2][NC];          // slots handed out so far per class
   __shared__ int total[2][NC];
-  __shared__ int tile0[2][NC], ntile[2][NC], grp0[2][NC + 1];   // first tile, tiles and first group (row pair) of each class
+  __shared__ int ntiles[2], qlen[2][8], ntj[2][kX8MaxK + 1];
+  __shared__ short tk[2][kX8MaxPlanTiles];                      // tile -> shifts of its first (= every other's at most) env
+  __shared__ short gx[2][kX8MaxPlanGroups];                     // group -> XCD
+  __shared__ int gbase[2][kX8MaxPlanGroups];                    // group -> first position in that XCD's queue
   if (tid < 2 * NC) { (&base[0][0])[tid] = 0; (&total[0][0])[tid] = 0; }
   for (int i = tid; i < 2 * p.slots_max; i += kX8PlanThreads) p.list[i] = -1;
   for (int i = tid; i < 2 * p.items_max; i += kX8PlanThreads) p.items[i] = -1;
   __syncthreads();
-  // pass A: shifts and class totals (tile bases need the totals of every class before any slot can be handed out)
+  // pass A: shifts and class totals (slot bases need the totals of every class before any slot can be handed out)
   for (int e0 = 0; e0 < p.B; e0 += kX8PlanThreads) {
     const int e = e0 + tid;
     int kx = 0, ky = 0;
@@ -127,42 +137,74 @@ __global__ __launch_bounds__(kX8PlanThreads) void k_x8_plan(X8Args p) {
     }
   }
   __syncthreads();
-  if (tid < 2) {   // tile bases per class (in 64-env tiles), tile -> k
-    int t = 0, g = 0;
-    for (int k = 1; k <= p.kcap; ++k) {
-      base[tid][k] = t * 64;
-      const int nt = (total[tid][k] + 63) / 64;
-      for (int i = 0; i < nt; ++i) p.tile_k[tid * p.tiles64_max + t + i] = k;
-      tile0[tid][k] = t;
-      ntile[tid][k] = nt;
-      grp0[tid][k] = g;
-      if (nt) g += p.tables[(tid == 0 ? 1 : 0) * (kX8MaxK + 1) + k].RT / 2;
-      t += nt;
+  if (tid < 2) {   // slot bases per class, most shifts first, no gaps
+    int b = 0;
+    for (int k = p.kcap; k >= 1; --k) {
+      base[tid][k] = b;
+      b += total[tid][k];
     }
-    for (int k = p.kcap + 1; k <= NC; ++k) grp0[tid][k] = g;
-    for (; t < p.tiles64_max; ++t) p.tile_k[tid * p.tiles64_max + t] = 0;
+    ntiles[tid] = min((b + 63) / 64, min(p.tiles64_max, kX8MaxPlanTiles));
+    if ((b + 63) / 64 > ntiles[tid]) atomicOr(p.status, 4);   // (B beyond what the plan's arrays hold: aog_upload_layer_composite refuses it)
   }
   __syncthreads();
-  // the product's workgroups: one per (64-env tile, row pair), listed class by class (most shifts first), within a class by row pair (last,
-  // i.e. longest, first) and then tile, and that list dealt to the XCDs in runs of 32 (workgroup L runs on XCD L mod 8; 32 CUs each): a run is a
-  // rectangle of tiles x row pairs, so an XCD's L2 serves each table row to all the class's tiles and each env tile's operands to several row
-  // pairs — operand traffic over the fabric, not matrix work, is what bounds this kernel when every workgroup streams its own copies (measured:
-  // 2500 .. 3600 cycles per double step for the workgroups of a one-tile class against 1300 where operands are shared).  Runs go to the XCDs
-  // in snake order (0..7, 7..0, ...) so that a second round evens out the first.
-  {
-    const int ph = tid >> 9, t0 = tid & 511;
-    for (int k = p.kcap; k >= 1; --k) {
-      const int nt = ntile[ph][k];
-      if (nt == 0) continue;
-      const int nrp = grp0[ph][k + 1] - grp0[ph][k];
-      int before = 0;
-      for (int k2 = p.kcap; k2 > k; --k2) before += (grp0[ph][k2 + 1] - grp0[ph][k2]) * ntile[ph][k2];
-      for (int i = t0; i < nrp * nt; i += 512) {
-        const int rp = nrp - 1 - i / nt, j = i % nt, pos = before + i;
-        const int run = pos >> 5, round = run >> 3, x = (round & 1) ? 7 - (run & 7) : (run & 7), L = ((round << 5) + (pos & 31)) * 8 + x;
-        if (L < p.items_max) p.items[ph * p.items_max + L] = (tile0[ph][k] + j) | (rp << 16);
-        else atomicOr(p.status, 4);   // (cannot happen: items_max covers every tile x row pair)
+  for (int i = tid; i < 2 * p.tiles64_max; i += kX8PlanThreads) {
+    const int ph = i / p.tiles64_max, t = i - ph * p.tiles64_max;
+    int k = 0;
+    if (t < ntiles[ph]) {
+      k = p.kcap;
+      while (k > 1 && base[ph][k] + total[ph][k] <= 64 * t) --k;   // the class of slot 64 t
+    }
+    p.tile_k[i] = k;
+    if (t < kX8MaxPlanTiles) tk[ph][t] = (short)k;
+  }
+  __syncthreads();
+  // the product's workgroups: one per (64-env tile, row pair of 64 table rows).  What bounds that kernel at B = 1024 is operand traffic over the
+  // fabric into each XCD's L2 (measured: 2500 .. 3600 cycles per double step where every workgroup of an XCD streams its own table rows,
+  // 1300 — the matrix pipe's pace — where they are shared), so workgroups go to XCDs (workgroup L runs on XCD L mod 8) in GROUPS of the 4 row
+  // pairs of one shift x a chunk of tiles: 8 table row tiles and at most 2 x chunk env tiles feed up to 4 x chunk workgroups from one L2.
+  // Groups are dealt, largest (shift 1: every tile) first, to the XCD with the shortest queue — no queue ends more than a group longer than
+  // another — and each queue then runs backwards: last shifts, the longest products, first.
+  if (tid < 2 * NC) {   // tiles of at least j shifts (tiles are sorted: they come first)
+    const int ph = tid / NC, j = tid % NC;
+    int n = 0;
+    while (n < ntiles[ph] && tk[ph][n] >= max(j, 1)) ++n;
+    ntj[ph][j] = n;
+  }
+  __syncthreads();
+  if (tid == 0 || tid == 512) {
+    const int ph = tid >> 9, ct = x8_chunk_tiles(ntiles[ph]), rps = p.tables[(ph == 0 ? 1 : 0) * (kX8MaxK + 1) + 1].Np / 64;
+    int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // (only ever indexed by unrolled loops: registers)
+    int g = 0;
+    for (int j = 1; j <= p.kcap; ++j) {
+      const int n = ntj[ph][j];
+      for (int c0 = 0; c0 < n; c0 += ct, ++g) {
+        int x = 0, best = cnt[0];
+#pragma unroll
+        for (int q = 1; q < 8; ++q)
+          if (cnt[q] < best) { best = cnt[q]; x = q; }
+        gx[ph][g] = (short)x;
+        gbase[ph][g] = best;
+        const int add = rps * min(ct, n - c0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) cnt[q] += q == x ? add : 0;
       }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) qlen[ph][q] = cnt[q];
+  }
+  __syncthreads();
+  {
+    const int ph = tid >> 9, t0 = tid & 511, ct = x8_chunk_tiles(ntiles[ph]), rps = p.tables[(ph == 0 ? 1 : 0) * (kX8MaxK + 1) + 1].Np / 64;
+    int g0 = 0;
+    for (int j = 1; j <= p.kcap; ++j) {
+      const int n = ntj[ph][j];
+      for (int i = t0; i < rps * n; i += 512) {   // workgroup i of shift j: tile i % n, row pair (j - 1) rps + i / n
+        const int t = i % n, r = i / n, g = g0 + t / ct, tw = min(ct, n - (t / ct) * ct);
+        const int x = gx[ph][g], fwd = gbase[ph][g] + r * tw + (t % ct), L = (qlen[ph][x] - 1 - fwd) * 8 + x;
+        if (L < p.items_max) p.items[ph * p.items_max + L] = t | (((j - 1) * rps + r) << 16);
+        else atomicOr(p.status, 4);   // (cannot happen: see x8_ensure_buffers)
+      }
+      g0 += (n + ct - 1) / ct;
     }
   }
   __syncthreads();
@@ -224,6 +266,17 @@ __device__ __forceinline__ void x8_digits5(double x, int (&d)[5]) {
   d[0] = (hi - d[1]) >> 7;
 }
 
+__device__ __forceinline__ void x8_store(const X8Args& p, int env, int N, int py, int px, double v) {
+  p.master[(size_t)env * N * N + (size_t)py * N + px] = v;
+  if (p.ring) {
+    const int RS = N + 4;
+    const float f = (float)((v - p.ring_ref[env]) * p.ring_inv);
+    float* row = p.ring + ((size_t)env * N + py) * RS;
+    row[px] = f;
+    if (px < 4) row[N + px] = f;
+  }
+}
+
 // ---- prepare: one workgroup per env, one 16-sample chunk per thread: the first threads gather the union stencil (detrended, quantised with
 // the env's own quantum), the last ones draw the normals; both write base-128 digits in the product's B-operand order.  Phase 1 also commits
 // the step's origin and stream position. ---------------------------------------------------------------------------------------------------
@@ -259,7 +312,22 @@ __global__ __launch_bounds__(kX8PrepMaxThreads) void k_x8_prepare(X8Args p, int 
   int ox = p.origin[2 * env], oy = p.origin[2 * env + 1];
   if (phase == 1) ox = ((ox + dx) % N + N) % N;   // the x shifts of this step have been applied
   const uint32_t ext_old = p.ext_counter[env];
-  __syncthreads();   // (every thread has read the origin and the stream position before thread 0 commits the step below)
+  if (phase == 1 && dx != 0) {
+    // the columns phase 0 made go into the screen here, a row's (adjacent) columns by adjacent lanes: one partly written cache line per row
+    // and array where the product's own stores would leave one per row AND shift (~2 M scattered 8-byte stores a step at B = 1024: their
+    // write-backs cost the x phase ~25 us)
+    const int kx = min(abs(dx), p.kcap), sl0 = p.slot[env], Np = p.tables[kX8MaxK + 2].Np, ox0 = p.origin[2 * env];
+    const double* cb = p.colbuf + (size_t)sl0 * p.kcap * Np;
+    for (int idx = tid; idx < N * kx; idx += nthr) {   // neighbouring lanes: neighbouring columns of one row (the memory pipeline merges them)
+      const int i = idx / kx, j = idx - i * kx + 1;
+      int py = (dx > 0 ? N - 1 - i : i) + oy;
+      if (py >= N) py -= N;
+      int px = dx > 0 ? ox0 + j - 1 : ox0 - j;
+      px = ((px % N) + N) % N;
+      x8_store(p, env, N, py, px, cb[(size_t)(j - 1) * Np + i]);
+    }
+  }
+  __syncthreads();   // (every thread has read the origin and the stream position before thread 0 commits the step below; the new columns are in place)
   if (phase == 1 && tid == 0) {   // commit the step: the products read origins from `rec`, nothing reads these before the step's last launch has run
     p.origin[2 * env] = ox;
     p.origin[2 * env + 1] = ((oy + dy) % N + N) % N;
@@ -346,7 +414,7 @@ __global__ __launch_bounds__(kX8PrepMaxThreads) void k_x8_prepare(X8Args p, int 
   const int ez = max(tb.ez_floor, m > 0.0 ? ilogb(m) + 1 : tb.ez_floor);   // 2^ez > every |zp|
   if (zjob || njob) {
     const double inv_q = zjob ? ldexp(1.0, 34 - ez) : ldexp(1.0, 34 - ez - tb.log2_cn);
-    const int c = zjob ? tid : cn, ks = (zjob ? 0 : tb.KsA) + (c >> 1), g = c & 1;
+    const int c = zjob ? tid : cn, ks = (zjob ? 0 : tb.KsAmax) + (c >> 1), g = c & 1;
     bool range_ok = isfinite(m);
     uint32_t w[5][4];
 #pragma unroll
@@ -379,16 +447,6 @@ __global__ __launch_bounds__(kX8PrepMaxThreads) void k_x8_prepare(X8Args p, int 
   }
 }
 
-__device__ __forceinline__ void x8_store(const X8Args& p, int env, int N, int py, int px, double v) {
-  p.master[(size_t)env * N * N + (size_t)py * N + px] = v;
-  if (p.ring) {
-    const int RS = N + 4;
-    const float f = (float)((v - p.ring_ref[env]) * p.ring_inv);
-    float* row = p.ring + ((size_t)env * N + py) * RS;
-    row[px] = f;
-    if (px < 4) row[N + px] = f;
-  }
-}
 
 // ---- product: workgroup = 64 rows x 64 envs = 2 x 2 tiles of 32 x 32, EIGHT waves: wave = (tile, half); the two waves of a tile sit on the same
 // SIMD and share the tile's 32-deep steps (even / odd), each into its own six int32 accumulators (19 digit products per step) — summed at the
@@ -410,17 +468,19 @@ __global__ __launch_bounds__(512, 2) void k_x8_product(X8Args p, int phase) {
   const int item = p.items[phase * p.items_max + (int)blockIdx.x];
   if (item < 0) return;
   const int tile64 = item & 0xffff, rt0 = 2 * (item >> 16);
-  const int k = p.tile_k[phase * p.tiles64_max + tile64];
-  const X8Table& tb = p.tables[(phase == 0 ? 1 : 0) * (kX8MaxK + 1) + k];
+  const int axis = phase == 0 ? 1 : 0;
+  const int Np = p.tables[axis * (kX8MaxK + 1) + 1].Np;
+  const int shift = rt0 / (Np / 32);                            // both row tiles lie in shift block `shift` + 1 (Np / 32 is even)
+  const X8Table& tb = p.tables[axis * (kX8MaxK + 1) + shift + 1];   // (the shared arrays; KsA: the stencil steps the rows of this shift read)
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;   // (scalar: everything selected by it is wave-uniform)
   const int t_wg0 = (AOG_X8_DEV(p) & 1024) ? (int)(__builtin_amdgcn_s_memrealtime() & 0x3fffffff) : 0;   // 10 ns ticks
   const int tile = wave & 3, half = wave >> 2;
   const int rtl = tile & 1, ctl = tile >> 1;
   const int N = p.N;
-  const int shift = rt0 / (tb.Np / 32);                         // both row tiles lie in shift block `shift` + 1 (Np / 32 is even)
-  const int n_steps = tb.KsA + (shift + 1) * (tb.Np / 32);         // normals of later shifts do not reach these rows
+  const int KsA = tb.KsA, gap = tb.KsAmax - KsA;                // stencil steps 0 .. KsA - 1, then the normals' steps from KsAmax on
+  const int n_steps = KsA + (shift + 1) * (Np / 32);            // normals of later shifts do not reach these rows
   // double steps (this wave's step of double step q is 2 q + half), an even count: the steps past n_steps multiply by exact zeros — normals of
-  // later shifts (their B_k blocks are zero for these rows) or the table's zero padding
+  // later shifts (their B blocks are zero for these rows) or the table's zero padding
   const int n_q = ((n_steps + 3) >> 2) << 1;
   const int st_last = tb.KsT - 1;
 
@@ -433,7 +493,8 @@ __global__ __launch_bounds__(512, 2) void k_x8_product(X8Args p, int phase) {
     src0[r] = blk >= 10 ? p.Z8 + ((((size_t)(2 * tile64 + h) * p.KsTot_max) * 5 + dgt) << 10) : tb.T8 + ((((size_t)(rt0 + h) * tb.KsT) * 5 + dgt) << 10);
   }
   auto issue1 = [&](int stage, int buf, int r) {
-    const unsigned off = (unsigned)min(stage * kX8Halves + half, st_last) * 5120u + ((unsigned)lane << 4);   // (past the end: a harmless re-load keeps the vmcnt arithmetic uniform)
+    const int sq = stage * kX8Halves + half;
+    const unsigned off = (unsigned)min(sq < KsA ? sq : sq + gap, st_last) * 5120u + ((unsigned)lane << 4);   // (past the end: a harmless re-load keeps the vmcnt arithmetic uniform)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src0[r] + off),
                                      (__attribute__((address_space(3))) void*)(&lds8[((buf * kX8Halves + half) * kX8Blocks + 4 * r + tile) * 1024]), 16, 0, 0);
   };
@@ -509,7 +570,7 @@ __global__ __launch_bounds__(512, 2) void k_x8_product(X8Args p, int phase) {
     const int w = atomicAdd(p.status + 12, 1);
     if (w < 2048) {   // per-workgroup records behind the 16 status words (aog_device_status writes them out)
       int* r = p.status + 16 + 4 * w;
-      r[0] = n_steps | (k << 8) | (phase << 12) | ((__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15) << 16) | ((__builtin_amdgcn_s_getreg(4 | (8 << 6) | (7 << 11)) & 255) << 20);
+      r[0] = n_steps | (p.tile_k[phase * p.tiles64_max + tile64] << 8) | (phase << 12) | ((__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15) << 16) | ((__builtin_amdgcn_s_getreg(4 | (8 << 6) | (7 << 11)) & 255) << 20);
       r[1] = cyc;
       r[2] = t_wg0;
       r[3] = (int)(__builtin_amdgcn_s_memrealtime() & 0x3fffffff);
@@ -554,52 +615,50 @@ __global__ __launch_bounds__(512, 2) void k_x8_product(X8Args p, int phase) {
     }
   }
   const bool vertical = phase == 1;
-  if (vertical) __syncthreads();   // (the transposition area overlaps the exchange area)
+  __syncthreads();   // (the transposition area overlaps the exchange area)
 
   const int slot = (2 * tile64 + ctl) * 32 + (lane & 31);
-  const int env = p.list[phase * p.slots_max + slot];
   const int j = shift + 1;   // these rows are the slice shift j creates
+  int env = p.list[phase * p.slots_max + slot];
+  if (env >= 0 && abs(p.dxy[2 * env + (vertical ? 1 : 0)]) < j) env = -1;   // (an env of fewer shifts than its tile's first: this slice is not its)
   const int row_base = (rt0 + rtl) * 32;
   const double* rc = p.rec + (size_t)slot * 4;
   const double scale = env >= 0 ? rc[0] : 0.0, c0 = env >= 0 ? rc[1] : 0.0, c1 = env >= 0 ? rc[2] : 0.0;
-  const int oy = env >= 0 ? __double2hiint(rc[3]) : 0, ox = env >= 0 ? __double2loint(rc[3]) : 0;
-  const bool flipped = env >= 0 && p.dxy[2 * env + (vertical ? 1 : 0)] > 0;
-  // new rows: the 32 samples of a tile row-block are consecutive in memory for each env: they are transposed through LDS (XOR-swizzled 32 x 32
-  // float64 image: conflict-free both ways) so that a store instruction writes two envs x 32 consecutive samples (2 x 256 bytes of the master,
-  // 2 x 128 of the ring) instead of 64 samples of 32 different envs.  New columns: sample i of an env goes to row (i + oy) of its screen, one
-  // 8-byte store per row whatever the order: stored as they come.
+  // the 32 samples of a tile row-block are consecutive for each env — in a new ROW of the screen (phase 1), in the staging run of a new COLUMN
+  // (phase 0: k_x8_prepare of phase 1 puts the columns into the screens, see there): they are transposed through LDS (XOR-swizzled 32 x 32
+  // float64 image: conflict-free both ways) so that a store instruction writes two envs x 32 consecutive samples instead of 64 samples of 32
+  // different envs
   double* mt = reinterpret_cast<double*>(lds8) + (size_t)tile * 32 * 32;
-  int pxh = flipped ? ox + j - 1 : ox - j;   // (new columns: every sample of this env and shift goes to this column)
-  pxh = ((pxh % N) + N) % N;
 #pragma unroll
   for (int r8 = 0; r8 < 8; ++r8) {
     const int r = 8 * half + r8, rr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), row = row_base + rr;
-    const double val = f8[r8] * scale + c0 * tb.r1[row] + c1 * tb.r2[row];
-    if (vertical) {
-      mt[(lane & 31) * 32 + (rr ^ (lane & 31))] = val;
-    } else {
-      const int i = row - shift * tb.Np;
-      if (env < 0 || i >= N || (AOG_X8_DEV(p) & 4)) continue;
-      int py = (flipped ? N - 1 - i : i) + oy;
-      if (py >= N) py -= N;
-      x8_store(p, env, N, py, pxh, val);
-    }
+    mt[(lane & 31) * 32 + (rr ^ (lane & 31))] = f8[r8] * scale + c0 * tb.r1[row] + c1 * tb.r2[row];
   }
-  if (vertical && !(AOG_X8_DEV(p) & 4)) {
-    // lane c (and c + 32) holds what the stores of env column c need: its screen row and the start and direction of the run along it
-    int pyv = flipped ? oy + j - 1 : oy - j;
-    pyv = ((pyv % N) + N) % N;
-    const int info = env < 0 ? -1 : (pyv | (ox << 12) | ((flipped ? 1 : 0) << 24));   // (N <= 4096)
+  if (!(AOG_X8_DEV(p) & 4)) {
+    // lane c (and c + 32) holds what the stores of env column c need: phase 1: its screen row and the start and direction of the run along it
+    int info = -1;
+    if (env >= 0 && vertical) {
+      const int oy = __double2hiint(rc[3]), ox = __double2loint(rc[3]);
+      const bool flipped = p.dxy[2 * env + 1] > 0;
+      int pyv = flipped ? oy + j - 1 : oy - j;
+      pyv = ((pyv % N) + N) % N;
+      info = pyv | (ox << 12) | ((flipped ? 1 : 0) << 24);   // (N <= 4096)
+    }
     __syncthreads();   // both waves of the tile have written their rows of the image
-    const int i = row_base + (lane & 31) - shift * tb.Np;
+    const int i = row_base + (lane & 31) - shift * Np;
 #pragma unroll
     for (int e8 = 0; e8 < 8; ++e8) {
       const int c = 2 * (8 * half + e8) + (lane >> 5);
       const int en = __shfl(env, c, 64), inf = __shfl(info, c, 64);
       if (en < 0 || i >= N) continue;
-      int px = ((inf >> 24) ? N - 1 - i : i) + ((inf >> 12) & 4095);
-      if (px >= N) px -= N;
-      x8_store(p, en, N, inf & 4095, px, mt[c * 32 + ((lane & 31) ^ c)]);
+      const double v = mt[c * 32 + ((lane & 31) ^ c)];
+      if (vertical) {
+        int px = ((inf >> 24) ? N - 1 - i : i) + ((inf >> 12) & 4095);
+        if (px >= N) px -= N;
+        x8_store(p, en, N, inf & 4095, px, v);
+      } else {
+        p.colbuf[((size_t)((2 * tile64 + ctl) * 32 + c) * p.kcap + shift) * Np + i] = v;
+      }
     }
   }
   if ((AOG_X8_DEV(p) & 1024) && wave == 0 && lane == 0) atomicMax(p.status + 5, (int)(__builtin_amdgcn_s_memrealtime() & 0x3fffffff));
