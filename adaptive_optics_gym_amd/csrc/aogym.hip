@@ -522,6 +522,12 @@ void aog_destroy(aog_env* e) {
   (void)hipSetDevice(e->device);
   for (void* p : e->allocs) (void)hipFree(p);
   if (e->host_flag) (void)hipHostFree(e->host_flag);
+  if (e->x8_plan_stream) {
+    (void)hipStreamSynchronize(e->x8_plan_stream);
+    (void)hipStreamDestroy(e->x8_plan_stream);
+    (void)hipEventDestroy(e->x8_ev_evolved);
+    (void)hipEventDestroy(e->x8_ev_planned);
+  }
   if (e->ext_stream) {
     (void)hipStreamSynchronize(e->ext_stream);
     (void)hipStreamDestroy(e->ext_stream);

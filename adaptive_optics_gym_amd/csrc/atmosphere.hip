@@ -96,7 +96,12 @@ int x8_evolve(aog_env* e, hipStream_t s, long long step_index) {
 #ifdef AOG_DEV
   if (const char* v = getenv("AOG_X8_DEV")) p.dev = atoi(v);
 #endif
-  hipLaunchKernelGGL(aog::k_x8_plan, dim3(1), dim3(aog::kX8PlanThreads), 0, s, p);
+  // The plan needs the clock and the winds only: the one for step t + 1 runs on a stream of its own beside whatever follows step t's extrusion
+  // (the fused kernel; ~16 us of a single workgroup otherwise in line).  A plan made for another step (a reset came between) is waited for and redone.
+  const bool ahead = !getenv("AOG_X8_NO_PLAN_AHEAD");
+  if (e->x8_plan_step >= 0) HIP_TRY(hipStreamWaitEvent(s, e->x8_ev_planned, 0));   // (-1: none made; -2: dropped after a stream synchronise)
+  if (e->x8_plan_step != step_index) hipLaunchKernelGGL(aog::k_x8_plan, dim3(1), dim3(aog::kX8PlanThreads), 0, s, p);
+  e->x8_plan_step = -1;
   const dim3 gprep(e->B), bprep(round_up(2 * e->x8_KsTot_max, 64)), gprod(e->x8_items_max);
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_x8_product), aog::kX8ProductLds, e->device)) return rc;
   for (int phase = 0; phase < 2; ++phase) {
@@ -104,9 +109,31 @@ int x8_evolve(aog_env* e, hipStream_t s, long long step_index) {
     hipLaunchKernelGGL(aog::k_x8_product, gprod, dim3(512), aog::kX8ProductLds, s, p, phase);
   }
   HIP_TRY(hipGetLastError());
+  if (ahead) {
+    if (!e->x8_plan_stream) {
+      HIP_TRY(hipStreamCreateWithFlags(&e->x8_plan_stream, hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&e->x8_ev_evolved, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&e->x8_ev_planned, hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventRecord(e->x8_ev_evolved, s));   // (this step's kernels read the plan's arrays)
+    HIP_TRY(hipStreamWaitEvent(e->x8_plan_stream, e->x8_ev_evolved, 0));
+    p.t_prev = (double)step_index * e->delta_t;
+    p.t_new = (double)(step_index + 1) * e->delta_t;
+    hipLaunchKernelGGL(aog::k_x8_plan, dim3(1), dim3(aog::kX8PlanThreads), 0, e->x8_plan_stream, p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(e->x8_ev_planned, e->x8_plan_stream));
+    e->x8_plan_step = step_index + 1;
+  }
   return AOG_OK;
 }
 }  // namespace
+
+// a plan made ahead read the winds and the clock as they were: whoever changes either (aog_set_wind, ...) calls this first
+int aog_host::x8_drop_plan(aog_env* e) {
+  if (e->x8_plan_stream) HIP_TRY(hipStreamSynchronize(e->x8_plan_stream));
+  if (e->x8_plan_step >= 0) e->x8_plan_step = -2;   // (made, finished, not to be used: no wait needed either — but the event exists; -2 keeps the branch above simple)
+  return AOG_OK;
+}
 
 namespace aog_host {
 // float64 ring-buffer master screens of envs [first, first+count) -> the fused kernels' fp32 layouts
@@ -516,6 +543,7 @@ int aog_set_wind(aog_env* e, const double* velocity_dev, double max_abs_componen
   if (!e->cfg.atm_dynamic) return fail(AOG_ERR_STATE, "aog_set_wind: handle was not created with atm_dynamic = 1");
   if (int rcp = refuse_pre_evolved(e, "aog_set_wind")) return rcp;   // (an extrusion launched ahead may still be reading the old wind)
   HIP_TRY(hipSetDevice(e->device));
+  if (int rcd = x8_drop_plan(e)) return rcd;
   hipStream_t s = static_cast<hipStream_t>(stream);
   HIP_TRY(hipMemcpyAsync(e->velocity, velocity_dev, sizeof(double) * 2 * e->B, hipMemcpyDeviceToDevice, s));
   // Group envs of similar per-step shift (|dx|, |dy|) for k_extrude16_split: a 16-env group runs max(|dx| + |dy|) rounds and a

@@ -85,7 +85,7 @@ struct X8Args {
   int KsTot_max;
   double* rec;               // [slots_max][4]: scale (qa qz 128^3), c0, c1, origin of the screen the phase reads
   double* colbuf;            // [slots_max][kcap][Np] the new COLUMNS of phase 0, one contiguous run per (env slot, shift): k_x8_prepare of phase 1 puts them into the screens
-  int dev;                   // AOG_DEV builds only (AOG_X8_DEV in the environment): 4 no result stores, 16 .. 128 prepare-kernel stages off, 1024 cycles per step read-out
+  int dev;                   // AOG_DEV builds only (AOG_X8_DEV in the environment): 4 no result stores, prepare kernel: 16 no normals, 32 no digits, 64 no gather, 128 no column scatter, 1024 cycles per step read-out
   int* status;               // sticky error word (bit 2: a stencil sample or a normal left its fixed-point range)
 };
 
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(kX8PrepMaxThreads) void k_x8_prepare(X8Args p, int 
   int ox = p.origin[2 * env], oy = p.origin[2 * env + 1];
   if (phase == 1) ox = ((ox + dx) % N + N) % N;   // the x shifts of this step have been applied
   const uint32_t ext_old = p.ext_counter[env];
-  if (phase == 1 && dx != 0) {
+  if (phase == 1 && dx != 0 && !(AOG_X8_DEV(p) & 128)) {
     // the columns phase 0 made go into the screen here, a row's (adjacent) columns by adjacent lanes: one partly written cache line per row
     // and array where the product's own stores would leave one per row AND shift (~2 M scattered 8-byte stores a step at B = 1024: their
     // write-backs cost the x phase ~25 us)
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(kX8PrepMaxThreads) void k_x8_prepare(X8Args p, int 
         s0 += x[4 * q + b];
         s1 += 16 * tid + 4 * q + b < tb.U ? x[4 * q + b] * xa : 0.0;
       }
-  } else if (njob) {
+  } else if (njob && !(AOG_X8_DEV(p) & 16)) {
     const int jj = (16 * cn) / tb.Np, i0 = 16 * cn - jj * tb.Np;   // shift jj + 1, samples i0 .. i0 + 15 (Np is a multiple of 64: no straddle)
     if (i0 < N) {
       const bool replay = p.noise && (r0 + jj) < p.max_ext;
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(kX8PrepMaxThreads) void k_x8_prepare(X8Args p, int 
   }
   m = x8_block_max(m, sm);
   const int ez = max(tb.ez_floor, m > 0.0 ? ilogb(m) + 1 : tb.ez_floor);   // 2^ez > every |zp|
-  if (zjob || njob) {
+  if ((zjob || njob) && !(AOG_X8_DEV(p) & 32)) {
     const double inv_q = zjob ? ldexp(1.0, 34 - ez) : ldexp(1.0, 34 - ez - tb.log2_cn);
     const int c = zjob ? tid : cn, ks = (zjob ? 0 : tb.KsAmax) + (c >> 1), g = c & 1;
     bool range_ok = isfinite(m);
