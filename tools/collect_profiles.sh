@@ -35,6 +35,9 @@ bash $R/tools/pmc_collect.sh gpurun_out/${TAG}_pmc_b4096 --B 4096 > $OUT/${TAG}_
 # 5. PMC of the reset kernels (semi_dynamic reset of 4096 envs: two-band synthesis + packing) and of the other rows' dominant kernels
 bash $R/tools/pmc_kernels.sh gpurun_out/${TAG}_pmc_reset $R/tools/reset_loop.py --B 4096 --episodes 1 > $OUT/${TAG}_pmc_reset.log 2>&1
 bash $R/tools/pmc_kernels.sh gpurun_out/${TAG}_pmc_sh $R/tools/sh_loop2.py 1024 512 20 single > $OUT/${TAG}_pmc_sh.log 2>&1
+# 6. the dynamic atmosphere's int8 extrusion kernels (config-4 shape without the policy kernel): kernel trace + PMC
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_dyn -- python3 $R/tools/dyn_loop.py 1024 200 > $OUT/${TAG}_prof_dyn.log 2>&1
+bash $R/tools/pmc_kernels.sh gpurun_out/${TAG}_pmc_x8 $R/tools/dyn_loop.py 1024 200 > $OUT/${TAG}_pmc_x8.log 2>&1
 fi
 cd $R
 # 4. summaries (from the raw files under gpurun_out/)
@@ -50,6 +53,12 @@ python3 tools/summarize_prof.py --stats gpurun_out/${TAG}_prof_c2_b4096 --pmc gp
   echo "# ${TAG}_sh_pmc — counters of the Shack-Hartmann kernels at config 5's pupil (tools/sh_loop2.py 1024 512 20 single: launches of 1024 envs, N = 512)"; echo
   python3 tools/summarize_pmc.py gpurun_out/${TAG}_pmc_sh --tag ${TAG}_sh --kernels k_phase_mfma k_sh_rows_sep k_sh_cols_sep
 } > profiles/${TAG}_sh_pmc.md
+{
+  echo "# ${TAG}_x8_pmc — the dynamic atmosphere's int8 extrusion kernels (tools/dyn_loop.py 1024 200: B = 1024, N = 256, v = 10 m/s, launches of 1024 envs)"; echo
+  python3 tools/summarize_stats.py gpurun_out/${TAG}_prof_dyn "kernels of the dynamic step loop" "rocprofv3 --kernel-trace --stats -- python3 tools/dyn_loop.py 1024 200"
+  echo '```'; grep -h "us per step" gpurun_out/${TAG}_dyn_loop.log; echo '```'; echo
+  python3 tools/summarize_pmc.py gpurun_out/${TAG}_pmc_x8 --tag ${TAG}_x8 --kernels k_x8_product k_x8_prepare k_x8_plan k_fused_tab
+} > profiles/${TAG}_x8_pmc.md
 python3 - <<PY
 import json
 d = json.load(open("profiles/${TAG}_reset_pmc.json"))
