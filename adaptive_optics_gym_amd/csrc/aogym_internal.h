@@ -163,9 +163,6 @@ struct aog_env {
   int32_t* x8_list = nullptr;
   int32_t* x8_tile_k = nullptr;
   int32_t* x8_items = nullptr;
-  int32_t* x8_pair_cnt = nullptr;
-  double* x8_pair_buf = nullptr;
-  int x8_rp_max = 0;
   int8_t* x8_Z8 = nullptr;
   double* x8_rec = nullptr;
   double* x8_colbuf = nullptr;

@@ -49,13 +49,8 @@ int x8_ensure_buffers(aog_env* e) {
   if ((rc = dev_alloc(e, &e->x8_slot, (size_t)2 * e->B)) != AOG_OK) return rc;
   if ((rc = dev_alloc(e, &e->x8_list, (size_t)2 * e->x8_slots_max)) != AOG_OK) return rc;
   if ((rc = dev_alloc(e, &e->x8_tile_k, (size_t)2 * e->x8_tiles64_max)) != AOG_OK) return rc;
-  // k_x8_plan deals groups of at most 4 row pairs x chunk tiles (x 2 workgroups where a block's steps are split) to the least loaded XCD: no
-  // queue is longer than the mean + one group
-  const int rp_max = (rt_max + 1) / 2, pairs = e->x8_tiles64_max * rp_max;
-  e->x8_rp_max = rp_max;
-  e->x8_items_max = 8 * ((2 * pairs + 7) / 8 + 8 * aog::x8_chunk_tiles(e->x8_tiles64_max));
-  if ((rc = dev_alloc(e, &e->x8_pair_cnt, (size_t)2 * pairs)) != AOG_OK) return rc;
-  if ((rc = dev_alloc(e, &e->x8_pair_buf, (size_t)pairs * 2 * 4096)) != AOG_OK) return rc;
+  // k_x8_plan deals groups of at most 4 row pairs x chunk tiles to the least loaded XCD: no queue is longer than the mean + one group
+  e->x8_items_max = 8 * ((e->x8_tiles64_max * ((rt_max + 1) / 2) + 7) / 8 + 4 * aog::x8_chunk_tiles(e->x8_tiles64_max));
   if ((rc = dev_alloc(e, &e->x8_items, (size_t)2 * e->x8_items_max)) != AOG_OK) return rc;
   if ((rc = dev_alloc(e, &e->x8_rec, (size_t)4 * e->x8_slots_max)) != AOG_OK) return rc;
   if ((rc = dev_alloc(e, &e->x8_colbuf, (size_t)e->x8_slots_max * kcap * h->tab[1][1].Np)) != AOG_OK) return rc;
@@ -91,10 +86,6 @@ int x8_evolve(aog_env* e, hipStream_t s, long long step_index) {
   p.tile_k = e->x8_tile_k;
   p.items = e->x8_items;
   p.items_max = e->x8_items_max;
-  p.pair_cnt = e->x8_pair_cnt;
-  p.pair_buf = e->x8_pair_buf;
-  p.rp_max = e->x8_rp_max;
-  p.split_steps = getenv("AOG_X8_SPLIT_STEPS") ? atoi(getenv("AOG_X8_SPLIT_STEPS")) : 64;
   p.tiles64_max = e->x8_tiles64_max;
   p.slots_max = e->x8_slots_max;
   p.Z8 = e->x8_Z8;

@@ -78,12 +78,8 @@ struct X8Args {
   int32_t* slot;             // [2][B] phase (0 = x shifts, 1 = y shifts) -> slot = tile32 * 32 + column, -1 = no shift in that phase
   int32_t* list;             // [2][slots_max] slot -> env, -1 = empty
   int32_t* tile_k;           // [2][tiles64_max] k of each 64-env tile, 0 = unused
-  int32_t* items;            // [2][items_max] workgroup -> (64-env tile | row pair << 16 | split << 29 | part << 30) of k_x8_product, heaviest first, -1 = none
+  int32_t* items;            // [2][items_max] workgroup -> (64-env tile | row pair << 16) of k_x8_product, heaviest first, -1 = none
   int tiles64_max, slots_max, items_max;
-  int split_steps;           // (tile, row pair)s of more 32-deep steps than this go to TWO workgroups, half the steps each
-  int32_t* pair_cnt;         // [2][tiles64_max * rp_max] arrivals of a split pair (zeroed by the plan)
-  double* pair_buf;          // [tiles64_max * rp_max][2][64 * 64] the parts' results: whichever part arrives second adds the other's and stores
-  int rp_max;
   // prepared operands
   int8_t* Z8;                // [tiles32_max][KsTot_max][5][64][16]
   int KsTot_max;
@@ -112,7 +108,6 @@ __global__ __launch_bounds__(kX8PlanThreads) void k_x8_plan(X8Args p) {
   if (tid < 2 * NC) { (&base[0][0])[tid] = 0; (&total[0][0])[tid] = 0; }
   for (int i = tid; i < 2 * p.slots_max; i += kX8PlanThreads) p.list[i] = -1;
   for (int i = tid; i < 2 * p.items_max; i += kX8PlanThreads) p.items[i] = -1;
-  for (int i = tid; i < 2 * p.tiles64_max * p.rp_max; i += kX8PlanThreads) p.pair_cnt[i] = 0;
   __syncthreads();
   // pass A: shifts and class totals (slot bases need the totals of every class before any slot can be handed out)
   for (int e0 = 0; e0 < p.B; e0 += kX8PlanThreads) {
@@ -177,12 +172,11 @@ __global__ __launch_bounds__(kX8PlanThreads) void k_x8_plan(X8Args p) {
   }
   __syncthreads();
   if (tid == 0 || tid == 512) {
-    const int ph = tid >> 9, ct = x8_chunk_tiles(ntiles[ph]), Np = (p.N + 63) / 64 * 64, rps = Np / 64;
+    const int ph = tid >> 9, ct = x8_chunk_tiles(ntiles[ph]), rps = p.tables[(ph == 0 ? 1 : 0) * (kX8MaxK + 1) + 1].Np / 64;
     int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // (only ever indexed by unrolled loops: registers)
     int g = 0;
     for (int j = 1; j <= p.kcap; ++j) {
       const int n = ntj[ph][j];
-      const int parts = p.tables[(ph == 0 ? 1 : 0) * (kX8MaxK + 1) + j].KsA + j * (Np / 32) > p.split_steps ? 2 : 1;
       for (int c0 = 0; c0 < n; c0 += ct, ++g) {
         int x = 0, best = cnt[0];
 #pragma unroll
@@ -190,7 +184,7 @@ __global__ __launch_bounds__(kX8PlanThreads) void k_x8_plan(X8Args p) {
           if (cnt[q] < best) { best = cnt[q]; x = q; }
         gx[ph][g] = (short)x;
         gbase[ph][g] = best;
-        const int add = parts * rps * min(ct, n - c0);
+        const int add = rps * min(ct, n - c0);
 #pragma unroll
         for (int q = 0; q < 8; ++q) cnt[q] += q == x ? add : 0;
       }
@@ -200,19 +194,15 @@ __global__ __launch_bounds__(kX8PlanThreads) void k_x8_plan(X8Args p) {
   }
   __syncthreads();
   {
-    const int ph = tid >> 9, t0 = tid & 511, ct = x8_chunk_tiles(ntiles[ph]), Np = (p.N + 63) / 64 * 64, rps = Np / 64;
+    const int ph = tid >> 9, t0 = tid & 511, ct = x8_chunk_tiles(ntiles[ph]), rps = p.tables[(ph == 0 ? 1 : 0) * (kX8MaxK + 1) + 1].Np / 64;
     int g0 = 0;
     for (int j = 1; j <= p.kcap; ++j) {
       const int n = ntj[ph][j];
-      const int parts = p.tables[(ph == 0 ? 1 : 0) * (kX8MaxK + 1) + j].KsA + j * (Np / 32) > p.split_steps ? 2 : 1;
-      for (int i = t0; i < rps * n; i += 512) {   // (tile i % n, row pair (j - 1) rps + i / n) of shift j: one workgroup, or two sharing its steps
+      for (int i = t0; i < rps * n; i += 512) {   // workgroup i of shift j: tile i % n, row pair (j - 1) rps + i / n
         const int t = i % n, r = i / n, g = g0 + t / ct, tw = min(ct, n - (t / ct) * ct);
-        const int x = gx[ph][g];
-        for (int part = 0; part < parts; ++part) {
-          const int fwd = gbase[ph][g] + (r * tw + (t % ct)) * parts + part, L = (qlen[ph][x] - 1 - fwd) * 8 + x;
-          if (L < p.items_max) p.items[ph * p.items_max + L] = t | (((j - 1) * rps + r) << 16) | ((parts - 1) << 29) | (part << 30);
-          else atomicOr(p.status, 4);   // (cannot happen: see x8_ensure_buffers)
-        }
+        const int x = gx[ph][g], fwd = gbase[ph][g] + r * tw + (t % ct), L = (qlen[ph][x] - 1 - fwd) * 8 + x;
+        if (L < p.items_max) p.items[ph * p.items_max + L] = t | (((j - 1) * rps + r) << 16);
+        else atomicOr(p.status, 4);   // (cannot happen: see x8_ensure_buffers)
       }
       g0 += (n + ct - 1) / ct;
     }
@@ -477,9 +467,7 @@ __global__ __launch_bounds__(512, 2) void k_x8_product(X8Args p, int phase) {
   extern __shared__ __attribute__((aligned(1024))) int8_t lds8[];   // kX8ProductLds bytes
   const int item = p.items[phase * p.items_max + (int)blockIdx.x];
   if (item < 0) return;
-  const int tile64 = item & 0xffff, rp = (item >> 16) & 0x1fff, rt0 = 2 * rp;
-  const bool split = (item >> 29) & 1;
-  const int part = (item >> 30) & 1;
+  const int tile64 = item & 0xffff, rt0 = 2 * (item >> 16);
   const int axis = phase == 0 ? 1 : 0;
   const int Np = p.tables[axis * (kX8MaxK + 1) + 1].Np;
   const int shift = rt0 / (Np / 32);                            // both row tiles lie in shift block `shift` + 1 (Np / 32 is even)
@@ -495,9 +483,6 @@ __global__ __launch_bounds__(512, 2) void k_x8_product(X8Args p, int phase) {
   // later shifts (their B blocks are zero for these rows) or the table's zero padding
   const int n_q = ((n_steps + 3) >> 2) << 1;
   const int st_last = tb.KsT - 1;
-  // a split (tile, row pair): this workgroup runs double steps q_begin .. q_end - 1 (even counts), the other part the rest
-  const int n_qh = ((n_q >> 1) + 1) & ~1;
-  const int q_begin = split && part ? n_qh : 0, q_end = split && !part ? n_qh : n_q;
 
   // block `blk` of a step: 0..9 = digits of the two row tiles of [A_k | sqrt(Cn^2) B_k], 10..19 = digits of the two env tiles; this wave moves
   // blocks tile, tile + 4, ..., tile + 16 of its own half's step.  Every block advances 5 KiB per step.
@@ -544,7 +529,7 @@ __global__ __launch_bounds__(512, 2) void k_x8_product(X8Args p, int phase) {
 #pragma unroll
   for (int st = 0; st < kX8Stages; ++st)
 #pragma unroll
-    for (int r = 0; r < 5; ++r) issue1(q_begin + st, st, r);
+    for (int r = 0; r < 5; ++r) issue1(st, st, r);
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * (kX8Stages - 1)) : "memory");   // this wave's blocks of stage 0 have landed
   __builtin_amdgcn_s_barrier();                                                  // ... and everybody's
   asm volatile("" ::: "memory");
@@ -560,7 +545,7 @@ __global__ __launch_bounds__(512, 2) void k_x8_product(X8Args p, int phase) {
   // double step q (operands of stage q in registers): behind the barrier every wave has read stage q (so its buffer takes stage q + kX8Stages)
   // and stage q + 1 has landed (so the next step's operands can be read)
   int buf = 0;
-  for (int q = q_begin; q < q_end; q += 2) {
+  for (int q = 0; q < n_q; q += 2) {
     __builtin_amdgcn_s_waitcnt(0x0070 | (5 * (kX8Stages - 2)));   // lgkmcnt(0), vmcnt(5 (kX8Stages - 2)) — as a builtin, so that the compiler's own wait insertion knows it
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -573,7 +558,7 @@ __global__ __launch_bounds__(512, 2) void k_x8_product(X8Args p, int phase) {
     buf = next(buf);
   }
   if ((AOG_X8_DEV(p) & 1024) && wave == 0 && lane == 0) {   // developer read-out: cycles per step of the slowest and of the fastest workgroup, steps of the longest, timeline
-    const int cyc = (int)(((long long)__builtin_amdgcn_s_memtime() - t_loop0) / (q_end - q_begin));
+    const int cyc = (int)(((long long)__builtin_amdgcn_s_memtime() - t_loop0) / n_q);
     atomicMax(p.status + 8, cyc);
     atomicMin(p.status + 9, cyc);
     atomicMax(p.status + 10, n_steps);
@@ -585,7 +570,7 @@ __global__ __launch_bounds__(512, 2) void k_x8_product(X8Args p, int phase) {
     const int w = atomicAdd(p.status + 12, 1);
     if (w < 2048) {   // per-workgroup records behind the 16 status words (aog_device_status writes them out)
       int* r = p.status + 16 + 4 * w;
-      r[0] = n_steps | (p.tile_k[phase * p.tiles64_max + tile64] << 8) | (phase << 12) | ((__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15) << 16) | ((__builtin_amdgcn_s_getreg(4 | (8 << 6) | (7 << 11)) & 255) << 20);
+      r[0] = n_steps | (p.tile_k[phase * p.tiles64_max + tile64] << 8) | (phase << 12) | ((__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15) << 16) | (((int)blockIdx.x >> 3) << 20);   // (position in its XCD's queue)
       r[1] = cyc;
       r[2] = t_wg0;
       r[3] = (int)(__builtin_amdgcn_s_memrealtime() & 0x3fffffff);
@@ -647,30 +632,7 @@ __global__ __launch_bounds__(512, 2) void k_x8_product(X8Args p, int phase) {
 #pragma unroll
   for (int r8 = 0; r8 < 8; ++r8) {
     const int r = 8 * half + r8, rr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), row = row_base + rr;
-    mt[(lane & 31) * 32 + (rr ^ (lane & 31))] = part ? f8[r8] * scale : f8[r8] * scale + c0 * tb.r1[row] + c1 * tb.r2[row];
-  }
-  if (split) {
-    // two workgroups hold this block's two halves of the contraction: each leaves its image in memory, the one that arrives second adds the
-    // other's (a + b in either order: the same bits) and goes on to store.  No workgroup waits for another.
-    volatile int* arrived = reinterpret_cast<volatile int*>(lds8 + 4096 * sizeof(double));   // (behind the images)
-    const int pair = phase * p.tiles64_max * p.rp_max + tile64 * p.rp_max + rp;
-    double* mine = p.pair_buf + ((size_t)(pair - phase * p.tiles64_max * p.rp_max) * 2 + part) * 4096;
-    const double* theirs = p.pair_buf + ((size_t)(pair - phase * p.tiles64_max * p.rp_max) * 2 + (part ^ 1)) * 4096;
-    __syncthreads();   // the four images are complete
-    const double* img = reinterpret_cast<const double*>(lds8);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) mine[u * 512 + threadIdx.x] = img[u * 512 + threadIdx.x];
-    __syncthreads();   // (every wave's stores have been acknowledged: s_waitcnt vmcnt(0) ahead of the barrier)
-    if (threadIdx.x == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      *arrived = __hip_atomic_fetch_add(&p.pair_cnt[pair], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (*arrived == 0) return;   // the other part finishes the block
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    double* imgw = reinterpret_cast<double*>(lds8);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) imgw[u * 512 + threadIdx.x] += theirs[u * 512 + threadIdx.x];
+    mt[(lane & 31) * 32 + (rr ^ (lane & 31))] = f8[r8] * scale + c0 * tb.r1[row] + c1 * tb.r2[row];
   }
   if (!(AOG_X8_DEV(p) & 4)) {
     // lane c (and c + 32) holds what the stores of env column c need: phase 1: its screen row and the start and direction of the run along it

@@ -144,3 +144,53 @@ def test_extrusion_mode_switch_and_operator_coverage():
     for env in (fast, slow, twin):
         assert env.device_status() == 0
         env.close()
+
+
+def test_plan_made_ahead_is_the_plan_made_in_line(monkeypatch):
+    """The shifts / slots / workgroup list of step t + 1 are computed on a side stream beside step t's fused kernel (x8_evolve).  Nothing may
+    depend on that: a handle that plans ahead and one that plans in line (AOG_X8_NO_PLAN_AHEAD) agree bit for bit through episode resets, a
+    restored state (the clock jumps back) and a changed wind (aog_set_wind drops the plan made for the old one)."""
+    import ctypes as C
+
+    torch = _torch()
+    from adaptive_optics_gym_amd import BatchedAOEnv, _lib
+
+    B, N, T = 160, 64, 5
+    kw = dict(atm_type="dynamic", atm_vel=12, atm_fried=0.15, act_type="num_actuators", act_dim=16, obs_dim=2, timesteps_per_episode=T,
+              num_pupil_pixels=N, seed=9, screen_source="device", screen_oversampling=4, verbose=False)
+    monkeypatch.delenv("AOG_X8_NO_PLAN_AHEAD", raising=False)
+    ahead = BatchedAOEnv(B, "cuda:0", **kw)
+    inline = BatchedAOEnv(B, "cuda:0", **kw)
+    assert ahead.extrusion_kmax >= 1
+
+    def both(f):
+        monkeypatch.delenv("AOG_X8_NO_PLAN_AHEAD", raising=False)
+        ra = f(ahead)
+        monkeypatch.setenv("AOG_X8_NO_PLAN_AHEAD", "1")
+        rb = f(inline)
+        return ra, rb
+
+    gen = torch.Generator("cuda").manual_seed(2)
+    both(lambda e: e.reset())
+    saved = None
+    for t in range(3 * T + 2):
+        a = torch.randn((B, 16), device="cuda", generator=gen)
+        (oa, ra, da, _, ia), (ob, rb, db, _, ib) = both(lambda e: e.step(a))
+        assert torch.equal(ia["obs_raw"], ib["obs_raw"]) and torch.equal(ra, rb) and torch.equal(da, db), f"step {t}"
+        sa, sb = both(lambda e: e.get_screens())
+        assert torch.equal(sa, sb), f"step {t}: screens differ"
+        if t == 2:
+            saved = both(lambda e: e.get_state())
+        if t == 7:   # the clock jumps back to step 3: the plan made for step 9 is not the one step 4 needs
+            ahead.set_state(saved[0])
+            inline.set_state(saved[1])
+        if t == 11:  # new winds: the plan made ahead read the old ones
+            v = np.ascontiguousarray(ahead.velocity_vectors[::-1] * 0.7)
+            for e in (ahead, inline):
+                e.velocity_vectors = v
+                vt = torch.from_numpy(v).cuda()
+                _lib.check(e.lib.aog_set_wind(e._handle, C.c_void_p(vt.data_ptr()), float(np.abs(v).max()), e._stream()))
+                torch.cuda.synchronize()
+        if bool(da.all()):
+            both(lambda e: e.reset())
+    assert ahead.device_status() == 0 and inline.device_status() == 0
