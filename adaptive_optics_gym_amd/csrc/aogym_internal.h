@@ -168,6 +168,7 @@ struct aog_env {
   double* x8_colbuf = nullptr;
   hipStream_t x8_plan_stream = nullptr;   // the plan of step t + 1 runs here beside step t's fused kernel (x8_evolve)
   hipEvent_t x8_ev_evolved = nullptr, x8_ev_planned = nullptr;
+  int x8_ahead_level = 0;                 // what was made ahead for x8_plan_step: 1 the plan, 2 the plan and the x phase
   long long x8_plan_step = -1;            // step the arrays of k_x8_plan were last made for ahead of time (-1 none, -2 dropped)
   int x8_tiles64_max = 0, x8_slots_max = 0, x8_KsTot_max = 0, x8_rt_max = 0, x8_items_max = 0;
   int near_v = 0, near_h = 0;    // stencil samples in the two newest slices come first in the uploaded order (aog_upload_layer)

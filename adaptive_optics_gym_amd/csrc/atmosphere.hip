@@ -96,30 +96,47 @@ int x8_evolve(aog_env* e, hipStream_t s, long long step_index) {
 #ifdef AOG_DEV
   if (const char* v = getenv("AOG_X8_DEV")) p.dev = atoi(v);
 #endif
-  // The plan needs the clock and the winds only: the one for step t + 1 runs on a stream of its own beside whatever follows step t's extrusion
-  // (the fused kernel; ~16 us of a single workgroup otherwise in line).  A plan made for another step (a reset came between) is waited for and redone.
+  // What step t + 1 needs that step t's fused kernel, epilogue and the caller's policy query do not touch runs beside them on a stream of
+  // its own (lowest priority): the PLAN (clock and winds only) and the whole x PHASE (prepare + product of phase 0: it reads the screens as
+  // step t's extrusion left them and writes operands and the staged columns — the screens themselves first change in phase 1).  Used only
+  // if it was made for this very step and state; anything that changes the state it read drops it first (x8_drop_plan), host-supplied
+  // normals arriving for a step whose x phase drew from the device stream redo that phase (nothing of it was committed).
   const bool ahead = !getenv("AOG_X8_NO_PLAN_AHEAD");
-  if (e->x8_plan_step >= 0) HIP_TRY(hipStreamWaitEvent(s, e->x8_ev_planned, 0));   // (-1: none made; -2: dropped after a stream synchronise)
-  if (e->x8_plan_step != step_index) hipLaunchKernelGGL(aog::k_x8_plan, dim3(1), dim3(aog::kX8PlanThreads), 0, s, p);
+  int have = 0;   // 1: the plan is there, 2: and phase 0
+  if (e->x8_plan_step >= 0) {
+    HIP_TRY(hipStreamWaitEvent(s, e->x8_ev_planned, 0));   // (-1: none made; -2: dropped after a stream synchronise)
+    if (e->x8_plan_step == step_index) have = e->x8_ahead_level;
+  }
+  if (have == 2 && e->next_noise) have = 1;
   e->x8_plan_step = -1;
   const dim3 gprep(e->B), bprep(round_up(2 * e->x8_KsTot_max, 64)), gprod(e->x8_items_max);
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_x8_product), aog::kX8ProductLds, e->device)) return rc;
-  for (int phase = 0; phase < 2; ++phase) {
+  if (have < 1) hipLaunchKernelGGL(aog::k_x8_plan, dim3(1), dim3(aog::kX8PlanThreads), 0, s, p);
+  for (int phase = have < 2 ? 0 : 1; phase < 2; ++phase) {
     hipLaunchKernelGGL(aog::k_x8_prepare, gprep, bprep, 0, s, p, phase);
     hipLaunchKernelGGL(aog::k_x8_product, gprod, dim3(512), aog::kX8ProductLds, s, p, phase);
   }
   HIP_TRY(hipGetLastError());
   if (ahead) {
     if (!e->x8_plan_stream) {
-      HIP_TRY(hipStreamCreateWithFlags(&e->x8_plan_stream, hipStreamNonBlocking));
+      int least = 0, greatest = 0;
+      HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+      HIP_TRY(hipStreamCreateWithPriority(&e->x8_plan_stream, hipStreamNonBlocking, least));
       HIP_TRY(hipEventCreateWithFlags(&e->x8_ev_evolved, hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&e->x8_ev_planned, hipEventDisableTiming));
     }
-    HIP_TRY(hipEventRecord(e->x8_ev_evolved, s));   // (this step's kernels read the plan's arrays)
+    HIP_TRY(hipEventRecord(e->x8_ev_evolved, s));   // (this step's kernels read the plan's arrays and write the screens)
     HIP_TRY(hipStreamWaitEvent(e->x8_plan_stream, e->x8_ev_evolved, 0));
     p.t_prev = (double)step_index * e->delta_t;
     p.t_new = (double)(step_index + 1) * e->delta_t;
     hipLaunchKernelGGL(aog::k_x8_plan, dim3(1), dim3(aog::kX8PlanThreads), 0, e->x8_plan_stream, p);
+    e->x8_ahead_level = 1;
+    // (not the x phase after an episode's last step — a reset follows — nor while the caller supplies the normals)
+    if (!getenv("AOG_X8_NO_PHASE_AHEAD") && !e->next_noise && (e->cfg.max_steps <= 0 || e->steps_since_reset < e->cfg.max_steps)) {
+      hipLaunchKernelGGL(aog::k_x8_prepare, gprep, bprep, 0, e->x8_plan_stream, p, 0);
+      hipLaunchKernelGGL(aog::k_x8_product, gprod, dim3(512), aog::kX8ProductLds, e->x8_plan_stream, p, 0);
+      e->x8_ahead_level = 2;
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(e->x8_ev_planned, e->x8_plan_stream));
     e->x8_plan_step = step_index + 1;
@@ -358,6 +375,7 @@ int aog_upload_layer(aog_env* e, const aog_layer_tables* t) {
   };
   if (e->layer_ready) return fail(AOG_ERR_STATE, "aog_upload_layer: already uploaded");
   if (int rcp = refuse_pre_evolved(e, "aog_upload_layer")) return rcp;
+  if (int rcd = x8_drop_plan(e)) return rcd;   // (work done ahead for the next step read the state this call changes)
   // The device keeps the stencil samples (and the matching columns of A) with the NEAR ones first — the samples in the two newest slices
   // (rows 0, 1 of the 'bottom' stencil, columns 0, 1 of the 'left' one), which change with every extrusion — and the FAR ones after
   // them: k_extrude16_split fetches an env's far samples for the next round ahead of the inter-workgroup barrier.  A permutation of
@@ -415,6 +433,7 @@ int aog_upload_layer_composite(aog_env* e, const aog_layer_composite* t) {
     return fail(AOG_ERR_INVALID, "aog_upload_layer_composite: bad argument (axis %d, k_max %d of at most %d, n_old %d)", t->axis, t->k_max, aog::kX8MaxK, t->n_old);
   if (e->x8_kmax[t->axis]) return fail(AOG_ERR_STATE, "aog_upload_layer_composite: axis %d already uploaded", t->axis);
   if (int rcp = refuse_pre_evolved(e, "aog_upload_layer_composite")) return rcp;
+  if (int rcd = x8_drop_plan(e)) return rcd;   // (work done ahead for the next step read the state this call changes)
   const int N = e->cfg.n_pupil, K = t->k_max, U = t->n_old, Np = round_up(N, 64);
   if (round_up(U, 32) + K * Np > aog::kX8PrepMaxThreads * 16)
     return fail(AOG_ERR_UNSUPPORTED, "aog_upload_layer_composite: %d stencil samples + %d normals per step (at most %d together)", U, K * Np, aog::kX8PrepMaxThreads * 16);
@@ -533,6 +552,7 @@ int aog_set_extrusion_mode(aog_env* e, int mode) {
   if (!e) return fail(AOG_ERR_INVALID, "aog_set_extrusion_mode: null handle");
   if (mode != AOG_EXTRUDE_AUTO && mode != AOG_EXTRUDE_F64) return fail(AOG_ERR_INVALID, "aog_set_extrusion_mode: unknown mode %d", mode);
   if (int rcp = refuse_pre_evolved(e, "aog_set_extrusion_mode")) return rcp;
+  if (int rcd = x8_drop_plan(e)) return rcd;   // (work done ahead for the next step read the state this call changes)
   e->ext_mode = mode;
   return AOG_OK;
 }
@@ -595,6 +615,7 @@ int aog_selftest_barrier_timeout(aog_env* e, void* stream) {
   if (!e->ext_bar || getenv("AOG_EXTRUDE_SIMPLE") || getenv("AOG_EXTRUDE_NOSPLIT") || ext_split_lds(e) > kLdsBytes)
     return fail(AOG_ERR_UNSUPPORTED, "aog_selftest_barrier_timeout: this handle does not use the split extrusion kernel");
   if (int rcp = refuse_pre_evolved(e, "aog_selftest_barrier_timeout")) return rcp;
+  if (int rcd = x8_drop_plan(e)) return rcd;   // (work done ahead for the next step read the state this call changes)
   HIP_TRY(hipSetDevice(e->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
   e->ext_spin_limit = 1u << 10;

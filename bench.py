@@ -538,6 +538,19 @@ def main():
                 gather.finish_episode()                           # all-gather of per-env episode returns
                 start_episode()
 
+    # config 5 (the 'SHACK' policy, algorithm.py:252-253) runs through the rollout harness itself whenever the timed steps are whole episodes
+    # (the default 40 and the driver's 20 are, T = 20): rollout(policy="shack") = reset, T x (SH_step, step), the episode's all-gather
+    harness = w["SH_operation"] and not w["rollout"] and args.steps % T == 0
+    if harness:
+        from adaptive_optics_gym_amd.rollout import rollout as rollout_harness
+
+        def run(n_steps, pipeline=False):   # (whole episodes: a warm-up that is not is rounded up)
+            n_ep = (n_steps + T - 1) // T
+            if n_ep:
+                rollout_harness(env, None, episodes=n_ep, policy="shack", gatherer=gather)
+                state["resets"] += n_ep
+            return n_ep * T
+
     def fence():
         if distributed:
             dist.barrier()
@@ -559,7 +572,8 @@ def main():
         run(spinup)
         fence()      # the first burst of launches after a LONG asynchronous run costs the host ~55 us per step instead of ~30 (measured:
                      # tools/spin_probe.py) — the W warm-up steps take that, not the K timed ones
-    run(args.warmup)
+    warm_run = run(args.warmup)
+    warm_run = args.warmup if warm_run is None else warm_run
     fence()
     env.profile_read()                       # discard the warm-up's samples; timing stays on
     gather.time_collective(True)
@@ -623,12 +637,12 @@ def main():
         mfma_flops = (3 * 2 * a_pad + 2 * 3 * 2 * 32) * n_pix_pad * env.info.num_envs_padded
         result = {
             "metric": "env_steps_per_sec", "value": world * B * args.steps / dt, "unit": "env-steps/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "warmup_effective": args.warmup + spinup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "steps": args.steps, "warmup": args.warmup, "warmup_effective": warm_run + spinup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32 storage, split-f16 MFMA, f32/f64 accumulate", "data": "synthetic",
             "config": {"workload": f"{w['name']}: {w['text']}", "batch_per_gpu": B, "global_batch": total, "n_pupil": w["n_pupil"],
                        "act_dim": w["act_dim"], "obs_dim": w["obs_dim"], "atm_type": w["atm_type"],
                        "kernel": {1: "valu", 2: "mfma"}.get(env.info.kernel, "ref"), "spinup_steps": spinup,
-                       "stepping": "aog_step" + ("" if plain_capable else " inside the policy / Shack-Hartmann loop"),
+                       "stepping": "rollout(policy='shack') harness: reset, T x (SH_step, step), all-gather of returns" if harness else "aog_step" + ("" if plain_capable else " inside the policy / Shack-Hartmann loop"),
                        "timed_window_resets": resets_timed,   # episode ends (reset + all-gather of returns) inside the K timed steps
                        "collective_backend": (dist.get_backend() if distributed else "none (single process)"),
                        "lookahead": bool(w["rollout"] and args.lookahead),

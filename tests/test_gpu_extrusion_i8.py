@@ -147,9 +147,10 @@ def test_extrusion_mode_switch_and_operator_coverage():
 
 
 def test_plan_made_ahead_is_the_plan_made_in_line(monkeypatch):
-    """The shifts / slots / workgroup list of step t + 1 are computed on a side stream beside step t's fused kernel (x8_evolve).  Nothing may
-    depend on that: a handle that plans ahead and one that plans in line (AOG_X8_NO_PLAN_AHEAD) agree bit for bit through episode resets, a
-    restored state (the clock jumps back) and a changed wind (aog_set_wind drops the plan made for the old one)."""
+    """The shifts / slots / workgroup list of step t + 1 AND its whole x phase (operands, product, staged columns) run on a side stream beside
+    step t's fused kernel (x8_evolve).  Nothing may depend on that: a handle that works ahead and one that does everything in line
+    (AOG_X8_NO_PLAN_AHEAD) agree bit for bit through episode resets, a restored state (the clock jumps back), a changed wind (aog_set_wind
+    drops what was made for the old one) and steps whose normals the caller supplies after the x phase already drew its own."""
     import ctypes as C
 
     torch = _torch()
@@ -179,6 +180,9 @@ def test_plan_made_ahead_is_the_plan_made_in_line(monkeypatch):
         assert torch.equal(ia["obs_raw"], ib["obs_raw"]) and torch.equal(ra, rb) and torch.equal(da, db), f"step {t}"
         sa, sb = both(lambda e: e.get_screens())
         assert torch.equal(sa, sb), f"step {t}: screens differ"
+        if t in (4, 5, 13):   # caller-supplied normals for the NEXT step: an x phase already run ahead on the device stream is redone with them
+            noise = torch.randn((B, 24, N), device="cuda", dtype=torch.float64, generator=gen)
+            both(lambda e: e.set_extrusion_noise(noise))
         if t == 2:
             saved = both(lambda e: e.get_state())
         if t == 7:   # the clock jumps back to step 3: the plan made for step 9 is not the one step 4 needs
