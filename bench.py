@@ -279,7 +279,7 @@ def roofline_dominant(env, w, kernels, steps_range):
 
         ms, n = kernels["extrude"]
         shifts = 0
-        int8_mfma = 0.0     # v_mfma_i32_32x32x32_i8 per step (int8 composite form), summed over the timed steps
+        int8_mfma = [0.0, 0.0]   # v_mfma_i32_32x32x32_i8 of the x and of the y phase (int8 composite form), summed over the timed steps
         f64_flop = 0.0      # flops of the same products in plain float64 arithmetic
         n_steps = max(1, steps_range[1] - steps_range[0])
         i8 = getattr(env, "extrusion_kmax", 0) > 0
@@ -289,26 +289,33 @@ def roofline_dominant(env, w, kernels, steps_range):
             shifts += int(sh.sum())
             if i8:
                 for phase, axis in ((0, 1), (1, 0)):          # x shifts use the horizontal operator
+                    # envs packed into 64-env tiles, most shifts first; a tile runs the row blocks of its first env's shift count; the rows of
+                    # shift j read KsA_j steps of stencil + j Np / 32 of normals, padded to a multiple of four 32-deep steps
+                    ks = np.sort(sh[:, phase][sh[:, phase] > 0])[::-1]
+                    for t0 in range(0, ks.size, 64):
+                        for j in range(1, int(ks[t0]) + 1):
+                            steps = -(-(-(-env.extrusion_union[axis][j - 1] // 32) + j * (Np // 32)) // 4) * 4
+                            int8_mfma[phase] += 19.0 * (Np // 32) * steps * 2
                     for k in range(1, env.extrusion_kmax + 1):
                         cnt = int((sh[:, phase] == k).sum())
-                        if not cnt:
-                            continue
-                        ksa = -(-env.extrusion_union[axis][k - 1] // 32)
-                        tiles32 = 2 * (-(-cnt // 64))          # 64-env workgroup tiles, partly filled ones included (they run in full)
-                        steps = sum((Np // 32) * (ksa + j * (Np // 32)) for j in range(1, k + 1))   # row tiles x steps of the contraction
-                        int8_mfma += 19.0 * steps * tiles32
-                        f64_flop += 2.0 * cnt * sum(N * (env.extrusion_union[axis][k - 1] + j * N) for j in range(1, k + 1))
+                        f64_flop += 2.0 * cnt * sum(N * (env.extrusion_union[axis][j - 1] + j * N) for j in range(1, k + 1))
         nz = int(max(env._layer["stencil_vertical"].size, env._layer["stencil_horizontal"].size))
         if i8:
-            ops = int8_mfma / n_steps * 65536.0        # 32 x 32 x 32 multiply-adds = 65 536 integer operations per instruction
-            out["extrude"] = {"kernel": "k_x8_plan + k_x8_prepare x 2 + k_x8_product x 2", "bound": "mfma_i8", "ms": ms, "launches": n,
+            ahead = not os.environ.get("AOG_X8_NO_PLAN_AHEAD") and not os.environ.get("AOG_X8_NO_PHASE_AHEAD")
+            # 32 x 32 x 32 multiply-adds = 65 536 integer operations per instruction; with the x phase run ahead only the y phase is inside `ms`
+            ops = (int8_mfma[1] if ahead else sum(int8_mfma)) / n_steps * 65536.0
+            out["extrude"] = {"kernel": "k_x8_prepare + k_x8_product of the y phase (plan and x phase: ahead, on a side stream beside the previous step's fused kernel)" if ahead
+                              else "k_x8_plan + k_x8_prepare x 2 + k_x8_product x 2", "bound": "mfma_i8", "ms": ms, "launches": n,
+                              "total_tops_per_step": sum(int8_mfma) / n_steps * 65536.0 / 1e12,
                               "achieved": ops / (ms * 1e-3) / 1e12, "peak": 2 * F16_MFMA_PEAK_TFLOPS, "unit": "TOP/s",
                               "frac": ops / (ms * 1e-3) / 1e12 / (2 * F16_MFMA_PEAK_TFLOPS),
-                              "equivalent_float64_tflops": f64_flop / n_steps / (ms * 1e-3) / 1e12,
+                              "equivalent_float64_tflops": f64_flop / n_steps / (ms * 1e-3) / 1e12 * (ops / max(1.0, sum(int8_mfma) / n_steps * 65536.0)),
                               "shifts_per_env_step": shifts / max(1, B * n_steps),
                               "note": "int8 composite extrusion: digit products as issued (19 v_mfma_i32_32x32x32_i8 per 32 x 32 tile and 32-deep step, "
                                       "partly filled env tiles included) against the dense int8 matrix peak (2 x the f16 peak); ms = mean duration of the "
-                                      "sampled steps' five launches together (HIP events around one block of 8 steps in 8); equivalent_float64_tflops = "
+                                      "sampled steps' in-line launches together (HIP events around one block of 8 steps in 8; by default the y phase, "
+                                      "including any wait for the x phase made ahead; AOG_X8_NO_PLAN_AHEAD=1 puts all five launches in line and in `ms`); "
+                                      "achieved counts the products of the launches inside ms; equivalent_float64_tflops = "
                                       "the same composite products counted as float64 flops (float64 matrix peak: 78.6)"}
         else:
             flop = 2.0 * N * (nz + N) * shifts / n_steps          # per step (= per launch), mean over the timed region
