@@ -157,7 +157,12 @@ int aog_upload_layer(aog_env* env, const aog_layer_tables* layer);
  * (csrc/k_extrude_i8.h: operands in base-128 digits, exact int32 accumulation; new samples good to ~1e-9 rad) instead of the chain of
  * one-pixel float64 rounds; operators for k < k_max are cut out of the uploaded one.  k_max must cover the largest whole-pixel shift any
  * env makes per step (floor(max wind component * delta_t / pixel_pitch) + 1) and be <= 8; steps the operators do not cover, float64
- * validation handles and AOG_EXTRUDE_F64 keep the float64 kernels.  HOST pointers. */
+ * validation handles and AOG_EXTRUDE_F64 keep the float64 kernels.  HOST pointers.
+ * Work ahead: what step t + 1 needs that depends on the clock, the winds and the screens step t's extrusion left — its shift plan and its
+ * whole x phase, which writes operands and staged columns only — is launched by aog_step(t) on a low-priority stream of the library's own
+ * and runs beside step t's remaining kernels and the caller's work between the two steps.  Invisible to the caller: every call that
+ * changes what it read drops it, normals supplied for the next step redo it, results are bit for bit those of the in-line order
+ * (AOG_X8_NO_PLAN_AHEAD=1 in the environment runs everything in line; AOG_X8_NO_PHASE_AHEAD=1 only the x phase). */
 typedef struct {
   int32_t axis;             /* 0: vertical ('bottom' / 'top': new rows), 1: horizontal ('left' / 'right': new columns)             */
   int32_t k_max;            /* shifts composed                                                                                    */
