@@ -5,7 +5,10 @@
 // normals they draw (extrusion_host.compose_extrusions; uploaded through aog_upload_layer_composite):
 //     [R_1; ...; R_k] = A_k z + sqrt(Cn^2) B_k n,      z = screen[union stencil], n = [n_1; ...; n_k]
 // so a step is: plan -> (prepare, product) for the x shifts -> (prepare, product) for the y shifts: no chain of k dependent rounds,
-// no inter-workgroup barrier, every row of the product independent of every other.
+// no inter-workgroup barrier, every row of the product independent of every other.  Slice j depends on the old screen and on the normals
+// of shifts 1 .. j only, so ONE table per axis (the k_max-shift operator, stencil columns ordered by first use) serves the envs of every
+// shift count.  The x phase writes operands and staged columns only — the screens first change in the y phase's launches — so the
+// host (x8_evolve, atmosphere.hip) runs the plan and the x phase of step t + 1 on a side stream beside step t's fused kernel.
 //
 // How it keeps float64-grade accuracy on an 8-bit pipe.  The AR recursion amplifies a white error of e rad per new sample to ~13 e of smooth
 // phase error (measured on the host: profiles/HISTORY.md), so new samples must be good to ~1e-8 rad of ~10: fp32 accumulation cannot do
