@@ -86,5 +86,14 @@ PY
   echo "Un-profiled runs of the same loops (the profiler's per-launch overhead inflates the loop times above):"; echo
   echo '```'; grep -h "per SH_step" gpurun_out/${TAG}_sh_loop.log; grep -h aog_focal_images gpurun_out/${TAG}_k4_loop.log; grep -h "us per step" gpurun_out/${TAG}_dyn_loop.log; echo '```'; echo
   echo "## single-env drop-in latency (tools/single_env_latency.py)"; echo; echo '```'; cat gpurun_out/${TAG}_single.log | grep AOEnv; echo '```'
+  if [ -f gpurun_out/${TAG}_share6.json ]; then
+    echo; echo "## multi-rank rehearsals on ONE card (AOG_BENCH_SHARE_GPU=1: every rank on card 0, gloo; the pool allows six GPU processes)"; echo
+    echo "\`AOG_BENCH_SHARE_GPU=1 python bench.py --gpus 6 --batch 256 --steps 40 --warmup 10 --no-cpu-baseline\` (rc 0; the ranks share the card, so the value says nothing about scaling):"; echo
+    echo '```json'; tail -1 gpurun_out/${TAG}_share6.json | python3 -c "import sys, json; d = json.loads(sys.stdin.read()); print(json.dumps({k: d[k] for k in ('metric', 'value', 'n_gpus', 'steps', 'ms_per_step', 'scaling', 'timing')}))"; echo '```'
+  fi
+  if [ -f gpurun_out/${TAG}_share4_c4.json ]; then
+    echo; echo "\`AOG_BENCH_SHARE_GPU=1 python bench.py --gpus 4 --config 4 --batch 256 --steps 60 --warmup 30 --no-cpu-baseline\` (dynamic atmosphere: int8 extrusion with its side streams in four processes on one card, rc 0):"; echo
+    echo '```json'; tail -1 gpurun_out/${TAG}_share4_c4.json | python3 -c "import sys, json; d = json.loads(sys.stdin.read()); print(json.dumps({k: d[k] for k in ('metric', 'value', 'n_gpus', 'steps', 'ms_per_step', 'scaling', 'timing')}))"; echo '```'
+  fi
 } > profiles/${TAG}_next_rows.md
 echo done
