@@ -573,8 +573,26 @@ __global__ __launch_bounds__(64 * kShFftWaves, 2) void k_sh_cols_sep(const float
     };
     const size_t line = ((f.env_base + blockIdx.y) * N + x) * 64 + pp;   // (sh_noisy_value's key, sep_rl form)
     const int32_t* slot_col = f.sub_slot + x;
+    // the lenslet of a pixel and its row coordinate come from memory: the four pixels of the NEXT round are requested while this round's
+    // noise is drawn (they were loaded where they were used: 8 rounds x a dependent L2 round trip per wave, with two waves per SIMD to hide it)
+    int slot_n[4];
+    double yd_n[4];
+    auto request = [&](int k4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int y = pp + RL * min(4 * k4 + j, NK - 1);
+        slot_n[j] = slot_col[(size_t)y * N];
+        yd_n[j] = f.x_det[y];
+      }
+    };
+    request(0);
 #pragma unroll 1
     for (int k4 = 0; k4 < (NK + 3) / 4; ++k4) {
+      int slot_c[4];
+      double yd_c[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { slot_c[j] = slot_n[j]; yd_c[j] = yd_n[j]; }
+      request(min(k4 + 1, (NK + 3) / 4 - 1));
       uint32_t wa[4], wb[4] = {0, 0, 0, 0};
       sh_noise_words(line, (uint32_t)k4, false, f.seed, f.call, wa);
       bool have_b = false;
@@ -582,9 +600,8 @@ __global__ __launch_bounds__(64 * kShFftWaves, 2) void k_sh_cols_sep(const float
       for (int j = 0; j < 4; ++j) {
         const int k2 = 4 * k4 + j;
         if (NK % 4 != 0 && k2 >= NK) break;   // (lines of 60 RL: NK = 30)
-        const int y = pp + RL * k2;
         const double lam = lamp[k2 * 64];
-        const int slot = slot_col[(size_t)y * N];
+        const int slot = slot_c[j];
         if (slot != cur) {
           flush(cur, s0, sy);
           cur = slot; s0 = 0.0; sy = 0.0;
@@ -598,7 +615,7 @@ __global__ __launch_bounds__(64 * kShFftWaves, 2) void k_sh_cols_sep(const float
           }
           const double w = out + 1e-10;   // estimate([image + 1e-10]) (AO_env.py:277)
           s0 += w;
-          sy = fma(w, f.x_det[y], sy);
+          sy = fma(w, yd_c[j], sy);
         }
       }
     }
