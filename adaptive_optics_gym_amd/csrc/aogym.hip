@@ -295,7 +295,7 @@ int set_screens(aog_env* e, const T* psi, int first, int count, hipStream_t s) {
   if (first < 0 || count < 0 || first + count > e->B)
     return fail(AOG_ERR_INVALID, "aog_set_screens: env range [%d,%d) outside [0,%d)", first, first + count, e->B);
   if (int rc = refuse_pre_evolved(e, "aog_set_screens")) return rc;
-  if (int rcd = x8_drop_plan(e)) return rcd;   // (work done ahead for the next step read the state this call changes)
+  if (int rcd = x8_drop_ahead(e)) return rcd;   // (work done ahead for the next step read the state this call changes)
   if (count == 0) return AOG_OK;
   HIP_TRY(hipSetDevice(e->device));
   const double inv = 1.0 / (2.0 * M_PI * e->cfg.wavelength_wfs);
@@ -757,7 +757,7 @@ int aog_set_screens_f32(aog_env* e, const float* psi, int first, int count, void
 int aog_set_rng_seed(aog_env* e, uint64_t seed) {
   if (!e) return fail(AOG_ERR_INVALID, "aog_set_rng_seed: null handle");
   if (int rcp = refuse_pre_evolved(e, "aog_set_rng_seed")) return rcp;   // (the extrusion launched ahead already drew from the old seed)
-  if (int rcd = x8_drop_plan(e)) return rcd;   // (work done ahead for the next step read the state this call changes)
+  if (int rcd = x8_drop_ahead(e)) return rcd;   // (work done ahead for the next step read the state this call changes)
   e->rng_seed = seed;
   return AOG_OK;
 }
@@ -858,7 +858,7 @@ int aog_set_state(aog_env* e, const void* blob_dev, int64_t timestep, void* stre
     HIP_TRY(hipStreamSynchronize(e->ext_stream));
     e->pre_evolved = false;
   }
-  if (int rcd = x8_drop_plan(e)) return rcd;   // (likewise what the int8 extrusion prepared ahead)
+  if (int rcd = x8_drop_ahead(e)) return rcd;   // (likewise what the int8 extrusion prepared ahead)
   hipStream_t s = static_cast<hipStream_t>(stream);
   size_t off = 0;
   for (const auto& p : state_parts(e)) {
@@ -973,7 +973,7 @@ int aog_reset(aog_env* e, const uint8_t* mask, float* obs_raw, uint16_t* obs, vo
   if (!e->tables_ready || !e->screens_ready) return fail(AOG_ERR_STATE, "aog_reset before aog_upload_tables/aog_set_screens");
   if (int rc = check_poisoned(e, "aog_reset")) return rc;
   if (int rc = refuse_pre_evolved(e, "aog_reset")) return rc;
-  if (int rcd = x8_drop_plan(e)) return rcd;   // (work done ahead for the next step read the state this call changes)
+  if (int rcd = x8_drop_ahead(e)) return rcd;   // (work done ahead for the next step read the state this call changes)
   HIP_TRY(hipSetDevice(e->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (!mask) e->steps_since_reset = 0;

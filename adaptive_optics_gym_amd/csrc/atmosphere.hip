@@ -99,7 +99,7 @@ int x8_evolve(aog_env* e, hipStream_t s, long long step_index) {
   // What step t + 1 needs that step t's fused kernel, epilogue and the caller's policy query do not touch runs beside them on a stream of
   // its own (lowest priority): the PLAN (clock and winds only) and the whole x PHASE (prepare + product of phase 0: it reads the screens as
   // step t's extrusion left them and writes operands and the staged columns — the screens themselves first change in phase 1).  Used only
-  // if it was made for this very step and state; anything that changes the state it read drops it first (x8_drop_plan), host-supplied
+  // if it was made for this very step and state; anything that changes the state it read drops it first (x8_drop_ahead), host-supplied
   // normals arriving for a step whose x phase drew from the device stream redo that phase (nothing of it was committed).
   const bool ahead = !getenv("AOG_X8_NO_PLAN_AHEAD");
   int have = 0;   // 1: the plan is there, 2: and phase 0
@@ -146,7 +146,7 @@ int x8_evolve(aog_env* e, hipStream_t s, long long step_index) {
 }  // namespace
 
 // a plan made ahead read the winds and the clock as they were: whoever changes either (aog_set_wind, ...) calls this first
-int aog_host::x8_drop_plan(aog_env* e) {
+int aog_host::x8_drop_ahead(aog_env* e) {
   if (e->x8_plan_stream) HIP_TRY(hipStreamSynchronize(e->x8_plan_stream));
   if (e->x8_plan_step >= 0) e->x8_plan_step = -2;   // (made, finished, not to be used: no wait needed either — but the event exists; -2 keeps the branch above simple)
   return AOG_OK;
@@ -375,7 +375,7 @@ int aog_upload_layer(aog_env* e, const aog_layer_tables* t) {
   };
   if (e->layer_ready) return fail(AOG_ERR_STATE, "aog_upload_layer: already uploaded");
   if (int rcp = refuse_pre_evolved(e, "aog_upload_layer")) return rcp;
-  if (int rcd = x8_drop_plan(e)) return rcd;   // (work done ahead for the next step read the state this call changes)
+  if (int rcd = x8_drop_ahead(e)) return rcd;   // (work done ahead for the next step read the state this call changes)
   // The device keeps the stencil samples (and the matching columns of A) with the NEAR ones first — the samples in the two newest slices
   // (rows 0, 1 of the 'bottom' stencil, columns 0, 1 of the 'left' one), which change with every extrusion — and the FAR ones after
   // them: k_extrude16_split fetches an env's far samples for the next round ahead of the inter-workgroup barrier.  A permutation of
@@ -433,7 +433,7 @@ int aog_upload_layer_composite(aog_env* e, const aog_layer_composite* t) {
     return fail(AOG_ERR_INVALID, "aog_upload_layer_composite: bad argument (axis %d, k_max %d of at most %d, n_old %d)", t->axis, t->k_max, aog::kX8MaxK, t->n_old);
   if (e->x8_kmax[t->axis]) return fail(AOG_ERR_STATE, "aog_upload_layer_composite: axis %d already uploaded", t->axis);
   if (int rcp = refuse_pre_evolved(e, "aog_upload_layer_composite")) return rcp;
-  if (int rcd = x8_drop_plan(e)) return rcd;   // (work done ahead for the next step read the state this call changes)
+  if (int rcd = x8_drop_ahead(e)) return rcd;   // (work done ahead for the next step read the state this call changes)
   const int N = e->cfg.n_pupil, K = t->k_max, U = t->n_old, Np = round_up(N, 64);
   if (round_up(U, 32) + K * Np > aog::kX8PrepMaxThreads * 16)
     return fail(AOG_ERR_UNSUPPORTED, "aog_upload_layer_composite: %d stencil samples + %d normals per step (at most %d together)", U, K * Np, aog::kX8PrepMaxThreads * 16);
@@ -552,7 +552,7 @@ int aog_set_extrusion_mode(aog_env* e, int mode) {
   if (!e) return fail(AOG_ERR_INVALID, "aog_set_extrusion_mode: null handle");
   if (mode != AOG_EXTRUDE_AUTO && mode != AOG_EXTRUDE_F64) return fail(AOG_ERR_INVALID, "aog_set_extrusion_mode: unknown mode %d", mode);
   if (int rcp = refuse_pre_evolved(e, "aog_set_extrusion_mode")) return rcp;
-  if (int rcd = x8_drop_plan(e)) return rcd;   // (work done ahead for the next step read the state this call changes)
+  if (int rcd = x8_drop_ahead(e)) return rcd;   // (work done ahead for the next step read the state this call changes)
   e->ext_mode = mode;
   return AOG_OK;
 }
@@ -563,7 +563,7 @@ int aog_set_wind(aog_env* e, const double* velocity_dev, double max_abs_componen
   if (!e->cfg.atm_dynamic) return fail(AOG_ERR_STATE, "aog_set_wind: handle was not created with atm_dynamic = 1");
   if (int rcp = refuse_pre_evolved(e, "aog_set_wind")) return rcp;   // (an extrusion launched ahead may still be reading the old wind)
   HIP_TRY(hipSetDevice(e->device));
-  if (int rcd = x8_drop_plan(e)) return rcd;
+  if (int rcd = x8_drop_ahead(e)) return rcd;
   hipStream_t s = static_cast<hipStream_t>(stream);
   HIP_TRY(hipMemcpyAsync(e->velocity, velocity_dev, sizeof(double) * 2 * e->B, hipMemcpyDeviceToDevice, s));
   // Group envs of similar per-step shift (|dx|, |dy|) for k_extrude16_split: a 16-env group runs max(|dx| + |dy|) rounds and a
@@ -615,7 +615,7 @@ int aog_selftest_barrier_timeout(aog_env* e, void* stream) {
   if (!e->ext_bar || getenv("AOG_EXTRUDE_SIMPLE") || getenv("AOG_EXTRUDE_NOSPLIT") || ext_split_lds(e) > kLdsBytes)
     return fail(AOG_ERR_UNSUPPORTED, "aog_selftest_barrier_timeout: this handle does not use the split extrusion kernel");
   if (int rcp = refuse_pre_evolved(e, "aog_selftest_barrier_timeout")) return rcp;
-  if (int rcd = x8_drop_plan(e)) return rcd;   // (work done ahead for the next step read the state this call changes)
+  if (int rcd = x8_drop_ahead(e)) return rcd;   // (work done ahead for the next step read the state this call changes)
   HIP_TRY(hipSetDevice(e->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
   e->ext_spin_limit = 1u << 10;

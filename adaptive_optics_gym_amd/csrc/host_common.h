@@ -81,7 +81,7 @@ int load_actuators(aog_env* e, hipStream_t s, _Float16* act_ll = nullptr);
 // atmosphere.hip
 int pack_from_master(aog_env* e, int first, int count, hipStream_t s, bool per_step = false);
 int evolve_layer(aog_env* e, hipStream_t s, long long step_index);
-int x8_drop_plan(aog_env* e);   // before the winds or the plan's buffers change
+int x8_drop_ahead(aog_env* e);   // before anything the int8 extrusion's work ahead (plan, x phase of the next step) read is changed
 int ensure_tiles(aog_env* e, hipStream_t s);
 int ring_from_master(aog_env* e, int first, int count, int keep_ref, hipStream_t s);
 int store_master_f64(aog_env* e, const double* psi, int first, int count, hipStream_t s);

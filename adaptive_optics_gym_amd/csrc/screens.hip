@@ -159,7 +159,7 @@ int aog_generate_screens(aog_env* e, int first, int count, int oversampling, dou
     return fail(AOG_ERR_INVALID, "aog_generate_screens: bad parameter");
   if (count == 0) return AOG_OK;
   HIP_TRY(hipSetDevice(e->device));
-  if (int rcd = x8_drop_plan(e)) return rcd;   // (work done ahead for the next step of a dynamic atmosphere read the screens this call replaces)
+  if (int rcd = x8_drop_ahead(e)) return rcd;   // (work done ahead for the next step of a dynamic atmosphere read the screens this call replaces)
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int N = e->cfg.n_pupil, m = N * oversampling;
   if ((m & 1) != 0) return fail(AOG_ERR_UNSUPPORTED, "aog_generate_screens: odd FFT size");
