@@ -289,7 +289,7 @@ int launch_epilogue(aog_env* e, bool is_step, float* obs_raw, uint16_t* obs, flo
 }
 
 template <typename T>
-int set_screens(aog_env* e, const T* psi, int first, int count, hipStream_t s) {
+int set_screens(aog_env* e, const T* psi, int first, int count, hipStream_t s, bool means_ready = false) {
   if (!e || !psi) return fail(AOG_ERR_INVALID, "aog_set_screens: null argument");
   if (!e->tables_ready) return fail(AOG_ERR_STATE, "aog_set_screens before aog_upload_tables");
   if (first < 0 || count < 0 || first + count > e->B)
@@ -313,7 +313,8 @@ int set_screens(aog_env* e, const T* psi, int first, int count, hipStream_t s) {
       if (rc != AOG_OK) return rc;
     }
     TimedRegion tr(e, s, AOG_PROF_PACK);
-    hipLaunchKernelGGL((aog::k_screen_means<T>), dim3(count), dim3(256), 0, s, psi, e->ap_index, e->pack_mean, N2, e->n_ap);
+    // (means_ready: the synthesis' last pass summed the aperture while it had the screens in registers: pack_mean[0 .. count) is there)
+    if (!means_ready) hipLaunchKernelGGL((aog::k_screen_means<T>), dim3(count), dim3(256), 0, s, psi, e->ap_index, e->pack_mean, N2, e->n_ap);
     const int et0 = first >> 5, et1 = (first + count - 1) >> 5;
     hipLaunchKernelGGL((aog::k_pack_tiles<T>), dim3((e->n_ptiles + aog::kPackTiles - 1) / aog::kPackTiles, et1 - et0 + 1), dim3(256), 0, s, psi,
                        e->ap_index, e->pack_mean, e->psi_rev, e->psi_tile, first, count, N2, e->n_ap, e->n_ptiles, e->Bp, inv);
@@ -332,7 +333,7 @@ int set_screens(aog_env* e, const T* psi, int first, int count, hipStream_t s) {
 }  // namespace
 
 namespace aog_host {
-int set_screens_f32(aog_env* e, const float* psi, int first, int count, hipStream_t s) { return set_screens<float>(e, psi, first, count, s); }
+int set_screens_f32(aog_env* e, const float* psi, int first, int count, hipStream_t s, bool means_ready) { return set_screens<float>(e, psi, first, count, s, means_ready); }
 }  // namespace aog_host
 
 extern "C" {
@@ -572,6 +573,19 @@ int aog_upload_tables(aog_env* e, const aog_tables* t) {
     if (p && t->ap_index[p] <= t->ap_index[p - 1]) return fail(AOG_ERR_INVALID, "aog_upload_tables: ap_index must be strictly increasing");
   }
   HIP_TRY(hipMemcpy(e->ap_index, t->ap_index, sizeof(int32_t) * n_ap, hipMemcpyHostToDevice));
+  {
+    const int Nw = (e->cfg.n_pupil + 31) / 32;
+    std::vector<uint32_t> bits((size_t)e->cfg.n_pupil * Nw, 0u);
+    for (int p = 0; p < n_ap; ++p) {
+      const int f = t->ap_index[p], iy = f / e->cfg.n_pupil, ix = f % e->cfg.n_pupil;
+      bits[(size_t)iy * Nw + (ix >> 5)] |= 1u << (ix & 31);
+    }
+    if (!e->ap_bits) {
+      const int rcb = dev_alloc(e, &e->ap_bits, bits.size(), false);
+      if (rcb != AOG_OK) return rcb;
+    }
+    HIP_TRY(hipMemcpy(e->ap_bits, bits.data(), sizeof(uint32_t) * bits.size(), hipMemcpyHostToDevice));
+  }
   HIP_TRY(hipMemcpy(e->gram, t->gram, sizeof(double) * A * A, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(e->wfs_coef, t->wfs_coef, sizeof(double) * e->n_out * e->MRW_used * 2, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(e->sci_coef, t->sci_coef, sizeof(double) * e->MRS_used * 2, hipMemcpyHostToDevice));

@@ -28,6 +28,9 @@ struct aog_env {
   int64_t dev_bytes = 0;
   // constant tables
   int32_t* ap_index = nullptr;
+  uint32_t* ap_bits = nullptr;   // [N][ceil(N / 32)] the aperture as a bit mask (bit x & 31 of word x >> 5 of row y): k_screen2_cols' aperture sums
+  double* syn_part = nullptr;    // [synthesis batch][column tiles] aperture sums of the screens just drawn, per column tile (k_screen2_cols -> k_mean_from_parts)
+  size_t syn_part_elems = 0;
   float* modes_f32 = nullptr;    // [n_ap_pad][A_pad]
   _Float16* modes16 = nullptr;   // [n_ptiles][A_pad/16][hi|lo][64][8]
   float* tabs_f32 = nullptr;     // [n_ap_pad][TROW]

@@ -75,7 +75,7 @@ struct TimedRegion {
 int check_poisoned(const aog_env* e, const char* who);
 int refuse_pre_evolved(const aog_env* e, const char* who);
 int clear_poison_if_whole(aog_env* e, int first, int count, hipStream_t s);
-int set_screens_f32(aog_env* e, const float* psi, int first, int count, hipStream_t s);   // device screens [count][N][N] -> internal layouts
+int set_screens_f32(aog_env* e, const float* psi, int first, int count, hipStream_t s, bool means_ready = false);   // means_ready: pack_mean[0 .. count) holds the aperture means already   // device screens [count][N][N] -> internal layouts
 // act_dm -> the operand layouts of the fused kernels (act_ll: optional third f16 term of the actuators, K4)
 int load_actuators(aog_env* e, hipStream_t s, _Float16* act_ll = nullptr);
 // atmosphere.hip

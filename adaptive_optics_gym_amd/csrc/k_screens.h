@@ -341,6 +341,9 @@ struct Screen2Args {
   const uint32_t* gen;       // [B] screens drawn so far per env
   float duH, duL, u0sq, ampH, ampL;   // frequency steps of the two grids; amplitudes in the screen's final unit (sqrt(PSD) du / 2 pi sqrt(Cn^2))
   BandWindow win;
+  const uint32_t* ap_bits;   // nullable: [N][ceil(N / 32)] aperture bit mask — pass B then leaves each column tile's aperture sum in `part`
+  double* part;              // [env in batch][column tiles]
+  int n_tiles;
 };
 
 // NL = 64 / (R Q) lines of length m = Q N at once: virtual column group g = b * NL + line (b < Q), sequence s = p * BC + g, BC = 64 / R.
@@ -636,6 +639,34 @@ __global__ __launch_bounds__(64 * kColsWaves) void k_screen2_cols(Screen2Args p)
         if (ix0 + l < N) *reinterpret_cast<float4*>(dst + l) = make_float4(acc[l][pp].x, acc[l + 1][pp].x, acc[l + 2][pp].x, acc[l + 3][pp].x);
     }
   }
+  if (p.ap_bits) {
+    // the aperture mean the conversion to the kernels' layouts subtracts: summed here, where the screen is in registers, instead of by a
+    // pass of its own over the stored screens (k_screen_means: 0.4 ms per 4096 envs at N = 256).  Fixed order: this lane's rows, then its
+    // columns, then the wave's lanes by a butterfly; k_mean_from_parts adds the column tiles in order.
+    double sum = 0.0;
+    if (lane < LW) {
+      const int nw = (N + 31) >> 5;
+#pragma unroll
+      for (int pp = 0; pp < R; ++pp) {
+        const uint32_t m = p.ap_bits[(size_t)(pp + R * lane) * nw + (ix0 >> 5)] >> (ix0 & 31);   // (a tile lies inside one word: NL divides 32)
+#pragma unroll
+        for (int l = 0; l < NL; ++l)
+          if ((m >> l) & 1u) sum += (double)acc[l][pp].x;   // (columns past N carry no mask bit)
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    if (lane == 0) p.part[(size_t)b * p.n_tiles + ix0 / NL] = sum;
+  }
+}
+
+// aperture means from pass B's per-tile sums (one thread per env of the batch; tiles added in order)
+__global__ void k_mean_from_parts(const double* __restrict__ part, double* __restrict__ mean, int n_env, int n_tiles, int n_ap) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n_env) return;
+  double s = 0.0;
+  for (int t = 0; t < n_tiles; ++t) s += part[(size_t)b * n_tiles + t];
+  mean[b] = s / (double)n_ap;
 }
 
 // Low band on the general route (pupils the pruned passes do not cover, and the equivalence test): spectrum, lines, sum — one thread per

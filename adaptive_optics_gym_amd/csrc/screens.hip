@@ -91,6 +91,22 @@ static int generate_twoband(aog_env* e, int first, int count, int qf, double cn_
     if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(rows), lds, e->device)) return rc;
     if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(cols), lds_cols, e->device)) return rc;
     const int NL = 32 / R;
+    // the aperture means ride in pass B when the screens go on to the tiled conversion (set_screens: static atmospheres, >= 8 screens a call)
+    a.n_tiles = (N + NL - 1) / NL;
+    const bool fused_means = !e->cfg.atm_dynamic && e->cfg.precision == AOG_PRECISION_FAST && e->ap_bits && !getenv("AOG_SCREENS_SEPARATE_MEANS");
+    if (fused_means) {
+      int rc;
+      const size_t need = (size_t)e->syn_batch * a.n_tiles;
+      if (e->syn_part_elems < need) {
+        if (e->syn_part) HIP_TRY(hipDeviceSynchronize());
+        dev_release(e, &e->syn_part);
+        if ((rc = dev_alloc(e, &e->syn_part, need, false)) != AOG_OK) return rc;
+        e->syn_part_elems = need;
+      }
+      if (!e->pack_mean && (rc = dev_alloc(e, &e->pack_mean, (size_t)e->B, false)) != AOG_OK) return rc;
+      a.ap_bits = e->ap_bits;
+      a.part = e->syn_part;
+    }
     const int nHgroups = (N + 1 + NL - 1) / NL, nHblocks = (nHgroups + 3) / 4, nLblocks = (KL + 3) / 4;
     const int n_launch = (count + e->syn_batch - 1) / e->syn_batch;
     const int per_launch = (count + n_launch - 1) / n_launch;   // even shares (no short tail launch)
@@ -106,7 +122,8 @@ static int generate_twoband(aog_env* e, int first, int count, int qf, double cn_
         hipLaunchKernelGGL(cols, dim3((N + aog::kColsWaves * NL - 1) / (aog::kColsWaves * NL), nb), dim3(64 * aog::kColsWaves), lds_cols, s, a);
       }
       HIP_TRY(hipGetLastError());
-      int rc = set_screens_f32(e, e->syn_out, first + done, nb, s);
+      if (fused_means) hipLaunchKernelGGL(aog::k_mean_from_parts, dim3((nb + 255) / 256), dim3(256), 0, s, e->syn_part, e->pack_mean, nb, a.n_tiles, e->n_ap);
+      int rc = set_screens_f32(e, e->syn_out, first + done, nb, s, fused_means);
       if (rc != AOG_OK) return rc;
     }
   } else {
