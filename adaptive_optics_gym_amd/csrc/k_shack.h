@@ -252,6 +252,10 @@ __device__ __forceinline__ void sh_fft_b2a(cf32 (&v)[64], float* __restrict__ lb
 }
 
 constexpr int kShFftWaves = 4;
+// the row pass of the separable form keeps the transfer function's L distinct entries in LDS behind the waves' planes (lines of 1024: 8 KB;
+// two workgroups of 66.5 + 8 KB still share a CU)
+template <int RL, int LW> constexpr bool kShHxInLds = RL == 16 && LW == 64;
+template <int RL, int LW> constexpr size_t kShHxLdsBytes = kShHxInLds<RL, LW> ? (size_t)RL * LW * 8 : 0;
 // rows, forward over x:  field [B][N][N] -> F1T [B][L][N]
 // GRID: `field` holds one float per pixel, the phase (atmosphere + mirror + micro-lens) in revolutions reduced to [-1/2, 1/2], or kShOutside
 // (k_phase_mfma<.., true, true>): the field amplitude e^{2 pi i w} is formed here, in registers
@@ -471,6 +475,20 @@ __global__ __launch_bounds__(64 * kShFftWaves, 2) void k_sh_rows_sep(const float
   constexpr int L = LW * RL, N = L / 2, BC = 64 / RL;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int iy0 = (blockIdx.x * kShFftWaves + wave) * BC;
+  // The transfer function's table.  A lane needs 64 entries, hx[lane / BC + RL k2]: fetched where they are used (eight batches of eight, each
+  // awaited in turn) they were eight L2 round trips in the wave's in-order stream — 17 k of its 59 k cycles — and 4 GB of L2 reads per
+  // launch, every wave re-reading the same 32 KB.  The workgroup's copy of the L distinct entries in LDS (kShHxLdsBytes behind the planes,
+  // requested first thing, needed after the forward transform) serves them instead.
+  constexpr bool HX_LDS = kShHxInLds<RL, LW>;
+  cf32* hx_lds = reinterpret_cast<cf32*>(lds_shfft + (size_t)kShFftWaves * 64 * 65);
+  if constexpr (HX_LDS) {
+    static_for<L / (64 * kShFftWaves)>([&](auto uc) {
+      const int en = (int)threadIdx.x + 64 * kShFftWaves * decltype(uc)::v;   // entry p + RL k2 lives at hxq[k2][BC p]
+      const float2 t = hxq[(en / RL) * 64 + BC * (en % RL)];
+      hx_lds[en] = cf32{t.x, t.y};
+    });
+    __syncthreads();
+  }
   if (iy0 >= N) return;
   const int la = min(lane, LW - 1);
   cf32 v[64];
@@ -490,6 +508,10 @@ __global__ __launch_bounds__(64 * kShFftWaves, 2) void k_sh_rows_sep(const float
   });
   float* lbuf = lds_shfft + (size_t)wave * 64 * 65;
   sh_fft_a2b<RL, true, LW>(v, lbuf, tw);
+  if constexpr (HX_LDS) {
+    const cf32* hl = hx_lds + lane / BC;
+    static_for<64>([&](auto kc) { constexpr int k2 = decltype(kc)::v; v[k2] = cmul(v[k2], hl[RL * k2]); });
+  } else {
   const float2* hq = hxq + lane;
   static_for<8>([&](auto gc) {   // (eight table loads at a time, as in k_sh_cols)
     constexpr int g8 = decltype(gc)::v;
@@ -501,6 +523,7 @@ __global__ __launch_bounds__(64 * kShFftWaves, 2) void k_sh_rows_sep(const float
     });
     __builtin_amdgcn_sched_barrier(0);
   });
+  }
   sh_fft_b2a<RL, false, LW>(v, lbuf, tw);
   if (LW == 64 || lane < LW) {
     float2* dst = G1 + (size_t)blockIdx.y * N * N;

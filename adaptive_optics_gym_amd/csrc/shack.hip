@@ -216,14 +216,15 @@ int aog_sh_image(aog_env* e, double* image_dev, void* stream) {
         // separable transfer function: rows (forward, x hx, inverse, keep x < N) then columns (forward, x hy, inverse, keep y < N) over an
         // N x N intermediate (in sh_pad): two passes, 20 N^2 bytes per env instead of three passes and 68 N^2
         float2* G1 = F1T;
-        if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_sh_rows_sep<RL, LW>), lds, e->device)) return rc;
+        const size_t lds_rows = lds + aog::kShHxLdsBytes<RL, LW>;
+        if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_sh_rows_sep<RL, LW>), lds_rows, e->device)) return rc;
         if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_sh_cols_sep<RL, LW, false>), lds, e->device)) return rc;
         if (fused)
           if (int rc = aog_host::ensure_dynamic_lds(reinterpret_cast<const void*>(aog::k_sh_cols_sep<RL, LW, true>), lds_fused, e->device)) return rc;
         const dim3 g1((N / BC + aog::kShFftWaves - 1) / aog::kShFftWaves, e->B);   // pass 1: groups of BC rows; pass 2: groups of BC columns
         {
           TimedRegion tr(e, s, AOG_PROF_SH_ROWS_FWD);
-          hipLaunchKernelGGL((aog::k_sh_rows_sep<RL, LW>), g1, dim3(64 * aog::kShFftWaves), lds, s, reinterpret_cast<const float*>(field), G1, tw,
+          hipLaunchKernelGGL((aog::k_sh_rows_sep<RL, LW>), g1, dim3(64 * aog::kShFftWaves), lds_rows, s, reinterpret_cast<const float*>(field), G1, tw,
                              reinterpret_cast<const float2*>(e->sh_hxq), (float)e->sh_amp);
         }
         TimedRegion tr(e, s, AOG_PROF_SH_COLS);
