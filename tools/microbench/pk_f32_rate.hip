@@ -26,7 +26,10 @@ int main() {
   hipMalloc(&out, 256 * 1024 * 16 * sizeof(float));
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  const int iters = 20000;
+  const int iters = 400000;   // ~10 ms per launch
+  // the device needs a few hundred ms of load to reach its clocks: warm up first (sub-millisecond launches on a cold device read ~2x slow)
+  for (int w = 0; w < 40; ++w) hipLaunchKernelGGL(k<true>, dim3(512), dim3(256), 0, 0, out, iters, 1.0001f, 0.5f);
+  hipDeviceSynchronize();
   for (int waves = 1; waves <= 2; ++waves)
     for (int pk = 0; pk < 2; ++pk) {
       const int grid = 256 * waves;   // 256 CUs x (4 waves = one per SIMD) x waves
