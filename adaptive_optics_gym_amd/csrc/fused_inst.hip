@@ -117,9 +117,10 @@ int AOG_CAT(launch_phase_apad, AOG_INST_APAD)(aog_env* e, hipStream_t s, const _
 int AOG_CAT(launch_phase_field_apad, AOG_INST_APAD)(aog_env* e, hipStream_t s, const _Float16* act16, const aog::PhaseFieldArgs& fa, bool grid) {
   constexpr int A_PAD = AOG_INST_APAD;
   auto kern = grid ? aog::k_phase_mfma<A_PAD, true, true> : aog::k_phase_mfma<A_PAD, true, false>;
-  hipLaunchKernelGGL(kern, dim3((e->n_ptiles + 3) / 4, e->n_etiles), dim3(256), 0, s,
+  const int epw = e->n_etiles >= 8 ? 2 : 1;   // env tiles per wave (k_phase_mfma; measured at 64 env tiles, N = 512: 975 / 875 / 889 / 947 us for 1 / 2 / 4 / 8)
+  hipLaunchKernelGGL(kern, dim3((e->n_ptiles + 3) / 4, (e->n_etiles + epw - 1) / epw), dim3(256), 0, s,
                      reinterpret_cast<const aog::f16x8*>(e->modes16), reinterpret_cast<const aog::f32x4*>(e->psi_tile),
-                     reinterpret_cast<const aog::f16x8*>(act16), static_cast<aog::f32x4*>(nullptr), e->n_ptiles, e->n_etiles, fa);
+                     reinterpret_cast<const aog::f16x8*>(act16), static_cast<aog::f32x4*>(nullptr), e->n_ptiles, e->n_etiles, fa, epw);
   return 0;
 }
 // K4: reduced phases of env tiles [etile0, etile0 + n_et) as one float per pixel on a dense [env][rows][row_stride] grid (no micro-lens term)

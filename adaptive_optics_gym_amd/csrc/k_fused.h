@@ -592,83 +592,108 @@ __global__ __launch_bounds__(512, 2) void k_fused_tab(const f16x8* __restrict__ 
 template <int A_PAD, bool FIELD = false, bool GRID = false>
 __global__ __launch_bounds__(256) void k_phase_mfma(const f16x8* __restrict__ modes16, const f32x4* __restrict__ psi_tile,
                                                     const f16x8* __restrict__ act16, f32x4* __restrict__ out_tile, int n_ptiles,
-                                                    int n_etiles, PhaseFieldArgs fa = PhaseFieldArgs{}) {
+                                                    int n_etiles, PhaseFieldArgs fa = PhaseFieldArgs{}, int etiles_per_wave = 1) {
   constexpr int NSTEP = A_PAD / 16;
   const int lane = threadIdx.x & 63;
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int etile = blockIdx.y;
   __shared__ float2 field_lds[(FIELD && !GRID) ? 4 * 32 * 33 : 1];
   __shared__ float grid_lds[GRID ? 4 * 32 * 33 : 1];   // (GRID: one float per pixel — half the LDS, twice the workgroups per CU)
   [[maybe_unused]] float2* field_tile = field_lds + ((FIELD && !GRID) ? (threadIdx.x >> 6) * 32 * 33 : 0);
   [[maybe_unused]] float* grid_tile = grid_lds + (GRID ? (threadIdx.x >> 6) * 32 * 33 : 0);
-  if (t >= n_ptiles || etile >= n_etiles) return;
-  const f16x8* asrc = act16 + ((size_t)etile * NSTEP * 2) * 64 + lane;
+  const int et0 = blockIdx.y * etiles_per_wave, et1 = min(et0 + etiles_per_wave, n_etiles);
+  if (t >= n_ptiles || et0 >= n_etiles) return;
+  // A wave takes ONE pixel tile through `etiles_per_wave` env tiles: the mode operands are loaded once, and the next env tile's actuator
+  // operands and screen values are requested while this one is reduced and stored (one env tile per wave put both round trips and the wave's
+  // start-up in front of ~1 k cycles of work: 0.95 ms per 2048 envs at N = 512 for 3.4 GB)
   const f16x8* ms = modes16 + ((size_t)t * NSTEP * 2) * 64 + lane;
-  f32x16 d = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  f16x8 mh[NSTEP], ml[NSTEP];
 #pragma unroll
-  for (int s = 0; s < NSTEP; ++s) {
-    const f16x8 mh = ms[(2 * s) * 64], ml = ms[(2 * s + 1) * 64], bh = asrc[(2 * s) * 64], bl = asrc[(2 * s + 1) * 64];
-    d = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh, bh, d, 0, 0, 0);
-    d = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh, bl, d, 0, 0, 0);
-    d = __builtin_amdgcn_mfma_f32_32x32x16_f16(ml, bh, d, 0, 0, 0);
-    if constexpr (GRID) {
-      // K4: the actuators to 33 bits.  A rounding error of an ACTUATOR is a smooth phase error over the whole pupil — it does not average
-      // down over the pixels like the per-pixel rounding of a mode value does — and at 2^-23 of an actuator of half a revolution it was
-      // most of the error of the focal fields (7e-8 of the peak amplitude, the whole tolerance of a pixel 30 dB down)
-      if (fa.act_ll) d = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh, fa.act_ll[((size_t)etile * NSTEP + s) * 64 + lane], d, 0, 0, 0);
-    }
-  }
-  const size_t base = (((size_t)etile * n_ptiles + t) * 4) * 64 + lane;
+  for (int s = 0; s < NSTEP; ++s) { mh[s] = ms[(2 * s) * 64]; ml[s] = ms[(2 * s + 1) * 64]; }
+  f16x8 bh[NSTEP], bl[NSTEP], bhn[NSTEP], bln[NSTEP];
+  f32x4 pc[4], pn[4];
+  auto request = [&](int etile, f16x8 (&ah)[NSTEP], f16x8 (&al)[NSTEP], f32x4 (&pp)[4]) {
+    const f16x8* asrc = act16 + ((size_t)etile * NSTEP * 2) * 64 + lane;
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) { ah[s] = asrc[(2 * s) * 64]; al[s] = asrc[(2 * s + 1) * 64]; }
+    const size_t base = (((size_t)etile * n_ptiles + t) * 4) * 64 + lane;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) pp[g] = psi_tile[base + g * 64];
+  };
+  request(et0, bh, bl, pc);
   [[maybe_unused]] const int h = lane >> 5;
+  // (per-pixel constants of this tile, the same for every env tile)
+  [[maybe_unused]] const int qs = lane & 31, pix_s = t * 32 + qs;
+  [[maybe_unused]] const int yx_s = (FIELD && pix_s < fa.n_ap) ? fa.ap_yx[pix_s] : 0;
+  [[maybe_unused]] const size_t at_s = (size_t)(yx_s >> 16) * fa.row_stride + (yx_s & 0xffff);
+  for (int etile = et0; etile < et1; ++etile) {
+    if (etile + 1 < et1) request(etile + 1, bhn, bln, pn);   // (wave-uniform)
+    f32x16 d = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const f32x4 p = psi_tile[base + g * 64];
-    f32x4 o;
+    for (int s = 0; s < NSTEP; ++s) {
+      d = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[s], bh[s], d, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[s], bl[s], d, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_32x32x16_f16(ml[s], bh[s], d, 0, 0, 0);
+      if constexpr (GRID) {
+        // K4: the actuators to 33 bits.  A rounding error of an ACTUATOR is a smooth phase error over the whole pupil — it does not average
+        // down over the pixels like the per-pixel rounding of a mode value does — and at 2^-23 of an actuator of half a revolution it was
+        // most of the error of the focal fields (7e-8 of the peak amplitude, the whole tolerance of a pixel 30 dB down)
+        if (fa.act_ll) d = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[s], fa.act_ll[((size_t)etile * NSTEP + s) * 64 + lane], d, 0, 0, 0);
+      }
+    }
+    const size_t base = (((size_t)etile * n_ptiles + t) * 4) * 64 + lane;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) o[r] = fmaf(d[4 * g + r], kPhaseUnscale, p[r]);
-    if constexpr (!FIELD) {
-      out_tile[base + g * 64] = o;
-    } else {
-      // this lane's four field values of register group g -> the wave's [32 envs][32 pixels] tile in LDS; written out below with the
-      // lanes along the PIXELS of an env (256 contiguous bytes per env and instruction: 32-byte pieces straight from the accumulator
-      // layout ran the kernel at 1.2 TB/s)
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 p = pc[g];
+      f32x4 o;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int q = 8 * g + 4 * h + r;
-        const int pix = min(t * 32 + q, fa.n_ap - 1);
-        [[maybe_unused]] const int yx = GRID ? 0 : fa.ap_yx[pix], iy = yx >> 16, ix = yx & 0xffff;
-        if constexpr (GRID) {
-          // screen and mirror phase are reduced to a revolution EACH before they are added: their sum then rounds at 2^-25 .. 2^-24 of a
-          // revolution instead of at the ulp of a phase of several revolutions (which was most of the error of the K4 focal fields: 0.93
-          // -> 0.5 of the test tolerance at N = 64, where the image is a speckle field and every pixel's phase error counts)
-          const float dm = d[4 * g + r] * kPhaseUnscale, ps = p[r];
-          const float w = ((ps - rintf(ps)) + (dm - rintf(dm))) + (fa.mla_rev ? fa.mla_rev[pix] : 0.f);   // + the micro-lens phase of this pixel (K4: none)
-          grid_tile[(lane & 31) * 33 + q] = w - rintf(w);
-        } else {
-          float sn, cs;
-          sincospif(2.0f * (o[r] - rintf(o[r])), &sn, &cs);
-          const float2 m = fa.mla32[iy * fa.N + ix];
-          field_tile[(lane & 31) * 33 + q] = make_float2(fa.amplitude * (cs * m.x - sn * m.y), fa.amplitude * (cs * m.y + sn * m.x));
+      for (int r = 0; r < 4; ++r) o[r] = fmaf(d[4 * g + r], kPhaseUnscale, p[r]);
+      if constexpr (!FIELD) {
+        out_tile[base + g * 64] = o;
+      } else {
+        // this lane's four field values of register group g -> the wave's [32 envs][32 pixels] tile in LDS; written out below with the
+        // lanes along the PIXELS of an env (256 contiguous bytes per env and instruction: 32-byte pieces straight from the accumulator
+        // layout ran the kernel at 1.2 TB/s)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int q = 8 * g + 4 * h + r;
+          const int pix = min(t * 32 + q, fa.n_ap - 1);
+          [[maybe_unused]] const int yx = GRID ? 0 : fa.ap_yx[pix], iy = yx >> 16, ix = yx & 0xffff;
+          if constexpr (GRID) {
+            // screen and mirror phase are reduced to a revolution EACH before they are added: their sum then rounds at 2^-25 .. 2^-24 of a
+            // revolution instead of at the ulp of a phase of several revolutions (which was most of the error of the K4 focal fields: 0.93
+            // -> 0.5 of the test tolerance at N = 64, where the image is a speckle field and every pixel's phase error counts)
+            const float dm = d[4 * g + r] * kPhaseUnscale, ps = p[r];
+            const float w = ((ps - rintf(ps)) + (dm - rintf(dm))) + (fa.mla_rev ? fa.mla_rev[pix] : 0.f);   // + the micro-lens phase of this pixel (K4: none)
+            grid_tile[(lane & 31) * 33 + q] = w - rintf(w);
+          } else {
+            float sn, cs;
+            sincospif(2.0f * (o[r] - rintf(o[r])), &sn, &cs);
+            const float2 m = fa.mla32[iy * fa.N + ix];
+            field_tile[(lane & 31) * 33 + q] = make_float2(fa.amplitude * (cs * m.x - sn * m.y), fa.amplitude * (cs * m.y + sn * m.x));
+          }
         }
       }
     }
-  }
-  if constexpr (FIELD) {
-    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the tile is private to the wave
-    __builtin_amdgcn_wave_barrier();
-    const int q = lane & 31, pix = t * 32 + q;
-    if (pix < fa.n_ap) {
-      const int yx = fa.ap_yx[pix];
-      const size_t at = (size_t)(yx >> 16) * fa.row_stride + (yx & 0xffff);
+    if constexpr (FIELD) {
+      __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the tile is private to the wave
+      __builtin_amdgcn_wave_barrier();
+      if (pix_s < fa.n_ap) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const int el = 2 * j + (lane >> 5), env_j = etile * 32 + el;
-        if (env_j < fa.B) {
-          if constexpr (GRID) reinterpret_cast<float*>(fa.field)[(size_t)env_j * fa.env_stride + at] = grid_tile[el * 33 + q];
-          else fa.field[(size_t)env_j * fa.env_stride + at] = field_tile[el * 33 + q];
+        for (int j = 0; j < 16; ++j) {
+          const int el = 2 * j + (lane >> 5), env_j = etile * 32 + el;
+          if (env_j < fa.B) {
+            if constexpr (GRID) reinterpret_cast<float*>(fa.field)[(size_t)env_j * fa.env_stride + at_s] = grid_tile[el * 33 + qs];
+            else fa.field[(size_t)env_j * fa.env_stride + at_s] = field_tile[el * 33 + qs];
+          }
         }
       }
+      __builtin_amdgcn_s_waitcnt(0xc07f);   // (the tile is rewritten by the next env tile)
+      __builtin_amdgcn_wave_barrier();
     }
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) { bh[s] = bhn[s]; bl[s] = bln[s]; }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) pc[g] = pn[g];
   }
 }
 
