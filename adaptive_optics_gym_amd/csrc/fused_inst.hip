@@ -126,10 +126,11 @@ int AOG_CAT(launch_phase_field_apad, AOG_INST_APAD)(aog_env* e, hipStream_t s, c
 // K4: reduced phases of env tiles [etile0, etile0 + n_et) as one float per pixel on a dense [env][rows][row_stride] grid (no micro-lens term)
 int AOG_CAT(launch_phase_grid_apad, AOG_INST_APAD)(aog_env* e, hipStream_t s, const _Float16* act16, const aog::PhaseFieldArgs& fa, int etile0, int n_et) {
   constexpr int A_PAD = AOG_INST_APAD;
-  hipLaunchKernelGGL((aog::k_phase_mfma<A_PAD, true, true>), dim3((e->n_ptiles + 3) / 4, n_et), dim3(256), 0, s,
+  const int epw = n_et >= 8 ? 2 : 1;   // (as launch_phase_field_apad)
+  hipLaunchKernelGGL((aog::k_phase_mfma<A_PAD, true, true>), dim3((e->n_ptiles + 3) / 4, (n_et + epw - 1) / epw), dim3(256), 0, s,
                      reinterpret_cast<const aog::f16x8*>(e->modes16), reinterpret_cast<const aog::f32x4*>(e->psi_tile) + (size_t)etile0 * e->n_ptiles * 4 * 64,
                      reinterpret_cast<const aog::f16x8*>(act16) + (size_t)etile0 * (A_PAD / 16) * 2 * 64, static_cast<aog::f32x4*>(nullptr), e->n_ptiles,
-                     n_et, fa);
+                     n_et, fa, epw);
   return 0;
 }
 }  // namespace aog_host
